@@ -1,0 +1,106 @@
+/* tsim.h — C ABI of the MI355X-native batched tactile-simulation step (libtsim_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of eanswer/TactileSimulation: what its python layer calls on
+ * `redmax_py.Simulation` (pybind11 over the un-vendored DiffRedMax C++) from
+ * envs/redmax_torch_functions.py.  Every entry point below names the reference call it replaces
+ * (paths relative to the reference repo).  Plain pointers and sizes only — no torch types.
+ *
+ * One `tsim_batch` = B independent environments of one model, resident on one GPU.  The reference's
+ * one-environment `Simulation` object is B = 1.  All array arguments are DEVICE pointers of the batch's
+ * real type (float for TSIM_F32, double for TSIM_F64), env-major ([B][dim], C order) unless noted.
+ * `stream` is a hipStream_t (NULL = default stream).  Functions return 0 on success, non-zero on error
+ * (message via tsim_last_error()).  Calls on one batch must be serialised by the caller (the reference's
+ * Simulation is single-threaded as well: algorithms/gd.py:30 torch.set_num_threads(1)).
+ */
+#ifndef TSIM_H
+#define TSIM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsim_batch tsim_batch;
+enum { TSIM_F32 = 0, TSIM_F64 = 1 };
+
+/* redmax.Simulation(model_path)                       envs/redmax_torch_env.py:33
+ * The XML is compiled on the host (tactilesimulation_amd/model/compiler.py) to the flat blob of
+ * include/tsim_blob.h; I / F are HOST pointers.  tape_capacity = max number of recorded sub-steps
+ * between reset() and backward (TactilePush: 100 env-steps x 5 = 500). */
+int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacity, int dtype, int device,
+                      tsim_batch** out);
+void tsim_batch_destroy(tsim_batch* b);
+
+/* sim.ndof_r / ndof_u / ndof_var / ndof_tactile / options.h   envs/redmax_torch_env.py:35-37,
+ * envs/redmax_torch_functions.py:161, envs/tactile_push_env.py:67 */
+int tsim_ndof_r(const tsim_batch* b);
+int tsim_ndof_u(const tsim_batch* b);
+int tsim_ndof_var(const tsim_batch* b);
+int tsim_ndof_tactile(const tsim_batch* b);
+int tsim_batch_size(const tsim_batch* b);
+int tsim_dtype(const tsim_batch* b);
+double tsim_timestep(const tsim_batch* b);
+int tsim_tape_len(const tsim_batch* b);          /* recorded sub-steps since the last reset */
+
+/* update_* model edits (envs/dclaw_rotate_env.py:173-178, envs/tactile_insertion_env.py:254-279,
+ * envs/stable_grasp_env.py:122): the host recompiles the blob and re-uploads it.  Topology (counts,
+ * offsets) must be unchanged. */
+int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* stream);
+
+/* sim.set_state_init(q, qdot) + sim.reset(backward_flag)      envs/redmax_torch_functions.py:39-41,
+ * envs/tactile_push_env.py:138,154.  q0 / qd0: [B][ndof_r].  Restarts the tape and zeroes the carried
+ * adjoint. */
+int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag, void* stream);
+
+/* sim.set_u(u); sim.forward(num_steps, ...); sim.get_q(); sim.get_variables();
+ * sim.get_tactile_force_vector()                               envs/redmax_torch_functions.py:131-136
+ * (and :48-57 with num_steps = 1).  u: [B][ndof_u], held for num_steps implicit sub-steps.
+ * Outputs (any may be NULL): q_out, qd_out [B][ndof_r]; var_out [B][ndof_var]; tac_out [B][ndof_tactile]
+ * (taxel-major: shear0, shear1, normal); status [B] int32 = number of sub-steps whose Newton solve did not
+ * reach tol (bit 30 set if a non-finite value appeared). */
+int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd_out, void* var_out,
+              void* tac_out, int32_t* status, void* stream);
+
+/* sim.get_q() / get_qdot() / get_variables() / get_tactile_force_vector() at the current state, e.g.
+ * right after reset (envs/tactile_push_env.py:157). */
+int tsim_get_state(tsim_batch* b, void* q_out, void* qd_out, void* stream);
+int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream);
+
+/* backward_info.set_flags / df_dq / df_dvar / df_dtactile; sim.backward_steps(n);
+ * backward_results.df_du                                       envs/redmax_torch_functions.py:151-170
+ * Adjoint of the newest n recorded sub-steps, newest first, continuing the adjoint carried from earlier
+ * calls; pops them from the tape.
+ *   seed_mode 0: df_dq [B][ndof_r], df_dvar [B][ndof_var], df_dtac [B][ndof_tactile] are the partials w.r.t.
+ *                the outputs after the LAST of the n sub-steps (what StepSimFunction.backward builds by
+ *                zero-padding, :153-163);
+ *   seed_mode 1: [B][n][dim], step-major, oldest first (the general layout of the reference).
+ * Any seed pointer may be NULL (= zeros).  df_du: [B][n][ndof_u], oldest first (reshape(num_steps, ndof_u)
+ * at :170). */
+int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, const void* df_dvar,
+                        const void* df_dtac, void* df_du, void* stream);
+
+/* sim.backward() results df_dq0 / df_dqdot0                    envs/redmax_torch_functions.py:92-100
+ * = the carried adjoint once the whole tape has been popped. [B][ndof_r] each. */
+int tsim_get_adjoint(tsim_batch* b, void* df_dq0, void* df_dqd0, void* stream);
+
+/* sim.saveBackwardCache() / popBackwardCache() / clearBackwardCache()
+ *                                     envs/redmax_torch_functions.py:65,81; envs/tactile_insertion_env.py:226
+ * LIFO of tapes so that several episodes can be forwarded before their backwards. */
+int tsim_cache_save(tsim_batch* b, void* stream);
+int tsim_cache_pop(tsim_batch* b, void* stream);
+int tsim_cache_clear(tsim_batch* b);
+
+/* Diagnostics (no reference counterpart): one residual evaluation g(q1; q0, qd0, u) and its Newton matrix
+ * H = dg/dq1 for env 0..B-1; g_out [B][nr], H_out [B][nr][nr] (row-major). Used by the parity tests. */
+int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u,
+                    void* g_out, void* H_out, void* stream);
+
+/* launch statistics of the most recent kernels (HIP events are the caller's business; this only reports
+ * static launch geometry): out[0] = LDS bytes per block, out[1] = threads per block, out[2] = blocks. */
+int tsim_launch_info(const tsim_batch* b, int32_t* out);
+
+const char* tsim_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,304 @@
+// tsim_eval.h — one residual evaluation g(q1) with its exact tangents, and the small dense solve.
+// See tsim_device.h for the execution model.  Reference counterpart: the per-sub-step Newton body behind
+// `sim.forward()` (envs/redmax_torch_functions.py:132); formulation in DESIGN.md §Physics.
+#pragma once
+#include "tsim_device.h"
+
+// ================================================================================================ phase 1
+// lanes = directions.  Lane k < nr walks the links root->leaf with dual numbers seeded on dof k:
+//   q_k += eps*sq, qd_k += eps*sv, qdd_k += eps*sa.
+// Writes per link: pose, spatial velocity / acceleration, inertial wrench (value by lane 0, tangent k by
+// lane k) and the world-frame twist columns W of the link's dofs.
+template <class R>
+__device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+  typedef Du<R> D;
+  const int nd = c.nd, k = lane;
+  const bool act = lane < c.nr;
+  const bool wp = lane == 0;
+  for (int i = 1; i <= c.nl; ++i) {
+    if (act) {
+      const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
+      const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
+      const int par = li[TSIM_LI_PARENT], jt = li[TSIM_LI_JTYPE], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
+      const int pb = par * LK_SIZE, xb = i * LK_SIZE;
+      M3<D> XR; V3<D> Xp;
+      // joint twist V_J = sum W_k qd_k and the qdd part sum W_k qdd_k, accumulated while the columns are built
+      V3<D> jw = mk3<D>(D(R(0)), D(R(0)), D(R(0))), jv = jw, bw = jw, bv = jw;
+      {
+        M3<D> PR = ld9<D>(c.LP, c.LT, pb + LK_R, nd, k);
+        V3<D> Pp = ld3<D>(c.LP, c.LT, pb + LK_P, nd, k);
+        M3<D> R0 = mulMcM(PR, lf + TSIM_LF_R);
+        V3<D> p0 = mulMc(PR, lf + TSIM_LF_P) + Pp;
+        const R* ax = lf + TSIM_LF_AXES;
+        if (jt == TSIM_J_REVOLUTE) {
+          D th(c.q[k0], k == k0 ? sq : R(0));
+          D s, co; t_sincos(th, s, co);
+          D t = D(R(1)) - co;
+          M3<D> Q;
+          Q.m[0] = t * (ax[0] * ax[0]) + co;         Q.m[1] = t * (ax[0] * ax[1]) - s * ax[2];  Q.m[2] = t * (ax[0] * ax[2]) + s * ax[1];
+          Q.m[3] = t * (ax[0] * ax[1]) + s * ax[2];  Q.m[4] = t * (ax[1] * ax[1]) + co;         Q.m[5] = t * (ax[1] * ax[2]) - s * ax[0];
+          Q.m[6] = t * (ax[0] * ax[2]) - s * ax[1];  Q.m[7] = t * (ax[1] * ax[2]) + s * ax[0];  Q.m[8] = t * (ax[2] * ax[2]) + co;
+          XR = mulMM(R0, Q); Xp = p0;
+          V3<D> a = mulMc(R0, ax);          // the axis is invariant under its own rotation
+          V3<D> av = cross3(Xp, a);
+          st3(c.WP, c.WT, k0 * 6, nd, k, wp, a);
+          st3(c.WP, c.WT, k0 * 6 + 3, nd, k, wp, av);
+          D qd(c.qd[k0], k == k0 ? sv : R(0)), qa(c.qa[k0], k == k0 ? sa : R(0));
+          jw = a * qd; jv = av * qd; bw = a * qa; bv = av * qa;
+        } else {  // prismatic / planar / translational: pure translations along constant joint-frame axes
+          XR = R0; Xp = p0;
+          for (int kk = 0; kk < ndj; ++kk) {
+            R e[3] = {kk == 0 ? R(1) : R(0), kk == 1 ? R(1) : R(0), kk == 2 ? R(1) : R(0)};
+            V3<D> a = mulMc(R0, jt == TSIM_J_TRANSLATIONAL ? e : ax + 3 * kk);
+            const int kd = k0 + kk;
+            D qk(c.q[kd], k == kd ? sq : R(0));
+            Xp = Xp + a * qk;
+            st3(c.WP, c.WT, kd * 6, nd, k, wp, mk3<D>(D(R(0)), D(R(0)), D(R(0))));
+            st3(c.WP, c.WT, kd * 6 + 3, nd, k, wp, a);
+            D qd(c.qd[kd], k == kd ? sv : R(0)), qa(c.qa[kd], k == kd ? sa : R(0));
+            jv = jv + a * qd; bv = bv + a * qa;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 9; ++e) st(c.LP, c.LT, xb + LK_R + e, nd, k, wp, XR.m[e]);
+      st3(c.LP, c.LT, xb + LK_P, nd, k, wp, Xp);
+      // V_i = V_p + V_J ;  A_i = A_p + sum W_k qdd_k + V_i x^ V_J   (constant joint-frame S)
+      V3<D> Xw = ld3<D>(c.LP, c.LT, pb + LK_W, nd, k) + jw;
+      V3<D> Xv = ld3<D>(c.LP, c.LT, pb + LK_V, nd, k) + jv;
+      V3<D> Xaw = ld3<D>(c.LP, c.LT, pb + LK_AW, nd, k) + bw + cross3(Xw, jw);
+      V3<D> Xav = ld3<D>(c.LP, c.LT, pb + LK_AV, nd, k) + bv + cross3(Xw, jv) + cross3(Xv, jw);
+      st3(c.LP, c.LT, xb + LK_W, nd, k, wp, Xw);
+      st3(c.LP, c.LT, xb + LK_V, nd, k, wp, Xv);
+      st3(c.LP, c.LT, xb + LK_AW, nd, k, wp, Xaw);
+      st3(c.LP, c.LT, xb + LK_AV, nd, k, wp, Xav);
+      // inertial wrench about the world origin
+      V3<D> cw = mulMc(XR, lf + TSIM_LF_COM) + Xp;
+      V3<D> vc = Xv + cross3(Xw, cw);
+      V3<D> ac = Xav + cross3(Xaw, cw) + cross3(Xw, vc);
+      V3<D> f = ac * D(lf[TSIM_LF_MASS]);
+      const R* ii = lf + TSIM_LF_INERTIA;
+      V3<D> wl = mulMtv(XR, Xw), al = mulMtv(XR, Xaw);
+      V3<D> Iw = mk3<D>(wl.x * ii[0] + wl.y * ii[3] + wl.z * ii[4], wl.x * ii[3] + wl.y * ii[1] + wl.z * ii[5], wl.x * ii[4] + wl.y * ii[5] + wl.z * ii[2]);
+      V3<D> Ia = mk3<D>(al.x * ii[0] + al.y * ii[3] + al.z * ii[4], al.x * ii[3] + al.y * ii[1] + al.z * ii[5], al.x * ii[4] + al.y * ii[5] + al.z * ii[2]);
+      V3<D> nc = mulMv(XR, Ia + cross3(wl, Iw));
+      st3(c.LP, c.LT, xb + LK_FF, nd, k, wp, f);
+      st3(c.LP, c.LT, xb + LK_FN, nd, k, wp, nc + cross3(cw, f));
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================================================ phase 2
+// lanes = contact points.  For every dynamics-active pair: value pass (which points penetrate, value
+// wrench), then one dual pass per relevant direction; wave butterfly sums; lane 0 folds the pair's wrench
+// into link A (minus) and link B (plus).
+// Force on a point fixed to link A (link-frame coordinates xa) against the primitive of a pair fixed to link B.
+// kp = {kn, kt, mu, kd}.  Link quantities are passed by value so that callers choose where tangents come from.
+template <class T, class R>
+__device__ __forceinline__ bool point_force(int prim, const R* pf, const R* kp, bool sphere_plane, const M3<T>& RA, V3<T> pA,
+                                            V3<T> wA, V3<T> vA, const M3<T>& RB, V3<T> pB, V3<T> wB, V3<T> vB, V3<R> xa,
+                                            V3<T>& Fw, V3<T>& xw) {
+  M3<T> RP = mulMcM(RB, pf + TSIM_PF_R);
+  V3<T> pP = mulMc(RB, pf + TSIM_PF_P) + pB;
+  R xac[3] = {xa.x, xa.y, xa.z};
+  xw = mulMc(RA, xac) + pA;
+  if (sphere_plane) xw = xw - mk3<T>(RP.m[2], RP.m[5], RP.m[8]) * T(pf[TSIM_PF_SHAPE]);
+  V3<T> vrel = (vA + cross3(wA, xw)) - (vB + cross3(wB, xw));
+  return contact_law<T, R>(prim, pf + TSIM_PF_SHAPE, kp[0], kp[1], kp[2], kp[3], RP, pP, xw, vrel, Fw);
+}
+// same, link quantities (value + tangent of direction dir) read from LDS
+template <class T, class R>
+__device__ __forceinline__ bool pair_point_force(const Ctx<R>& c, const int* pi, const R* pf, const R* kp, int la, int lb, int dir,
+                                                 V3<R> xa, bool sphere_plane, V3<T>& Fw, V3<T>& mo) {
+  const int nd = c.nd, ab = la * LK_SIZE, bb = lb * LK_SIZE;
+  M3<T> RA = ld9<T>(c.LP, c.LT, ab + LK_R, nd, dir);
+  M3<T> RB = ld9<T>(c.LP, c.LT, bb + LK_R, nd, dir);
+  V3<T> xw;
+  bool hit = point_force<T, R>(pi[TSIM_PI_PRIM], pf, kp, sphere_plane, RA, ld3<T>(c.LP, c.LT, ab + LK_P, nd, dir),
+                               ld3<T>(c.LP, c.LT, ab + LK_W, nd, dir), ld3<T>(c.LP, c.LT, ab + LK_V, nd, dir), RB,
+                               ld3<T>(c.LP, c.LT, bb + LK_P, nd, dir), ld3<T>(c.LP, c.LT, bb + LK_W, nd, dir),
+                               ld3<T>(c.LP, c.LT, bb + LK_V, nd, dir), xa, Fw, xw);
+  if (hit) mo = cross3(xw, Fw);
+  return hit;
+}
+
+template <class R>
+__device__ void phase2(const Ctx<R>& c, int lane) {
+  typedef Du<R> D;
+  const int nd = c.nd;
+  for (int pk = 0; pk < c.npair; ++pk) {
+    const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+    const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+    const int flags = pi[TSIM_PI_FLAGS];
+    if (!(flags & 1)) continue;
+    const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB], pt0 = pi[TSIM_PI_PT0], npt = pi[TSIM_PI_NPT];
+    const int ancA = la > 0 ? c.I[c.off_link + (la - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
+    const int ancB = lb > 0 ? c.I[c.off_link + (lb - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
+    const int anc = ancA | ancB;
+    for (int base = 0; base < npt; base += TS_WAVE) {
+      const int pidx = base + lane;
+      const bool valid = pidx < npt;
+      V3<R> xa = mk3<R>(R(0), R(0), R(0));
+      if (valid) {
+        const R* cp = c.F + c.foff_cpt + pt0 + pidx;    // SoA: consecutive lanes -> consecutive addresses
+        xa = mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt]);
+      }
+      V3<R> F0 = mk3<R>(R(0), R(0), R(0)), M0 = F0;
+      bool hit = false;
+      if (valid) {
+        V3<R> Fw, mo;
+        hit = pair_point_force<R, R>(c, pi, pf, pf + TSIM_PF_KN, la, lb, 0, xa, (flags & 2) != 0, Fw, mo);
+        if (hit) { F0 = Fw; M0 = mo; }
+      }
+      if (!__any(hit)) continue;
+      R s0 = wave_sum(M0.x), s1 = wave_sum(M0.y), s2 = wave_sum(M0.z), s3 = wave_sum(F0.x), s4 = wave_sum(F0.y), s5 = wave_sum(F0.z);
+      if (lane == 0) {
+        R* a = c.LP + la * LK_SIZE + LK_FN;
+        a[0] -= s0; a[1] -= s1; a[2] -= s2; a[3] -= s3; a[4] -= s4; a[5] -= s5;
+        if (lb > 0) { R* b = c.LP + lb * LK_SIZE + LK_FN; b[0] += s0; b[1] += s1; b[2] += s2; b[3] += s3; b[4] += s4; b[5] += s5; }
+      }
+      for (int dir = 0; dir < nd; ++dir) {
+        if (!((anc >> dir) & 1)) continue;
+        V3<D> Fw, mo;
+        R t0 = R(0), t1 = R(0), t2 = R(0), t3 = R(0), t4 = R(0), t5 = R(0);
+        if (hit) {
+          if (pair_point_force<D, R>(c, pi, pf, pf + TSIM_PF_KN, la, lb, dir, xa, (flags & 2) != 0, Fw, mo)) {
+            t0 = mo.x.d; t1 = mo.y.d; t2 = mo.z.d; t3 = Fw.x.d; t4 = Fw.y.d; t5 = Fw.z.d;
+          }
+        }
+        t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); t3 = wave_sum(t3); t4 = wave_sum(t4); t5 = wave_sum(t5);
+        if (lane == 0) {
+          R* a = c.LT + (la * LK_SIZE + LK_FN) * nd + dir;
+          a[0] -= t0; a[nd] -= t1; a[2 * nd] -= t2; a[3 * nd] -= t3; a[4 * nd] -= t4; a[5 * nd] -= t5;
+          if (lb > 0) {
+            R* b = c.LT + (lb * LK_SIZE + LK_FN) * nd + dir;
+            b[0] += t0; b[nd] += t1; b[2 * nd] += t2; b[3 * nd] += t3; b[4 * nd] += t4; b[5 * nd] += t5;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ================================================================================================ phase 3
+// lanes = directions.  Leaf -> root: tau_j = W_j . F_subtree(link(j)); fold each link's wrench into its
+// parent; then the joint-space forces.  Result: g (value, LDS) and H[j][k] = d g_j / d dir_k (lane k owns
+// column k).  Both are scaled by h^2.
+template <class R>
+__device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
+  typedef Du<R> D;
+  const int nd = c.nd, k = lane, nr = c.nr;
+  const bool act = lane < nr;
+  const R h2 = c.h * c.h;
+  for (int i = c.nl; i >= 1; --i) {
+    const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
+    const int par = li[TSIM_LI_PARENT], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
+    if (act) {
+      V3<D> fn = ld3<D>(c.LP, c.LT, i * LK_SIZE + LK_FN, nd, k), ff = ld3<D>(c.LP, c.LT, i * LK_SIZE + LK_FF, nd, k);
+      for (int j = k0; j < k0 + ndj; ++j) {
+        V3<D> Ww = ld3<D>(c.WP, c.WT, j * 6, nd, k), Wv = ld3<D>(c.WP, c.WT, j * 6 + 3, nd, k);
+        D tau = dot3(Ww, fn) + dot3(Wv, ff);
+        if (lane == 0) c.g[j] = tau.v;
+        c.H[j * nr + k] = tau.d;
+      }
+      if (par > 0) {
+        R* pt = c.LT + (par * LK_SIZE + LK_FN) * nd + k;
+        pt[0] += fn.x.d; pt[nd] += fn.y.d; pt[2 * nd] += fn.z.d; pt[3 * nd] += ff.x.d; pt[4 * nd] += ff.y.d; pt[5 * nd] += ff.z.d;
+        if (lane == 0) {
+          R* pp = c.LP + par * LK_SIZE + LK_FN;
+          pp[0] += fn.x.v; pp[1] += fn.y.v; pp[2] += fn.z.v; pp[3] += ff.x.v; pp[4] += ff.y.v; pp[5] += ff.z.v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // joint-space forces: damping, limits (lanes = dofs), then motors
+  if (act) {
+    const int j = lane;
+    const R* df = c.F + c.foff_dof + j * TSIM_DF_SIZE;
+    R gj = c.g[j], hjj = c.H[j * nr + j];
+    gj += df[TSIM_DF_DAMPING] * c.qd[j]; hjj += df[TSIM_DF_DAMPING] * sv;
+    if (df[TSIM_DF_LIM_K] > R(0)) {
+      if (c.q[j] < df[TSIM_DF_LIM_LO]) { gj -= df[TSIM_DF_LIM_K] * (df[TSIM_DF_LIM_LO] - c.q[j]); hjj += df[TSIM_DF_LIM_K] * sq; }
+      else if (c.q[j] > df[TSIM_DF_LIM_HI]) { gj += df[TSIM_DF_LIM_K] * (c.q[j] - df[TSIM_DF_LIM_HI]); hjj += df[TSIM_DF_LIM_K] * sq; }
+    }
+    for (int m = 0; m < c.nu; ++m) {
+      const int* mi = c.I + c.off_motor + m * TSIM_MI_SIZE;
+      if (mi[TSIM_MI_DOF] != j) continue;
+      const R* mf = c.F + c.foff_motor + m * TSIM_MF_SIZE;
+      if (mi[TSIM_MI_CTRL] == 0) {
+        R uc = fmin(fmax(c.u[m], R(-1)), R(1));
+        gj -= mf[TSIM_MF_LO] + (uc + R(1)) * (R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]));
+      } else {
+        gj -= mf[TSIM_MF_P] * (c.u[m] - c.q[j]) - mf[TSIM_MF_D] * c.qd[j];
+        hjj += mf[TSIM_MF_P] * sq + mf[TSIM_MF_D] * sv;
+      }
+    }
+    c.g[j] = gj; c.H[j * nr + j] = hjj;
+  }
+  __syncthreads();
+  for (int e = lane; e < nr * nr; e += TS_WAVE) c.H[e] *= h2;
+  if (act) c.g[lane] *= h2;
+  __syncthreads();
+}
+
+// full evaluation at the trial q held in c.q (with c.q0, c.qd0, c.u): fills c.qd, c.qa, link state, g, H.
+// forward seeds: (1, 1/h, 1/h^2) -> H = dg/dq1 ;  adjoint seeds: (1, 0, 0) -> H = h^2 dr/dq.
+template <class R>
+__device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+  if (lane < c.nr) {
+    R d = c.q[lane] - c.q0[lane];
+    c.qd[lane] = d / c.h;
+    c.qa[lane] = (d - c.h * c.qd0[lane]) / (c.h * c.h);
+  }
+  __syncthreads();
+  phase1(c, lane, sq, sv, sa);
+  phase2(c, lane);
+  phase3(c, lane, sq, sv);
+}
+
+// ================================================================================================ dense solve
+// Gauss-Jordan with partial pivoting, one matrix row per lane held in registers (fp64 regardless of R),
+// pivot rows broadcast with wave shuffles.  Solves A x = b (or A^T x = b), n <= NRM <= 16.
+template <class R, int NRM>
+__device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane) {
+  double a[NRM], rb = 0.0;
+#pragma unroll
+  for (int j = 0; j < NRM; ++j) {
+    double v = (j == lane) ? 1.0 : 0.0;
+    if (lane < n && j < n) v = (double)(transpose ? A[j * n + lane] : A[lane * n + j]);
+    a[j] = v;
+  }
+  if (lane < n) rb = (double)b[lane];
+  bool done = false; int mycol = -1; double mypiv = 1.0;
+#pragma unroll
+  for (int col = 0; col < NRM; ++col) {
+    if (col < n) {
+      double mag = (!done && lane < n) ? fabs(a[col]) : -1.0;
+      int idx = lane;
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        double om = __shfl_xor(mag, o, TS_WAVE); int oi = __shfl_xor(idx, o, TS_WAVE);
+        if (om > mag || (om == mag && oi < idx)) { mag = om; idx = oi; }
+      }
+      const int p = __shfl(idx, 0, TS_WAVE);
+      const double piv = __shfl(a[col], p, TS_WAVE);
+      const double f = (lane != p) ? a[col] / piv : 0.0;
+#pragma unroll
+      for (int j = 0; j < NRM; ++j) {
+        if (j >= col) { double pj = __shfl(a[j], p, TS_WAVE); a[j] -= f * pj; }
+      }
+      double pb = __shfl(rb, p, TS_WAVE); rb -= f * pb;
+      if (lane == p) { done = true; mycol = col; mypiv = piv; }
+    }
+  }
+  if (lane < n && mycol >= 0) x[mycol] = (R)(rb / mypiv);
+  __syncthreads();
+}
+
+template <class R> __device__ __forceinline__ R block_norm2(const R* v, int n, int lane) {
+  R s = lane < n ? v[lane] * v[lane] : R(0);
+  return t_sqrt(wave_sum(s));
+}

@@ -1,0 +1,157 @@
+"""BatchSim — B environments of one model resident on one MI355X, driven through the C ABI (include/tsim.h).
+
+Device memory, streams and dtype plumbing come from PyTorch-ROCm; all simulation arithmetic runs in the
+hand-written HIP kernels (tactilesimulation_amd/csrc). Host-side mirror of the stepping/adjoint part of the
+reference's `redmax_py.Simulation`, batched.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from ..model.compiler import CompiledModel, load_model
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BatchSim:
+    def __init__(self, model, batch_size, device="cuda:0", dtype=torch.float32, tape_capacity=512):
+        if isinstance(model, str):
+            model = load_model(model)
+        assert isinstance(model, CompiledModel)
+        self.model = model
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BatchSim needs a GPU device (got %s); the HIP path has no CPU fallback" % device)
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("dtype must be float32 or float64")
+        self.dtype = dtype
+        self.B = int(batch_size)
+        self.tape_capacity = int(tape_capacity)
+        L = capi.lib()
+        self._I = np.ascontiguousarray(model.I, dtype=np.int32)
+        self._F = np.ascontiguousarray(model.F, dtype=np.float64)
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        capi.check(L.tsim_batch_create(self._I.ctypes.data_as(capi._ip), self._F.ctypes.data_as(C.POINTER(C.c_double)), self.B,
+                                       self.tape_capacity, capi.TSIM_F32 if dtype == torch.float32 else capi.TSIM_F64, idx,
+                                       C.byref(h)))
+        self._h = h
+        self.ndof_r, self.ndof_u = L.tsim_ndof_r(h), L.tsim_ndof_u(h)
+        self.ndof_var, self.ndof_tactile = L.tsim_ndof_var(h), L.tsim_ndof_tactile(h)
+        self.h = L.tsim_timestep(h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                capi.lib().tsim_batch_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t, dim, name):
+        if t is None:
+            return None
+        if t.device != self.device or t.dtype != self.dtype:
+            t = t.to(device=self.device, dtype=self.dtype)
+        t = t.contiguous()
+        if t.numel() != self.B * dim:
+            raise ValueError("%s: expected %d x %d values, got shape %s" % (name, self.B, dim, tuple(t.shape)))
+        return t
+
+    def empty(self, *dims):
+        return torch.empty((self.B,) + dims, device=self.device, dtype=self.dtype)
+
+    # ------------------------------------------------------------------ stepping
+    def update_model(self, model):
+        self.model = model
+        self._I = np.ascontiguousarray(model.I, dtype=np.int32)
+        self._F = np.ascontiguousarray(model.F, dtype=np.float64)
+        capi.check(capi.lib().tsim_update_model(self._h, self._I.ctypes.data_as(capi._ip),
+                                                self._F.ctypes.data_as(C.POINTER(C.c_double)), self._stream()))
+
+    def reset(self, q0, qd0=None, backward_flag=False):
+        q0 = self._chk(q0, self.ndof_r, "q0")
+        qd0 = self._chk(qd0, self.ndof_r, "qd0")
+        capi.check(capi.lib().tsim_reset(self._h, _ptr(q0), _ptr(qd0), int(bool(backward_flag)), self._stream()))
+
+    def step(self, u, num_steps=1, want_qd=False, want_var=True, want_tactile=True, out=None):
+        """One env-step for all B environments. Returns dict(q, qd, var, tactile, status)."""
+        u = self._chk(u, self.ndof_u, "u")
+        o = out if out is not None else {}
+        if "q" not in o:
+            o["q"] = self.empty(self.ndof_r)
+        if want_qd and "qd" not in o:
+            o["qd"] = self.empty(self.ndof_r)
+        if want_var and self.ndof_var and "var" not in o:
+            o["var"] = self.empty(self.ndof_var)
+        if want_tactile and self.ndof_tactile and "tactile" not in o:
+            o["tactile"] = self.empty(self.ndof_tactile)
+        if "status" not in o:
+            o["status"] = torch.empty(self.B, device=self.device, dtype=torch.int32)
+        capi.check(capi.lib().tsim_step(self._h, _ptr(u), int(num_steps), _ptr(o["q"]), _ptr(o.get("qd")), _ptr(o.get("var")),
+                                        _ptr(o.get("tactile")), _ptr(o["status"]), self._stream()))
+        return o
+
+    def get_state(self):
+        q, qd = self.empty(self.ndof_r), self.empty(self.ndof_r)
+        capi.check(capi.lib().tsim_get_state(self._h, _ptr(q), _ptr(qd), self._stream()))
+        return q, qd
+
+    def readout(self, want_var=True, want_tactile=True):
+        var = self.empty(self.ndof_var) if (want_var and self.ndof_var) else None
+        tac = self.empty(self.ndof_tactile) if (want_tactile and self.ndof_tactile) else None
+        if var is not None or tac is not None:
+            capi.check(capi.lib().tsim_readout(self._h, _ptr(var), _ptr(tac), self._stream()))
+        return var, tac
+
+    # ------------------------------------------------------------------ adjoint
+    def backward_steps(self, n, df_dq=None, df_dvar=None, df_dtactile=None, all_steps=False):
+        """Adjoint of the newest n recorded sub-steps. Seeds are [B, dim] (last sub-step only) or, with
+        all_steps=True, [B, n, dim]. Returns df_du [B, n, ndof_u]."""
+        mul = n if all_steps else 1
+        a = self._chk(df_dq, mul * self.ndof_r, "df_dq")
+        b = self._chk(df_dvar, mul * self.ndof_var, "df_dvar") if self.ndof_var else None
+        c = self._chk(df_dtactile, mul * self.ndof_tactile, "df_dtactile") if self.ndof_tactile else None
+        du = self.empty(n, self.ndof_u)
+        capi.check(capi.lib().tsim_backward_steps(self._h, int(n), int(bool(all_steps)), _ptr(a), _ptr(b), _ptr(c), _ptr(du),
+                                                  self._stream()))
+        return du
+
+    def get_adjoint(self):
+        a, b = self.empty(self.ndof_r), self.empty(self.ndof_r)
+        capi.check(capi.lib().tsim_get_adjoint(self._h, _ptr(a), _ptr(b), self._stream()))
+        return a, b
+
+    def tape_len(self):
+        return capi.lib().tsim_tape_len(self._h)
+
+    def cache_save(self):
+        capi.check(capi.lib().tsim_cache_save(self._h, self._stream()))
+
+    def cache_pop(self):
+        capi.check(capi.lib().tsim_cache_pop(self._h, self._stream()))
+
+    def cache_clear(self):
+        capi.check(capi.lib().tsim_cache_clear(self._h))
+
+    # ------------------------------------------------------------------ diagnostics
+    def debug_eval(self, q1, q0, qd0, u):
+        q1, q0, qd0 = (self._chk(x, self.ndof_r, "q") for x in (q1, q0, qd0))
+        u = self._chk(u, self.ndof_u, "u")
+        g, H = self.empty(self.ndof_r), self.empty(self.ndof_r, self.ndof_r)
+        capi.check(capi.lib().tsim_debug_eval(self._h, _ptr(q1), _ptr(q0), _ptr(qd0), _ptr(u), _ptr(g), _ptr(H), self._stream()))
+        return g, H
+
+    def launch_info(self):
+        out = (C.c_int32 * 3)()
+        capi.lib().tsim_launch_info(self._h, out)
+        return {"lds_bytes": out[0], "threads": out[1], "blocks": out[2]}

@@ -1,0 +1,54 @@
+"""ctypes binding of the C ABI in include/tsim.h (libtsim_hip.so, built in-tree by __graft_entry__.build()).
+
+There is NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
+LIB_PATH = os.path.abspath(os.path.join(_DIR, "libtsim_hip.so"))
+_lib = None
+
+TSIM_F32, TSIM_F64 = 0, 1
+_vp, _ip = C.c_void_p, C.POINTER(C.c_int32)
+
+_SIGS = {
+    "tsim_batch_create": (C.c_int, [_ip, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tsim_batch_destroy": (None, [_vp]),
+    "tsim_ndof_r": (C.c_int, [_vp]), "tsim_ndof_u": (C.c_int, [_vp]), "tsim_ndof_var": (C.c_int, [_vp]),
+    "tsim_ndof_tactile": (C.c_int, [_vp]), "tsim_batch_size": (C.c_int, [_vp]), "tsim_dtype": (C.c_int, [_vp]),
+    "tsim_timestep": (C.c_double, [_vp]), "tsim_tape_len": (C.c_int, [_vp]),
+    "tsim_update_model": (C.c_int, [_vp, _ip, C.POINTER(C.c_double), _vp]),
+    "tsim_reset": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "tsim_step": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_get_state": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "tsim_readout": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "tsim_backward_steps": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_get_adjoint": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "tsim_cache_save": (C.c_int, [_vp, _vp]), "tsim_cache_pop": (C.c_int, [_vp, _vp]), "tsim_cache_clear": (C.c_int, [_vp]),
+    "tsim_debug_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_launch_info": (C.c_int, [_vp, _ip]),
+    "tsim_last_error": (C.c_char_p, []),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def lib():
+    """Load libtsim_hip.so (after torch, so that both share one HIP runtime)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'`). There is no CPU fallback." % LIB_PATH)
+        import torch  # noqa: F401  (loads libamdhip64 first)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("tsim: " + lib().tsim_last_error().decode())

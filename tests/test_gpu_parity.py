@@ -1,0 +1,138 @@
+"""HIP path vs the fp64 CPU oracle on identical inputs (TactilePush model). Calls go through the C ABI
+(include/tsim.h) via tactilesimulation_amd.host.BatchSim. PARITY UNPINNED w.r.t. the reference itself (its
+simulator source is absent) — the oracle is this build's restatement, see oracle/tsim_oracle.cpp.
+
+Tolerances (stated per test): fp64 kernels must agree with the oracle to round-off; fp32 kernels to the fp32
+tolerance of DESIGN.md §Precision.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.workloads import push_workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_tol(model, tol):
+    """Copy of the model with the Newton tolerance overridden. The <solver_option tol> of the XML (1e-8 on ||g||) is
+    loose enough that two correct solvers may stop one iteration apart; round-off-level parity is therefore
+    checked with a tight tolerance, and default-tolerance parity with a solver-tolerance bound."""
+    import copy
+    import tactilesimulation_amd.model.blob as B
+    m = copy.copy(model)
+    m.F = model.F.copy()
+    m.F[B.TSIM_FH_TOL] = tol
+    return m
+
+
+def _oracle(model):
+    from oracle.oracle import OracleSim
+    return OracleSim(model)
+
+
+def _batch(model, B, dtype, cap=64):
+    from tactilesimulation_amd.host.batch import BatchSim
+    return BatchSim(model, B, device="cuda:0", dtype=dtype, tape_capacity=cap)
+
+
+def _contact_states(model, n):
+    """n states in contact, generated with the oracle: (q1 trial, q0, qd0, u)."""
+    o = _oracle(model)
+    q0s, us, _ = push_workload(n, 12, seed=3)
+    out = []
+    for e in range(n):
+        o.reset(q0s[e])
+        for t in range(6 + e % 6):
+            o.forward(us[e, t], 5)
+        q, qd = o.state()
+        out.append((q + model.h * qd * (1.0 + 0.1 * e), q, qd, us[e, 11]))
+    return out
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 2e-3)])
+def test_residual_and_newton_matrix(pusher_model, dtype, tol):
+    """g and H = dg/dq1 of one evaluation: HIP vs oracle (dual-number Jacobian)."""
+    m = pusher_model
+    states = _contact_states(m, 8)
+    o = _oracle(m)
+    sim = _batch(m, len(states), dtype)
+    q1 = torch.tensor(np.stack([s[0] for s in states])); q0 = torch.tensor(np.stack([s[1] for s in states]))
+    qd0 = torch.tensor(np.stack([s[2] for s in states])); u = torch.tensor(np.stack([s[3] for s in states]))
+    g, H = sim.debug_eval(q1, q0, qd0, u)
+    g, H = g.double().cpu().numpy(), H.double().cpu().numpy()
+    for e, s in enumerate(states):
+        go, Ho = o.residual(s[0], s[1], s[2], s[3], which=0)
+        assert np.abs(g[e] - go).max() <= tol * max(np.abs(go).max(), 1e-6), (e, g[e], go)
+        assert np.abs(H[e] - Ho).max() <= tol * np.abs(Ho).max(), (e, H[e] - Ho)
+
+
+@pytest.mark.parametrize("dtype,newton_tol,tol_q,tol_tac", [
+    (torch.float64, 1e-13, 1e-9, 1e-6),      # arithmetic parity: round-off only
+    (torch.float64, None, 1e-5, 1e-2),       # XML tolerance (1e-8): solver-tolerance bound
+    (torch.float32, None, 2e-4, 5e-2)])      # fp32 path
+def test_forward_rollout(pusher_model, dtype, newton_tol, tol_q, tol_tac):
+    """20 env-steps (100 implicit sub-steps) of 16 envs: q, variables, tactile vs oracle."""
+    m = pusher_model if newton_tol is None else _with_tol(pusher_model, newton_tol)
+    B, T = 16, 20
+    q0, u, _ = push_workload(B, T, seed=0)
+    sim = _batch(m, B, dtype)
+    sim.reset(torch.tensor(q0), None, backward_flag=False)
+    var0, tac0 = sim.readout()
+    o = _oracle(m)
+    ud = torch.tensor(u)
+    outs = []
+    for t in range(T):
+        r = sim.step(ud[:, t], 5, want_qd=True)
+        outs.append({k: v.double().cpu().numpy() for k, v in r.items()})
+    assert all((x["status"] == 0).all() for x in outs)
+    for e in range(B):
+        o.reset(q0[e])
+        v, tc = o.outputs()
+        assert np.abs(var0[e].double().cpu().numpy() - v).max() < 1e-5
+        for t in range(T):
+            assert o.forward(u[e, t], 5) == 0
+            q, qd = o.state()
+            v, tc = o.outputs()
+            assert np.abs(outs[t]["q"][e] - q).max() <= tol_q, (e, t, outs[t]["q"][e], q)
+            assert np.abs(outs[t]["var"][e] - v).max() <= tol_q * 10
+            scale = max(np.abs(tc).max(), 1e-4)
+            assert np.abs(outs[t]["tactile"][e] - tc).max() <= tol_tac * scale, (e, t)
+
+
+@pytest.mark.parametrize("dtype,newton_tol,tol", [(torch.float64, 1e-13, 1e-7), (torch.float64, None, 1e-4), (torch.float32, None, 5e-3)])
+def test_adjoint_vs_oracle(pusher_model, dtype, newton_tol, tol):
+    """dL/du for L = sum_t w_q.q_t + w_v.var_t + w_t.tactile_t over 10 env-steps, 8 envs; plus carried adjoint."""
+    m = pusher_model if newton_tol is None else _with_tol(pusher_model, newton_tol)
+    B, T, S = 8, 10, 5
+    q0, u, _ = push_workload(B, T, seed=1)
+    rng = np.random.default_rng(5)
+    wq, wv, wt = rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0
+    sim = _batch(m, B, dtype, cap=T * S)
+    sim.reset(torch.tensor(q0), None, backward_flag=True)
+    ud = torch.tensor(u)
+    for t in range(T):
+        sim.step(ud[:, t], S)
+    assert sim.tape_len() == T * S
+    G = np.zeros((B, T, 6))
+    for t in reversed(range(T)):
+        du = sim.backward_steps(S, torch.tensor(np.tile(wq[t], (B, 1))), torch.tensor(np.tile(wv[t], (B, 1))),
+                                torch.tensor(np.tile(wt[t], (B, 1))))
+        G[:, t] = du.double().cpu().numpy().sum(1)
+    lq, lv = (x.double().cpu().numpy() for x in sim.get_adjoint())
+    o = _oracle(m)
+    for e in range(B):
+        o.reset(q0[e], record=True)
+        for t in range(T):
+            o.forward(u[e, t], S)
+        Go = np.zeros((T, 6))
+        for t in reversed(range(T)):
+            dq = np.zeros((S, 7)); dq[-1] = wq[t]
+            dv = np.zeros((S, 6)); dv[-1] = wv[t]
+            dt = np.zeros((S, 390)); dt[-1] = wt[t]
+            Go[t] = o.backward_steps(S, dq, dv, dt).sum(0)
+        alq, alv = o.adjoint()
+        sc = np.abs(Go).max()
+        assert np.abs(G[e] - Go).max() <= tol * sc, (e, np.abs(G[e] - Go).max() / sc)
+        assert np.abs(lq[e] - alq).max() <= tol * max(np.abs(alq).max(), 1e-9)
+        assert np.abs(lv[e] - alv).max() <= tol * max(np.abs(alv).max(), 1e-9)
