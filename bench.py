@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — env-steps/s (forward + adjoint) of the batched TactilePush step on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: launched under torch.distributed.run)
+A "step" = one env-step (5 implicit BDF1 sub-steps, tactile read-out) forward AND its adjoint for one batch of
+B = 4096 TactilePush environments per GPU (BASELINE.json configs[2]: gd_tactile fwd+adjoint, batch 4096).  The K steps
+are run as episodes of <= 100 env-steps (forward all, then backward all — the order autograd imposes in
+algorithms/gd.py:239-259).  Inputs are resident in HBM before the timed region.  Environments shard across ranks with
+no data-path exchange (weak scaling); the only collective is the GD outer loop's policy-gradient all-reduce
+(29 574 fp32 = 118 296 B), issued once per episode.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
+(the fp64 CPU oracle — this build's restatement, NOT DiffRedMax — on a bounded sample, 1 thread).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+POLICY_GRAD_FLOATS = 29574      # DiagGaussianActor(393 -> 64 -> 64 -> 3), SURVEY.md §2.2
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_bytes(nr, nu, nvar, ntac, S, esz):
+    """per env-step, state on chip across the S sub-steps, model constants batch-shared."""
+    fwd = esz * (nu + nr + nvar + ntac + 2 * nr * S)
+    bwd = esz * (2 * nr * S + nr + nvar + ntac + nu * S)
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--frame-skip", type=int, default=5)
+    ap.add_argument("--episode", type=int, default=100, help="env-steps per episode (tape length / frame_skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] style run (not the headline)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tests.workloads import push_workload
+
+    model = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    B, S, T = args.batch, args.frame_skip, args.episode
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4 if args.dtype == "f32" else 8
+    sim = BatchSim(model, B, device=str(dev), dtype=tdt, tape_capacity=T * S)
+    nr, nu, nvar, ntac = sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile
+
+    # synthetic inputs, resident in HBM (seed differs per rank so that ranks do different work)
+    q0_np, u_np, _ = push_workload(B, T, seed=rank)
+    q0 = torch.tensor(q0_np, device=dev, dtype=tdt)
+    u = torch.tensor(u_np, device=dev, dtype=tdt).transpose(0, 1).contiguous()      # [T, B, 6]
+    wq = torch.ones(B, nr, device=dev, dtype=tdt)
+    wv = torch.ones(B, nvar, device=dev, dtype=tdt)
+    wt = torch.ones(B, ntac, device=dev, dtype=tdt) * 100.0
+    grad_buf = torch.zeros(POLICY_GRAD_FLOATS, device=dev, dtype=torch.float32)
+    out = {}
+    ev = {"fwd": [], "bwd": []}
+
+    def run_steps(k_total, timed):
+        """k_total env-steps as episodes of <= T: forward all, backward all."""
+        done = 0
+        bad = 0
+        while done < k_total:
+            n = min(T, k_total - done)
+            sim.reset(q0, None, backward_flag=not args.forward_only)
+            for t in range(n):
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                sim.step(u[t], S, out=out)
+                if timed:
+                    e1.record()
+                    ev["fwd"].append((e0, e1))
+            bad += int((out["status"] != 0).sum().item()) if not timed else 0
+            if not args.forward_only:
+                for t in reversed(range(n)):
+                    if timed:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    du = sim.backward_steps(S, wq, wv, wt)
+                    if timed:
+                        e1.record()
+                        ev["bwd"].append((e0, e1))
+                grad_buf[:6] = du[0].sum(0).float()[:6] if nu >= 6 else 0.0
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(grad_buf)           # GD outer loop: policy-gradient all-reduce over xGMI (RCCL)
+            done += n
+        return bad
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    bad_warm = run_steps(args.warmup, False) if args.warmup > 0 else 0
+    sync_all()
+    t0 = time.perf_counter()
+    run_steps(args.steps, True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]])) if ev["fwd"] else 0.0
+    bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]])) if ev["bwd"] else 0.0
+    status_bad = int((out["status"] != 0).sum().item())
+
+    if rank == 0:
+        fb, bb = algorithmic_bytes(nr, nu, nvar, ntac, S, esz)
+        dom, dom_ms, dom_bytes = ("k_forward", fwd_ms, fb) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb)
+        achieved = dom_bytes * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        value = B * world * args.steps / dt
+        res = {
+            "metric": "env-steps/sec (fwd+bwd) TactilePush batch=4096" if not args.forward_only else "env-steps/sec (fwd only) TactilePush",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "TactilePush (pusher.xml, 13x10 taxels, ndof_r 7) gd_tactile fwd+adjoint, frame_skip %d, "
+                                   "batch %d envs/GPU, episodes of %d env-steps" % (S, B, T),
+                       "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb},
+                         "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms},
+                         "note": "state stays in LDS across sub-steps, so this path is latency/VALU-bound, not HBM-bound (SURVEY.md §0.6)"},
+            "nonconverged_envs_last_step": status_bad, "nonconverged_warmup": bad_warm,
+            "lds_bytes_per_env": sim.launch_info()["lds_bytes"],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(model, S, not args.forward_only)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model, S, with_backward):
+    """fp64 CPU oracle (oracle/tsim_oracle.cpp — the build's own restatement) on a bounded sample, 1 thread."""
+    from oracle.oracle import OracleSim
+    from tests.workloads import push_workload
+    nenv, nstep = 8, 100
+    q0, u, _ = push_workload(nenv, nstep, seed=0)
+    o = OracleSim(model)
+    o.bench_rollout(q0[:1], u[:1, :5], S, with_backward)       # warm
+    t0 = time.perf_counter()
+    n, _ = o.bench_rollout(q0, u, S, with_backward)
+    dt = time.perf_counter() - t0
+    st = o.stats()
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d env-steps of the same TactilePush workload, %s, fp64, g++ -O3, 1 thread; "
+                      "mean Newton iterations/sub-step %.2f" % (nenv, nstep, "fwd+adjoint" if with_backward else "fwd only",
+                                                                st["newton_iters"] / max(st["substeps"], 1)),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

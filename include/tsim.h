@@ -90,13 +90,17 @@ int tsim_cache_pop(tsim_batch* b, void* stream);
 int tsim_cache_clear(tsim_batch* b);
 
 /* Diagnostics (no reference counterpart): one residual evaluation g(q1; q0, qd0, u) and its Newton matrix
- * H = dg/dq1 for env 0..B-1; g_out [B][nr], H_out [B][nr][nr] (row-major). Used by the parity tests. */
+ * H = dg/dq1 for env 0..B-1; g_out [B][nr], H_out [B][nr][nr] (row-major). Used by the parity tests.
+ * cycles (device int64 [B][4], may be NULL): shader-clock cycles of phase 1 / 2 / 3 / dense solve. */
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u,
-                    void* g_out, void* H_out, void* stream);
+                    void* g_out, void* H_out, long long* cycles, void* stream);
 
 /* launch statistics of the most recent kernels (HIP events are the caller's business; this only reports
  * static launch geometry): out[0] = LDS bytes per block, out[1] = threads per block, out[2] = blocks. */
 int tsim_launch_info(const tsim_batch* b, int32_t* out);
+
+/* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */
+int tsim_last_evals(tsim_batch* b, int32_t* host_out);
 
 const char* tsim_last_error(void);
 

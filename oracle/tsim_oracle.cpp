@@ -319,7 +319,9 @@ static bool lu_factor(int n, double* A, int* piv) {
   return true;
 }
 static void lu_solve(int n, const double* A, const int* piv, double* b) {
-  for (int c = 0; c < n; ++c) { if (piv[c] != c) std::swap(b[c], b[piv[c]]); for (int r = c + 1; r < n; ++r) b[r] -= A[r * n + c] * b[c]; }
+  // full rows (L part included) were swapped during factorisation, so the whole permutation is applied first
+  for (int c = 0; c < n; ++c) if (piv[c] != c) std::swap(b[c], b[piv[c]]);
+  for (int c = 0; c < n; ++c) for (int r = c + 1; r < n; ++r) b[r] -= A[r * n + c] * b[c];
   for (int c = n - 1; c >= 0; --c) { b[c] /= A[c * n + c]; for (int r = 0; r < c; ++r) b[r] -= A[r * n + c] * b[c]; }
 }
 static bool solve_dense(int n, const double* A, const double* b, double* x, bool transpose) {

@@ -1,0 +1,254 @@
+"""`redmax_py` drop-in: the python surface of the reference's pybind11 module, backed by the HIP path.
+
+Put this directory on PYTHONPATH and the reference's `envs/*.py`, `envs/redmax_torch_functions.py`,
+`algorithms/gd.py` and `examples/RollingBallExp/test_sim_speed.py` run unmodified:  `import redmax_py as redmax`.
+
+Every member used anywhere in the reference is here (list reconstructed in SURVEY.md §8b; call sites cited inline).
+One `Simulation` == one environment == a B = 1 `tsim_batch` (include/tsim.h).  Arrays cross this boundary as
+float64 numpy, exactly like the pybind11/Eigen binding (the reference computes in float64:
+examples/TactilePushExp/train_tactile_push_gd.py:13).  There is no CPU fallback: a GPU and the built
+libtsim_hip.so are required.  Viewer members are accepted and ignored (rendering is out of scope).
+"""
+import numpy as np
+import torch
+
+from tactilesimulation_amd.host.batch import BatchSim
+from tactilesimulation_amd.model import compiler as _mc
+
+
+class _Options:
+    def __init__(self, h):
+        self.h = h
+
+
+class _ViewerOptions:
+    """envs/redmax_torch_env.py:52-70, utils/renderer.py:7-30 — stored, never used."""
+    def __init__(self):
+        self.fps, self.speed, self.loop, self.infinite = 30, 1.0, False, False
+        self.record, self.record_folder = False, ""
+        self.camera_pos, self.camera_lookat = np.zeros(3), np.zeros(3)
+
+
+class _BackwardInfo:
+    """envs/redmax_torch_functions.py:83-90,151-165"""
+    def __init__(self):
+        self.flag_q0 = self.flag_qdot0 = self.flag_p = False
+        self.flag_u = True
+        self.df_dq = self.df_dvar = self.df_dtactile = None
+        self.df_dq0 = self.df_dqdot0 = self.df_du = self.df_dp = None
+
+    def set_flags(self, flag_q0=False, flag_qdot0=False, flag_p=False, flag_u=False):
+        if flag_p:
+            raise NotImplementedError("design-parameter gradients (flag_p) are not part of this path; the reference "
+                                      "always passes flag_p=False (envs/redmax_torch_functions.py:83,151)")
+        self.flag_q0, self.flag_qdot0, self.flag_p, self.flag_u = bool(flag_q0), bool(flag_qdot0), False, bool(flag_u)
+
+
+class _BackwardResults:
+    """envs/redmax_torch_functions.py:95-105,170"""
+    def __init__(self):
+        self.df_dq0 = self.df_dqdot0 = self.df_du = None
+
+
+class Simulation:
+    def __init__(self, model_path, verbose=False, device="cuda:0", dtype=torch.float64, tape_capacity=1024):
+        self._model = _mc.load_model(model_path) if isinstance(model_path, str) else model_path
+        self._sim = BatchSim(self._model, 1, device=device, dtype=dtype, tape_capacity=tape_capacity)
+        self._dev, self._dtype = self._sim.device, dtype
+        self.ndof_r, self.ndof_u = self._sim.ndof_r, self._sim.ndof_u
+        self.ndof_var, self.ndof_tactile = self._sim.ndof_var, self._sim.ndof_tactile
+        self.ndof_p = 0
+        self.options = _Options(self._sim.h)
+        self.viewer_options = _ViewerOptions()
+        self.backward_info = _BackwardInfo()
+        self.backward_results = _BackwardResults()
+        self._q_init = np.zeros(self.ndof_r)
+        self._qdot_init = np.zeros(self.ndof_r)
+        self._u = np.zeros(self.ndof_u)
+        self._backward_flag = False
+        self._dirty_outputs = True
+        self._q = self._qdot = self._var = self._tac = None
+        self.reset(False)
+
+    # ------------------------------------------------------------------ helpers
+    def _t(self, a, n, name):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(-1)   # pybind11/Eigen copied too; grads from
+        if a.size != n:                                                          # sum() arrive as stride-0 views
+            raise RuntimeError("%s: expected %d values, got %d" % (name, n, a.size))
+        return torch.from_numpy(a.copy()).to(device=self._dev, dtype=self._dtype).reshape(1, n)
+
+    def _np(self, t):
+        return t.detach().to(torch.float64).cpu().numpy().reshape(-1)
+
+    def _refresh(self):
+        if self._dirty_outputs:
+            q, qd = self._sim.get_state()
+            var, tac = self._sim.readout()
+            self._q, self._qdot = self._np(q), self._np(qd)
+            self._var = self._np(var) if var is not None else np.zeros(0)
+            self._tac = self._np(tac) if tac is not None else np.zeros(0)
+            self._dirty_outputs = False
+
+    # ------------------------------------------------------------------ initial state
+    def get_q_init(self):
+        return self._q_init.copy()
+
+    def get_qdot_init(self):
+        return self._qdot_init.copy()
+
+    def set_q_init(self, q):
+        self._q_init = np.array(q, dtype=np.float64).reshape(-1).copy()
+        if self._q_init.size != self.ndof_r:
+            raise RuntimeError("set_q_init: expected %d values" % self.ndof_r)
+
+    def set_qdot_init(self, qdot):
+        self._qdot_init = np.array(qdot, dtype=np.float64).reshape(-1).copy()
+
+    def set_state_init(self, q, qdot):
+        self.set_q_init(q)
+        self.set_qdot_init(qdot)
+
+    # ------------------------------------------------------------------ stepping
+    def reset(self, backward_flag=False, backward_design_params_flag=False):
+        self._backward_flag = bool(backward_flag)
+        self._sim.reset(self._t(self._q_init, self.ndof_r, "q_init"), self._t(self._qdot_init, self.ndof_r, "qdot_init"),
+                        backward_flag=self._backward_flag)
+        self._dirty_outputs = True
+
+    def set_u(self, u):
+        u = np.asarray(u, dtype=np.float64).reshape(-1)
+        if u.size != self.ndof_u:
+            raise RuntimeError("set_u: expected %d values, got %d" % (self.ndof_u, u.size))
+        self._u = u.copy()          # callers mutate their array afterwards (envs/tactile_insertion_env.py:160-163)
+
+    def forward(self, num_steps, verbose=False, test_derivatives=False, save_last_frame_var_only=False):
+        if test_derivatives:
+            raise NotImplementedError("test_derivatives: use tests/test_gpu_parity.py (adjoint vs oracle / finite differences)")
+        out = self._sim.step(self._t(self._u, self.ndof_u, "u"), int(num_steps), want_qd=True)
+        st = int(out["status"].item())
+        if st & (1 << 30):
+            raise RuntimeError("simulation produced non-finite values")
+        self._q, self._qdot = self._np(out["q"]), self._np(out["qd"])
+        self._var = self._np(out["var"]) if "var" in out else np.zeros(0)
+        self._tac = self._np(out["tactile"]) if "tactile" in out else np.zeros(0)
+        self._dirty_outputs = False
+        self.last_nonconverged_substeps = st
+
+    def get_q(self):
+        self._refresh()
+        return self._q
+
+    def get_qdot(self):
+        self._refresh()
+        return self._qdot
+
+    def get_variables(self):
+        self._refresh()
+        return self._var
+
+    def get_tactile_force_vector(self):
+        self._refresh()
+        return self._tac
+
+    def get_tactile_image_pos(self, name):
+        """list of (row, col) per taxel (examples/RollingBallExp/test_sim_speed.py:57-61)."""
+        return [tuple(p) for p in self._model.meta["image_pos"][name]]
+
+    def get_tactile_flow_images(self):
+        """list[n_sensor] of [rows][cols][3] (envs/dclaw_rotate_env.py:103-105); empty cells are zero."""
+        tac = self.get_tactile_force_vector().reshape(-1, 3)
+        imgs = []
+        for name, (t0, nt, rows, cols) in zip(self._model.meta["sensor_names"], self._model.meta["sensor_taxels"]):
+            img = np.zeros((rows, cols, 3))
+            for k, (r, c) in enumerate(self._model.meta["image_pos"][name]):
+                img[r, c] = tac[t0 + k]
+            imgs.append(img)
+        return imgs
+
+    # ------------------------------------------------------------------ differentiation
+    def _seeds(self, n):
+        bi = self.backward_info
+        nr, nv, nt = self.ndof_r, self.ndof_var, self.ndof_tactile
+
+        def seed(a, dim, name):
+            if a is None or dim == 0:
+                return None
+            a = np.asarray(a, dtype=np.float64).reshape(-1)
+            if a.size != n * dim:
+                raise RuntimeError("backward_info.%s has %d values, expected num_steps * %d = %d (a tactile gradient that "
+                                   "holds only masked frames must be scattered to all frames first)" % (name, a.size, dim, n * dim))
+            return self._t(a, n * dim, name)
+        return seed(bi.df_dq, nr, "df_dq"), seed(bi.df_dvar, nv, "df_dvar"), seed(bi.df_dtactile, nt, "df_dtactile")
+
+    def backward_steps(self, num_steps):
+        """envs/redmax_torch_functions.py:167 — newest num_steps sub-steps, continuing the carried adjoint."""
+        n = int(num_steps)
+        a, b, c = self._seeds(n)
+        du = self._sim.backward_steps(n, a, b, c, all_steps=True)
+        self.backward_results.df_du = self._np(du)
+        self._dirty_outputs = True
+
+    def backward(self):
+        """envs/redmax_torch_functions.py:92 — the whole tape."""
+        n = self._sim.tape_len()
+        if n == 0:
+            raise RuntimeError("backward(): nothing recorded (reset(backward_flag=True) + forward first)")
+        self.backward_steps(n)
+        lq, lv = self._sim.get_adjoint()
+        self.backward_results.df_dq0 = self._np(lq)
+        self.backward_results.df_dqdot0 = self._np(lv)
+
+    def saveBackwardCache(self):
+        self._sim.cache_save()
+
+    def popBackwardCache(self):
+        self._sim.cache_pop()
+        self._dirty_outputs = True
+
+    def clearBackwardCache(self):
+        self._sim.cache_clear()
+
+    # ------------------------------------------------------------------ model edits (domain randomisation)
+    def _edit(self, what, name, *args, **kw):
+        _mc.edit_spec(self._model.spec, what, name, *args, **kw)
+        if what != "virtual_object":
+            self._model = _mc.compile_spec(self._model.spec)
+            self._sim.update_model(self._model)
+            self._dirty_outputs = True
+
+    def update_virtual_object(self, name, data):            # envs/tactile_push_env.py:148-152 (render only)
+        self._edit("virtual_object", name, data)
+
+    def update_joint_damping(self, name, damping):          # envs/dclaw_rotate_env.py:173
+        self._edit("joint_damping", name, damping)
+
+    def update_joint_location(self, name, pos):             # envs/dclaw_rotate_env.py:178
+        self._edit("joint_location", name, pos)
+
+    def update_body_size(self, name, size):                 # envs/dclaw_rotate_env.py:175
+        self._edit("body_size", name, size)
+
+    def update_endeffector_position(self, name, pos):       # envs/dclaw_rotate_env.py:176
+        self._edit("endeffector_position", name, pos)
+
+    def update_body_density(self, name, density):           # envs/stable_grasp_env.py:122
+        self._edit("body_density", name, density)
+
+    def update_body_color(self, name, color):               # envs/stable_grasp_env.py:128 (render only)
+        pass
+
+    def update_contact_parameters(self, general_body, primitive_body, kn=None, kt=None, mu=None, damping=None):
+        self._edit("contact_parameters", (general_body, primitive_body), kn=kn, kt=kt, mu=mu, damping=damping)
+
+    def update_tactile_parameters(self, sensor_body, kn=None, kt=None, mu=None, damping=None):
+        self._edit("tactile_parameters", sensor_body, kn=kn, kt=kt, mu=mu, damping=damping)
+
+    # ------------------------------------------------------------------ viewer (out of scope)
+    def replay(self):
+        pass
+
+    def print_ctrl_info(self):
+        pass
+
+    def print_design_params_info(self):
+        pass

@@ -135,7 +135,7 @@ template <class R> struct Ctx {
   R h, gx, gy, gz, tol;
   int max_iter, max_ls;
   // LDS
-  R *q, *q0, *qd0, *u, *qd, *qa, *g, *dq, *H, *lamq, *lamv, *z, *rhs;
+  R *q, *q0, *qd0, *u, *qd, *qa, *g, *dq, *dl, *H, *lamq, *lamv, *z, *rhs;
   R *LP, *LT, *WP, *WT, *scr;
 };
 
@@ -143,7 +143,7 @@ template <class R> struct Ctx {
 __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu) {
   int nd = nr;
   int n = 0;
-  n += 8 * nr + nu;            // q q0 qd0 qd qa g dq (7) + spare(1) ; u
+  n += 10 * nr + nu;           // q q0 qd0 qd qa g dq dl-base(2) dl ; u
   n += nr * nr;                // H
   n += 4 * nr;                 // lamq lamv z rhs
   n += (nl + 1) * LK_SIZE;     // LP
@@ -170,7 +170,7 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
   int nr = c.nr, nl = c.nl, nd = c.nd;
   R* p = lds;
   c.q = p; p += nr; c.q0 = p; p += nr; c.qd0 = p; p += nr; c.qd = p; p += nr; c.qa = p; p += nr;
-  c.g = p; p += nr; c.dq = p; p += 2 * nr; c.u = p; p += c.nu;
+  c.g = p; p += nr; c.dq = p; p += 2 * nr; c.dl = p; p += nr; c.u = p; p += c.nu;
   c.H = p; p += nr * nr;
   c.lamq = p; p += nr; c.lamv = p; p += nr; c.z = p; p += nr; c.rhs = p; p += nr;
   c.LP = p; p += (nl + 1) * LK_SIZE;

@@ -244,14 +244,17 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   __syncthreads();
 }
 
-// full evaluation at the trial q held in c.q (with c.q0, c.qd0, c.u): fills c.qd, c.qa, link state, g, H.
+// full evaluation at the trial increment held in c.dl (with c.q0, c.qd0, c.u): fills c.q, c.qd, c.qa, link state, g, H.
+// The Newton unknown is the increment  dl = q1 - q0 - h qd0  (O(h^2 * acceleration)), not q1 itself, so that the
+// discrete acceleration dl/h^2 and velocity qd0 + dl/h keep full relative precision in fp32 (no q1 - q0 cancellation).
 // forward seeds: (1, 1/h, 1/h^2) -> H = dg/dq1 ;  adjoint seeds: (1, 0, 0) -> H = h^2 dr/dq.
 template <class R>
 __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   if (lane < c.nr) {
-    R d = c.q[lane] - c.q0[lane];
-    c.qd[lane] = d / c.h;
-    c.qa[lane] = (d - c.h * c.qd0[lane]) / (c.h * c.h);
+    const R d = c.dl[lane];
+    c.qd[lane] = c.qd0[lane] + d / c.h;
+    c.qa[lane] = d / (c.h * c.h);
+    c.q[lane] = c.q0[lane] + (c.h * c.qd0[lane] + d);
   }
   __syncthreads();
   phase1(c, lane, sq, sv, sa);

@@ -68,7 +68,7 @@ template <class R> struct FwdArgs {
   const int* I; const R* F;
   int B, nsub, record, t0;
   R* tape; const R* u;
-  R *q_out, *qd_out, *var_out, *tac_out; int* status;
+  R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
 };
 
 template <class R, int NRM>
@@ -86,26 +86,27 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   }
   __syncthreads();
   const R sq = R(1), sv = R(1) / c.h, sa = R(1) / (c.h * c.h);
-  R* qbase = c.dq + nr;
+  R* dlbase = c.dq + nr;
   int bad = 0; bool nonfinite = false;
+  long long evals = 0;
   for (int s = 0; s < a.nsub; ++s) {
-    if (lane < nr) c.q[lane] = c.q0[lane] + c.h * c.qd0[lane];
+    if (lane < nr) c.dl[lane] = R(0);          // initial guess q1 = q0 + h qd0
     __syncthreads();
-    evaluate(c, lane, sq, sv, sa);
+    evaluate(c, lane, sq, sv, sa); ++evals;
     R gn = block_norm2(c.g, nr, lane);
     int iter = 0; bool conv = false;
     while (true) {
       if (!(gn == gn)) { nonfinite = true; break; }
       if (gn < c.tol) { conv = true; break; }
       if (iter >= c.max_iter) break;
-      if (lane < nr) { c.rhs[lane] = -c.g[lane]; qbase[lane] = c.q[lane]; }
+      if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
       __syncthreads();
       solve_lanes<R, NRM>(c.H, c.rhs, c.dq, nr, false, lane);
       R alpha = R(1), gn2 = gn;
       for (int ls = 0; ls <= c.max_ls; ++ls) {
-        if (lane < nr) c.q[lane] = qbase[lane] + alpha * c.dq[lane];
+        if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
         __syncthreads();
-        evaluate(c, lane, sq, sv, sa);
+        evaluate(c, lane, sq, sv, sa); ++evals;
         gn2 = block_norm2(c.g, nr, lane);
         if (gn2 < gn || ls == c.max_ls) break;
         alpha *= R(0.5);
@@ -133,6 +134,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     if (a.qd_out) a.qd_out[(size_t)env * nr + lane] = c.qd0[lane];
   }
   if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
+  if (a.evals && lane == 0) a.evals[env] = (int)evals;
   // link poses / velocities in LDS are those of the accepted state (last evaluation)
   readout(c, lane, env, a.var_out, a.tac_out);
 }
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
 }
 
 // ================================================================================================ debug evaluation
-template <class R> struct DbgArgs { const int* I; const R* F; int B; const R *q1, *q0, *qd0, *u; R *g, *H; };
+template <class R> struct DbgArgs { const int* I; const R* F; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; };
 
 template <class R>
 __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
@@ -166,10 +168,34 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   Ctx<R> c; ctx_init(c, a.I, a.F, lds);
   const int nr = c.nr, nu = c.nu;
   init_world(c, lane);
-  if (lane < nr) { c.q[lane] = a.q1[(size_t)env * nr + lane]; c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane]; }
+  if (lane < nr) {
+    c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane];
+    c.dl[lane] = a.q1[(size_t)env * nr + lane] - c.q0[lane] - c.h * c.qd0[lane];
+  }
   if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
   __syncthreads();
-  evaluate(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+  if (a.cyc) {   // phase-by-phase shader-clock stamps (s_memtime), under whatever load the launch creates
+    const R sq = R(1), sv = R(1) / c.h, sa = R(1) / (c.h * c.h);
+    long long t0 = clock64();
+    if (lane < nr) {
+      const R d = c.dl[lane];
+      c.qd[lane] = c.qd0[lane] + d / c.h; c.qa[lane] = d / (c.h * c.h); c.q[lane] = c.q0[lane] + (c.h * c.qd0[lane] + d);
+    }
+    __syncthreads();
+    phase1(c, lane, sq, sv, sa);
+    long long t1 = clock64();
+    phase2(c, lane);
+    long long t2 = clock64();
+    phase3(c, lane, sq, sv);
+    long long t3 = clock64();
+    if (lane < nr) c.rhs[lane] = -c.g[lane];
+    __syncthreads();
+    solve_lanes<R, 16>(c.H, c.rhs, c.dq, nr, false, lane);
+    long long t4 = clock64();
+    if (lane == 0) { long long* o = a.cyc + (size_t)env * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t4 - t3; }
+  } else {
+    evaluate(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+  }
   if (lane < nr) a.g[(size_t)env * nr + lane] = c.g[lane];
   for (int e = lane; e < nr * nr; e += TS_WAVE) a.H[(size_t)env * nr * nr + e] = c.H[e];
 }
@@ -331,15 +357,13 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
     const int t = a.t_end - (a.n - 1 - j);
     const R* r1 = a.tape + ((size_t)t * a.B + env) * REC;
     const R* r0 = a.tape + ((size_t)(t - 1) * a.B + env) * REC;
-    if (lane < nr) { c.q[lane] = r1[lane]; c.q0[lane] = r0[lane]; c.qd0[lane] = r0[nr + lane]; }
+    if (lane < nr) {
+      c.q[lane] = r1[lane]; c.q0[lane] = r0[lane]; c.qd0[lane] = r0[nr + lane];
+      c.qd[lane] = r1[nr + lane];                               // taped (q1 - q0)/h
+      c.qa[lane] = (r1[nr + lane] - r0[nr + lane]) / c.h;       // discrete acceleration, no position cancellation
+    }
     if (lane < nu) c.u[lane] = r1[2 * nr + nr * nr + lane];
     for (int e = lane; e < nr * nr; e += TS_WAVE) H2[e] = r1[2 * nr + e];
-    __syncthreads();
-    if (lane < nr) {
-      R d = c.q[lane] - c.q0[lane];
-      c.qd[lane] = d / c.h;
-      c.qa[lane] = (d - c.h * c.qd0[lane]) / (c.h * c.h);
-    }
     __syncthreads();
     phase1(c, lane, R(1), R(0), R(0));
     // direct partials of the loss w.r.t. this sub-step's outputs
@@ -388,6 +412,7 @@ struct tsim_batch {
   int* dI; void* dF;             // model on device (dF in the batch's real type)
   void* tape;                    // [(cap+1)][B][rec]
   void *lamq, *lamv;             // carried adjoint [B][nr]
+  int* evals;                    // residual evaluations of the last forward launch, per env (diagnostics)
   int t_cur, record;
   size_t lds_bytes, esz;
   std::vector<CacheEntry> cache;
@@ -427,7 +452,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, v
   FwdArgs<R> a;
   a.I = b->dI; a.F = (const R*)b->dF; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur;
   a.tape = (R*)b->tape; a.u = (const R*)u;
-  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status;
+  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals;
   if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   else hipLaunchKernelGGL((k_forward<R, 16>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   HIPCHK(hipGetLastError());
@@ -478,11 +503,11 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
   if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   b->t_cur = 0; b->record = 0;
-  b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr;
+  b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, b->I.size() * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess) {
+      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
   }
@@ -497,7 +522,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
-  (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv);
+  (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals);
   delete b;
 }
 
@@ -510,6 +535,10 @@ int tsim_dtype(const tsim_batch* b) { return b->dtype; }
 double tsim_timestep(const tsim_batch* b) { return b->F[TSIM_FH_H]; }
 int tsim_tape_len(const tsim_batch* b) { return b->record ? b->t_cur : 0; }
 int tsim_launch_info(const tsim_batch* b, int32_t* out) { out[0] = (int32_t)b->lds_bytes; out[1] = TS_WAVE; out[2] = b->B; return 0; }
+int tsim_last_evals(tsim_batch* b, int32_t* host_out) {
+  if (hipSetDevice(b->device) != hipSuccess || hipMemcpy(host_out, b->evals, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_evals: copy failed");
+  return 0;
+}
 
 int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* stream) {
   if (I[TSIM_IH_NI] != (int)b->I.size() || I[TSIM_IH_NF] != (int)b->F.size()) return fail("update_model: blob size changed");
@@ -618,13 +647,13 @@ int tsim_cache_clear(tsim_batch* b) {
   return 0;
 }
 
-int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u, void* g_out, void* H_out, void* stream) {
+int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u, void* g_out, void* H_out, long long* cycles, void* stream) {
   HIPCHK(hipSetDevice(b->device));
   if (b->dtype == TSIM_F32) {
-    DbgArgs<float> a{b->dI, (const float*)b->dF, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out};
+    DbgArgs<float> a{b->dI, (const float*)b->dF, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles};
     hipLaunchKernelGGL(k_debug_eval<float>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   } else {
-    DbgArgs<double> a{b->dI, (const double*)b->dF, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out};
+    DbgArgs<double> a{b->dI, (const double*)b->dF, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles};
     hipLaunchKernelGGL(k_debug_eval<double>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());

@@ -144,12 +144,19 @@ class BatchSim:
         capi.check(capi.lib().tsim_cache_clear(self._h))
 
     # ------------------------------------------------------------------ diagnostics
-    def debug_eval(self, q1, q0, qd0, u):
+    def debug_eval(self, q1, q0, qd0, u, cycles=False):
         q1, q0, qd0 = (self._chk(x, self.ndof_r, "q") for x in (q1, q0, qd0))
         u = self._chk(u, self.ndof_u, "u")
         g, H = self.empty(self.ndof_r), self.empty(self.ndof_r, self.ndof_r)
-        capi.check(capi.lib().tsim_debug_eval(self._h, _ptr(q1), _ptr(q0), _ptr(qd0), _ptr(u), _ptr(g), _ptr(H), self._stream()))
-        return g, H
+        cyc = torch.zeros(self.B, 4, device=self.device, dtype=torch.int64) if cycles else None
+        capi.check(capi.lib().tsim_debug_eval(self._h, _ptr(q1), _ptr(q0), _ptr(qd0), _ptr(u), _ptr(g), _ptr(H), _ptr(cyc),
+                                              self._stream()))
+        return (g, H, cyc) if cycles else (g, H)
+
+    def last_evals(self):
+        out = np.zeros(self.B, dtype=np.int32)
+        capi.check(capi.lib().tsim_last_evals(self._h, out.ctypes.data_as(capi._ip)))
+        return out
 
     def launch_info(self):
         out = (C.c_int32 * 3)()

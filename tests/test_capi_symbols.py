@@ -1,0 +1,52 @@
+"""The C-ABI library loads and exports every symbol include/tsim.h declares (no GPU, no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "tsim.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsim_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tactilesimulation_amd.host import capi
+    so = capi.LIB_PATH
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(so)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    assert sorted(capi.EXPORTS) == names, "host binding and header disagree"
+
+
+def test_host_refuses_to_run_without_gpu_or_library(monkeypatch, pusher_model):
+    """No CPU fallback: a CPU device is rejected, and a missing library raises."""
+    from tactilesimulation_amd.host import capi
+    from tactilesimulation_amd.host.batch import BatchSim
+    with pytest.raises(RuntimeError):
+        BatchSim(pusher_model, 4, device="cpu")
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", "/nonexistent/libtsim_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.lib()
+
+
+def test_create_rejects_bad_blobs_without_touching_the_gpu(pusher_model):
+    import numpy as np
+    from tactilesimulation_amd.host import capi
+    L = capi.lib()
+    I = np.ascontiguousarray(pusher_model.I, dtype=np.int32).copy()
+    F = np.ascontiguousarray(pusher_model.F, dtype=np.float64)
+    I[0] = 0
+    h = ctypes.c_void_p()
+    rc = L.tsim_batch_create(I.ctypes.data_as(capi._ip), F.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 4, 8, 0, 0, ctypes.byref(h))
+    assert rc != 0 and b"magic" in L.tsim_last_error()

@@ -1,0 +1,91 @@
+"""GPU-vs-oracle accuracy + Newton statistics + per-phase cycle counts (writes gpurun_out/accuracy_<tag>.json)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from tactilesimulation_amd.model.compiler import load_model  # noqa: E402
+from tactilesimulation_amd.host.batch import BatchSim  # noqa: E402
+from oracle.oracle import OracleSim  # noqa: E402
+from tests.workloads import push_workload  # noqa: E402
+
+
+def report(dtype, B=32, T=40, S=5):
+    m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    q0, u, _ = push_workload(B, T, seed=2)
+    rng = np.random.default_rng(9)
+    wq, wv, wt = rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0
+    sim = BatchSim(m, B, dtype=dtype, tape_capacity=T * S)
+    sim.reset(torch.tensor(q0), None, backward_flag=True)
+    ud = torch.tensor(u)
+    outs, evals, bad = [], [], 0
+    for t in range(T):
+        r = sim.step(ud[:, t], S, want_qd=True)
+        outs.append({k: v.double().cpu().numpy() for k, v in r.items()})
+        evals.append(sim.last_evals())
+        bad += int((outs[-1]["status"] != 0).sum())
+    G = np.zeros((B, T, 6))
+    for t in reversed(range(T)):
+        G[:, t] = sim.backward_steps(S, torch.tensor(np.tile(wq[t], (B, 1))), torch.tensor(np.tile(wv[t], (B, 1))),
+                                     torch.tensor(np.tile(wt[t], (B, 1)))).double().cpu().numpy().sum(1)
+    o = OracleSim(m)
+    eq, ev, et, eg, egc = [], [], [], [], []
+    for e in range(B):
+        o.reset(q0[e], record=True)
+        for t in range(T):
+            o.forward(u[e, t], S)
+            q, _ = o.state()
+            v, tc = o.outputs()
+            eq.append(np.abs(outs[t]["q"][e] - q).max())
+            ev.append(np.abs(outs[t]["var"][e] - v).max())
+            et.append(np.abs(outs[t]["tactile"][e] - tc).max() / max(np.abs(tc).max(), 1e-6))
+        Go = np.zeros((T, 6))
+        for t in reversed(range(T)):
+            dq = np.zeros((S, 7)); dq[-1] = wq[t]
+            dv = np.zeros((S, 6)); dv[-1] = wv[t]
+            dt = np.zeros((S, 390)); dt[-1] = wt[t]
+            Go[t] = o.backward_steps(S, dq, dv, dt).sum(0)
+        eg.append(np.abs(G[e] - Go).max() / np.abs(Go).max())
+        a, b = G[e].ravel(), Go.ravel()
+        egc.append(1.0 - float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b))))
+    ev_all = np.concatenate(evals)
+    return {"dtype": str(dtype), "B": B, "T": T, "q_max_abs_err": float(np.max(eq)), "q_median_abs_err": float(np.median(eq)),
+            "var_max_abs_err": float(np.max(ev)), "tactile_max_rel_err": float(np.max(et)), "tactile_median_rel_err": float(np.median(et)),
+            "grad_max_rel_err": float(np.max(eg)), "grad_median_rel_err": float(np.median(eg)), "grad_max_one_minus_cos": float(np.max(egc)),
+            "evals_per_env_step_mean": float(ev_all.mean()), "evals_per_env_step_max": int(ev_all.max()), "nonconverged": bad,
+            "oracle_newton_iters_per_substep": o.stats()["newton_iters"] / o.stats()["substeps"]}
+
+
+def phase_cycles(dtype, B=4096):
+    m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    o = OracleSim(m)
+    q0s, us, _ = push_workload(64, 10, seed=4)
+    st = []
+    for e in range(64):
+        o.reset(q0s[e])
+        for t in range(4 + e % 6):
+            o.forward(us[e, t], 5)
+        q, qd = o.state()
+        st.append((q + m.h * qd, q, qd, us[e, 9]))
+    rep = B // 64
+    q1, q0, qd0, u = (torch.tensor(np.tile(np.stack([s[i] for s in st]), (rep, 1))) for i in range(4))
+    sim = BatchSim(m, B, dtype=dtype, tape_capacity=4)
+    for _ in range(3):
+        g, H, cyc = sim.debug_eval(q1, q0, qd0, u, cycles=True)
+    c = cyc.double().cpu().numpy()
+    return {"dtype": str(dtype), "B": B, "phase1_kinematics": float(c[:, 0].mean()), "phase2_contacts": float(c[:, 1].mean()),
+            "phase3_projection": float(c[:, 2].mean()), "dense_solve": float(c[:, 3].mean()), "unit": "shader cycles per evaluation (mean over waves, all resident waves running)"}
+
+
+if __name__ == "__main__":
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    res = {"accuracy": [report(torch.float32), report(torch.float64)],
+           "phase_cycles": [phase_cycles(torch.float32), phase_cycles(torch.float64)]}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "accuracy_%s.json" % tag), "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
