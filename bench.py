@@ -136,6 +136,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # untimed: Newton work statistics (residual evaluations per env-step) of the same workload
+    sim.reset(q0, None, backward_flag=False)
+    evs = []
+    for t in range(min(T, 30)):
+        sim.step(u[t], S, out=out)
+        evs.append(sim.last_evals())
+    evs = np.array(evs)
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]])) if ev["fwd"] else 0.0
     bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]])) if ev["bwd"] else 0.0
     status_bad = int((out["status"] != 0).sum().item())
@@ -160,6 +167,8 @@ def main():
                          "note": "state stays in LDS across sub-steps, so this path is latency/VALU-bound, not HBM-bound (SURVEY.md §0.6)"},
             "nonconverged_envs_last_step": status_bad, "nonconverged_warmup": bad_warm,
             "lds_bytes_per_env": sim.launch_info()["lds_bytes"],
+            "residual_evals_per_env_step": {"mean": float(evs.mean()), "p99": float(np.percentile(evs, 99)),
+                                            "mean_of_per_step_max": float(evs.max(axis=1).mean()), "max": int(evs.max())},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(model, S, not args.forward_only)

@@ -120,10 +120,36 @@ template <class R> __device__ __forceinline__ void st3(R* P, R* T, int idx, int 
 }
 
 // ------------------------------------------------------------------------------------------------ wave reductions
+// Cross-lane traffic stays in the VALU: DPP row operations (quad_perm / row_mirror / row_bcast) instead of
+// ds_bpermute round trips through the LDS crossbar, and v_readlane for broadcasts of a wave-uniform lane.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dpp_i(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xf, false);
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_r(float x) {
+  return __builtin_bit_cast(float, dpp_i<CTRL, ROWMASK>(__builtin_bit_cast(int, x)));
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_r(double x) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = dpp_i<CTRL, ROWMASK>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL, ROWMASK>((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane_bcast(float x, int lane_uniform) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane_uniform));
+}
+__device__ __forceinline__ double lane_bcast(double x, int lane_uniform) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane_uniform), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_uniform);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the 64 lanes, result in every lane
 template <class R> __device__ __forceinline__ R wave_sum(R x) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, TS_WAVE);
-  return x;
+  x += dpp_r<0xB1, 0xf>(x);    // quad_perm [1,0,3,2]
+  x += dpp_r<0x4E, 0xf>(x);    // quad_perm [2,3,0,1]
+  x += dpp_r<0x141, 0xf>(x);   // row_half_mirror
+  x += dpp_r<0x140, 0xf>(x);   // row_mirror      -> every lane of a 16-lane row holds the row total
+  x += dpp_r<0x142, 0xa>(x);   // row_bcast:15    -> rows 1 and 3 add the total of the row below
+  x += dpp_r<0x143, 0xc>(x);   // row_bcast:31    -> rows 2 and 3 add the total of rows 0-1; lane 63 has the sum
+  return lane_bcast(x, 63);
 }
 
 // ------------------------------------------------------------------------------------------------ per-block context

@@ -263,8 +263,9 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
 }
 
 // ================================================================================================ dense solve
-// Gauss-Jordan with partial pivoting, one matrix row per lane held in registers (fp64 regardless of R),
-// pivot rows broadcast with wave shuffles.  Solves A x = b (or A^T x = b), n <= NRM <= 16.
+// Gauss-Jordan with partial pivoting, one matrix row per lane held in registers (fp64 regardless of R).
+// Pivot search: 4 DPP steps inside the first 16-lane row; pivot row broadcast: v_readlane. No LDS traffic.
+// Solves A x = b (or A^T x = b), n <= NRM <= 16.
 template <class R, int NRM>
 __device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane) {
   double a[NRM], rb = 0.0;
@@ -279,21 +280,20 @@ __device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose,
 #pragma unroll
   for (int col = 0; col < NRM; ++col) {
     if (col < n) {
-      double mag = (!done && lane < n) ? fabs(a[col]) : -1.0;
+      float mag = (!done && lane < n) ? (float)fabs(a[col]) : -1.0f;
       int idx = lane;
-#pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) {
-        double om = __shfl_xor(mag, o, TS_WAVE); int oi = __shfl_xor(idx, o, TS_WAVE);
-        if (om > mag || (om == mag && oi < idx)) { mag = om; idx = oi; }
-      }
-      const int p = __shfl(idx, 0, TS_WAVE);
-      const double piv = __shfl(a[col], p, TS_WAVE);
+#define TS_ARGMAX_STEP(CTRL) { float om = dpp_r<CTRL, 0xf>(mag); int oi = dpp_i<CTRL, 0xf>(idx); \
+        if (om > mag || (om == mag && oi < idx)) { mag = om; idx = oi; } }
+      TS_ARGMAX_STEP(0xB1) TS_ARGMAX_STEP(0x4E) TS_ARGMAX_STEP(0x141) TS_ARGMAX_STEP(0x140)
+#undef TS_ARGMAX_STEP
+      const int p = __builtin_amdgcn_readfirstlane(idx);
+      const double piv = lane_bcast(a[col], p);
       const double f = (lane != p) ? a[col] / piv : 0.0;
 #pragma unroll
       for (int j = 0; j < NRM; ++j) {
-        if (j >= col) { double pj = __shfl(a[j], p, TS_WAVE); a[j] -= f * pj; }
+        if (j >= col) { const double pj = lane_bcast(a[j], p); a[j] -= f * pj; }
       }
-      double pb = __shfl(rb, p, TS_WAVE); rb -= f * pb;
+      const double pb = lane_bcast(rb, p); rb -= f * pb;
       if (lane == p) { done = true; mycol = col; mypiv = piv; }
     }
   }

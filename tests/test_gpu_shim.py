@@ -1,0 +1,148 @@
+"""The reference-facing surface on the GPU: compat/redmax_py.Simulation (B = 1, float64 numpy across the binding like
+the pybind11 module) driven through StepSimFunction / EpisodicSimFunction, and the batched autograd function.
+Checked against the fp64 CPU oracle on identical inputs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.workloads import push_workload
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tactilesimulation_amd", "compat"))
+PUSHER = os.path.join(ROOT, "tests", "golden", "models", "pusher.npz")
+
+
+def _tight(model, tol=1e-13):
+    import copy
+    import tactilesimulation_amd.model.blob as B
+    m = copy.copy(model); m.F = model.F.copy(); m.F[B.TSIM_FH_TOL] = tol
+    m.spec = copy.deepcopy(model.spec); m.spec["options"]["tol"] = tol      # survives update_* recompiles
+    return m
+
+
+def test_simulation_shim_step_and_autograd(pusher_model):
+    import redmax_py as redmax
+    from tactilesimulation_amd.functions import StepSimFunction
+    from oracle.oracle import OracleSim
+    m = _tight(pusher_model)
+    sim = redmax.Simulation(m)
+    assert (sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile) == (7, 6, 6, 390) and abs(sim.options.h - 5e-3) < 1e-15
+    q0, u, _ = push_workload(1, 6, seed=21)
+    sim.set_q_init(q0[0]); sim.reset(backward_flag=True)
+    assert sim.get_tactile_force_vector().shape == (390,) and np.allclose(sim.get_q(), q0[0])
+    acts = [torch.tensor(u[0, t], dtype=torch.float64, requires_grad=True) for t in range(6)]
+    L = 0.0
+    for a in acts:
+        q, var, tac = StepSimFunction.apply(a, 5, sim, True)
+        L = L + q[3] + 2.0 * q[6] + var.sum() + 50.0 * tac.sum()
+    L.backward()
+    o = OracleSim(m); o.reset(q0[0], record=True)
+    Lo = 0.0
+    for t in range(6):
+        o.forward(u[0, t], 5)
+        q, _ = o.state(); v, tc = o.outputs()
+        Lo += q[3] + 2 * q[6] + v.sum() + 50 * tc.sum()
+    assert abs(float(L.detach()) - Lo) < 1e-9 * max(abs(Lo), 1)
+    for t in reversed(range(6)):
+        dq = np.zeros((5, 7)); dq[-1, 3] = 1; dq[-1, 6] = 2
+        dv = np.zeros((5, 6)); dv[-1] = 1
+        dt = np.zeros((5, 390)); dt[-1] = 50
+        go = o.backward_steps(5, dq, dv, dt).sum(0)
+        assert np.abs(acts[t].grad.numpy() - go).max() < 1e-7 * max(np.abs(go).max(), 1e-3), t
+
+
+def test_batched_function_matches_per_env_shim(pusher_model):
+    from tactilesimulation_amd.functions import BatchedStepSimFunction
+    from tactilesimulation_amd.host.batch import BatchSim
+    from oracle.oracle import OracleSim
+    m = _tight(pusher_model)
+    B, T = 6, 5
+    q0, u, _ = push_workload(B, T, seed=22)
+    sim = BatchSim(m, B, dtype=torch.float64, tape_capacity=T * 5)
+    sim.reset(torch.tensor(q0), None, backward_flag=True)
+    W = torch.nn.Parameter(torch.zeros(6, 7, dtype=torch.float64, device="cuda"))      # toy linear "policy" on q
+    ud = torch.tensor(u, device="cuda")
+    q = torch.tensor(q0, device="cuda")
+    L = 0.0
+    for t in range(T):
+        a = ud[:, t] + q @ W.t()
+        q, var, tac = BatchedStepSimFunction.apply(a, 5, sim, True)
+        L = L + (q[:, 3] + var.sum(1) + 20.0 * tac.sum(1)).sum()
+    L.backward()
+    assert sim.tape_len() == 0 and torch.isfinite(W.grad).all()
+    # W = 0, so dL/dW = sum_t dL/da_t (x) q_{t-1}: rebuild it from oracle adjoints
+    o = OracleSim(m)
+    Gw = np.zeros((6, 7))
+    for e in range(B):
+        o.reset(q0[e], record=True)
+        qs = [q0[e]]
+        for t in range(T):
+            o.forward(u[e, t], 5); qs.append(o.state()[0])
+        lam_next = np.zeros(7)       # gradient flowing into q_t from a_{t+1} = u + W q_t is zero at W = 0
+        for t in reversed(range(T)):
+            dq = np.zeros((5, 7)); dq[-1, 3] = 1
+            dv = np.zeros((5, 6)); dv[-1] = 1
+            dt = np.zeros((5, 390)); dt[-1] = 20
+            da = o.backward_steps(5, dq, dv, dt).sum(0)
+            Gw += np.outer(da, qs[t])
+    assert np.abs(W.grad.cpu().numpy() - Gw).max() < 1e-6 * np.abs(Gw).max()
+
+
+def test_episodic_function_and_cache(pusher_model):
+    import redmax_py as redmax
+    from tactilesimulation_amd.functions import EpisodicSimFunction
+    from oracle.oracle import OracleSim
+    m = _tight(pusher_model)
+    sim = redmax.Simulation(m)
+    q0s, u, _ = push_workload(1, 3, seed=23)
+    T = 12
+    acts = torch.tensor(np.repeat(u[0], 4, axis=0), dtype=torch.float64, requires_grad=True)
+    q0 = torch.tensor(q0s[0], dtype=torch.float64, requires_grad=True)
+    qd0 = torch.zeros(7, dtype=torch.float64, requires_grad=True)
+    mask = torch.zeros(T, dtype=torch.bool); mask[3] = True; mask[11] = True
+    qs, vs, ts = EpisodicSimFunction.apply(q0, qd0, acts, mask, sim, True)
+    assert qs.shape == (T, 7) and vs.shape == (T, 6) and ts.shape == (2, 390)
+    (qs[:, 3].sum() + vs[-1].sum() + 30.0 * ts.sum()).backward()
+    o = OracleSim(m); o.reset(q0s[0], np.zeros(7), record=True)
+    an = acts.detach().numpy()
+    for t in range(T):
+        o.forward(an[t], 1)
+    dq = np.zeros((T, 7)); dq[:, 3] = 1
+    dv = np.zeros((T, 6)); dv[-1] = 1
+    dt = np.zeros((T, 390)); dt[3] = 30; dt[11] = 30
+    du = o.backward_steps(T, dq, dv, dt)
+    lq, lv = o.adjoint()
+    assert np.abs(acts.grad.numpy() - du).max() < 1e-7 * np.abs(du).max()
+    assert np.abs(q0.grad.numpy() - lq).max() < 1e-7 * np.abs(lq).max()
+    assert np.abs(qd0.grad.numpy() - lv).max() < 1e-7 * np.abs(lv).max()
+
+
+def test_update_parameters_and_flow_images(pusher_model):
+    import redmax_py as redmax
+    from tactilesimulation_amd.model import compiler as mc
+    from oracle.oracle import OracleSim
+    sim = redmax.Simulation(_tight(pusher_model))
+    sim.update_contact_parameters("tactile_pad_left", "box", kn=400.0, kt=4.0, mu=0.7, damping=20.0)
+    sim.update_tactile_parameters("tactile_pad_left", kn=55.0, kt=2.0, mu=0.9, damping=3.0)
+    sim.update_virtual_object("goal", np.array([0.2, 0.1, 0.025, 1, 0, 0, 0.0]))
+    q0, u, _ = push_workload(1, 8, seed=24)
+    sim.set_q_init(q0[0]); sim.reset(False)
+    for t in range(8):
+        sim.set_u(u[0, t]); sim.forward(5)
+    spec = mc.compile_spec(_tight(pusher_model).spec).spec
+    mc.edit_spec(spec, "contact_parameters", ("tactile_pad_left", "box"), kn=400.0, kt=4.0, mu=0.7, damping=20.0)
+    mc.edit_spec(spec, "tactile_parameters", "tactile_pad_left", kn=55.0, kt=2.0, mu=0.9, damping=3.0)
+    o = OracleSim(mc.compile_spec(spec)); o.reset(q0[0])
+    for t in range(8):
+        o.forward(u[0, t], 5)
+    assert np.abs(sim.get_q() - o.state()[0]).max() < 1e-9
+    tac = o.outputs()[1]
+    assert np.abs(sim.get_tactile_force_vector() - tac).max() < 1e-7 * max(np.abs(tac).max(), 1e-6)
+    img = sim.get_tactile_flow_images()
+    assert len(img) == 1 and img[0].shape == (13, 10, 3) and np.allclose(img[0].reshape(-1), sim.get_tactile_force_vector())
+    pos = sim.get_tactile_image_pos("tactile_pad_left")
+    assert len(pos) == 130 and pos[12] == (1, 2)
