@@ -3,59 +3,45 @@
 // Execution model: ONE ENVIRONMENT PER 64-LANE WAVEFRONT (block = 64 threads).  The environment's reduced
 // state (q, qd), the per-link world transforms / spatial velocities / wrenches and the Newton matrix live
 // in LDS for the whole kernel (all sub-steps of an env-step); HBM is touched only for the action, the
-// outputs and the tape.  Two lane mappings alternate inside one residual evaluation:
+// outputs and the tape.  Lane mappings inside one residual evaluation:
 //
-//   lanes = tangent directions  (phase 1: kinematics + inertial wrenches, phase 3: projection on joints)
-//       lane k carries dual numbers (value, d/d(direction k)); the few links are walked serially, all
-//       lanes in lock-step on the same link, so there is no divergence.  Exact Newton matrix, no
-//       hand-derived second-order kinematics.
-//   lanes = contact points / taxels  (phase 2, tactile read-out)
-//       each lane owns one sampled surface point, loops over the relevant directions reading the link
-//       tangents as LDS broadcasts, and the per-link wrench (value + tangents) is combined with
-//       wavefront butterfly reductions.
+//   phase 1  (all lanes, uniform)     value kinematics + inertial wrench per link, root -> leaf
+//   phase 1t (lanes = directions)     exact tangents of link twist / acceleration / inertial wrench w.r.t. dof k,
+//                                     propagated with world-frame spatial algebra (6-vectors, no matrices)
+//   phase 2  (lanes = contact points) penalty contact in the primitive's frame: force + its 3x3 local Jacobians,
+//                                     applied to the per-direction relative displacement / twist of the pair
+//                                     (12 reals per direction, LDS broadcast); wavefront DPP reductions
+//   phase 3  (lanes = directions)     projection on the joints, leaf -> root:  g  and  H[:,k]
 //
 // Replaces the per-sub-step C++ of the reference's absent DiffRedMax behind `sim.forward()` /
-// `sim.backward_steps()` (envs/redmax_torch_functions.py:132,167).  Formulation: DESIGN.md §Physics.
+// `sim.backward_steps()` (envs/redmax_torch_functions.py:132,167).  Formulation: DESIGN.md §1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/tsim_blob.h"
 
 #define TS_WAVE 64
-// per-link record in LDS (reals)
-enum { LK_R = 0, LK_P = 9, LK_W = 12, LK_V = 15, LK_AW = 18, LK_AV = 21, LK_FN = 24, LK_FF = 27, LK_SIZE = 30 };
-
-// ------------------------------------------------------------------------------------------------ dual numbers
-template <class R> struct Du {
-  R v, d;
-  __device__ __forceinline__ Du() {}
-  __device__ __forceinline__ Du(R a) : v(a), d(R(0)) {}
-  __device__ __forceinline__ Du(R a, R b) : v(a), d(b) {}
-};
-template <class T> struct RealOf { typedef T type; };
-template <class R> struct RealOf<Du<R>> { typedef R type; };
-
-template <class R> __device__ __forceinline__ Du<R> operator+(Du<R> a, Du<R> b) { return Du<R>(a.v + b.v, a.d + b.d); }
-template <class R> __device__ __forceinline__ Du<R> operator-(Du<R> a, Du<R> b) { return Du<R>(a.v - b.v, a.d - b.d); }
-template <class R> __device__ __forceinline__ Du<R> operator-(Du<R> a) { return Du<R>(-a.v, -a.d); }
-template <class R> __device__ __forceinline__ Du<R> operator*(Du<R> a, Du<R> b) { return Du<R>(a.v * b.v, a.d * b.v + a.v * b.d); }
-template <class R> __device__ __forceinline__ Du<R> operator*(Du<R> a, R b) { return Du<R>(a.v * b, a.d * b); }
-template <class R> __device__ __forceinline__ Du<R> operator/(Du<R> a, Du<R> b) { R iv = R(1) / b.v; R q = a.v * iv; return Du<R>(q, (a.d - q * b.d) * iv); }
+#define TS_PAIR_GROUP 4      // contact pairs staged in LDS at a time
+// per-link value record in LDS (reals)
+enum { LK_R = 0, LK_P = 9, LK_W = 12, LK_V = 15, LK_AW = 18, LK_AV = 21, LK_FN = 24, LK_FF = 27, LK_C = 30, LK_IC = 33,
+       LK_JW = 39, LK_JV = 42, LK_SIZE = 45 };
+// per (link, direction) tangent record: d(twist) d(acceleration) d(wrench)
+enum { DT_VW = 0, DT_VV = 3, DT_AW = 6, DT_AV = 9, DT_FN = 12, DT_FF = 15, DT_SIZE = 18 };
+// staged pair, value part: pose of A in the primitive frame P, relative twist in P, pose of P in the world, wrench sum (P frame)
+enum { PP_RPA = 0, PP_PPA = 9, PP_WREL = 12, PP_VREL = 15, PP_RP = 18, PP_PP = 27, PP_WN = 30, PP_WF = 33, PP_SIZE = 36 };
+// staged pair, per direction: relative displacement (P frame), d(relative twist), d(wrench sum)
+enum { PT_DTH = 0, PT_DRHO = 3, PT_DW = 6, PT_DV = 9, PT_WN = 12, PT_WF = 15, PT_SIZE = 18 };
 
 __device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
-template <class R> __device__ __forceinline__ Du<R> t_sqrt(Du<R> a) { R s = t_sqrt(a.v); return Du<R>(s, a.d * (R(0.5) / s)); }
 __device__ __forceinline__ void t_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
 __device__ __forceinline__ void t_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
-template <class R> __device__ __forceinline__ void t_sincos(Du<R> a, Du<R>& s, Du<R>& c) { R sv, cv; t_sincos(a.v, sv, cv); s = Du<R>(sv, a.d * cv); c = Du<R>(cv, -a.d * sv); }
-__device__ __forceinline__ float pv(float x) { return x; }
-__device__ __forceinline__ double pv(double x) { return x; }
-template <class R> __device__ __forceinline__ R pv(Du<R> x) { return x.v; }
 __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double t_abs(double x) { return fabs(x); }
 
 // ------------------------------------------------------------------------------------------------ 3-vectors / 3x3
 template <class T> struct V3 { T x, y, z; };
 template <class T> __device__ __forceinline__ V3<T> mk3(T x, T y, T z) { V3<T> r; r.x = x; r.y = y; r.z = z; return r; }
+template <class T> __device__ __forceinline__ V3<T> zero3() { return mk3<T>(T(0), T(0), T(0)); }
 template <class T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return mk3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
 template <class T> __device__ __forceinline__ V3<T> operator-(V3<T> a, V3<T> b) { return mk3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
 template <class T> __device__ __forceinline__ V3<T> operator*(V3<T> a, T s) { return mk3<T>(a.x * s, a.y * s, a.z * s); }
@@ -76,47 +62,54 @@ template <class T> __device__ __forceinline__ M3<T> mulMM(const M3<T>& A, const 
     for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
   return C;
 }
-// products with model constants (plain reals read from the blob): no tangent on the constant side
-template <class T, class R> __device__ __forceinline__ V3<T> mulMc(const M3<T>& A, const R* c) {
-  return mk3<T>(A.m[0] * c[0] + A.m[1] * c[1] + A.m[2] * c[2], A.m[3] * c[0] + A.m[4] * c[1] + A.m[5] * c[2], A.m[6] * c[0] + A.m[7] * c[1] + A.m[8] * c[2]);
-}
-template <class T, class R> __device__ __forceinline__ M3<T> mulMcM(const M3<T>& A, const R* c) {
+template <class T> __device__ __forceinline__ M3<T> mulMtM(const M3<T>& A, const M3<T>& B) {   // A^T B
   M3<T> C;
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * c[j] + A.m[3 * i + 1] * c[3 + j] + A.m[3 * i + 2] * c[6 + j];
+    for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[i] * B.m[j] + A.m[3 + i] * B.m[3 + j] + A.m[6 + i] * B.m[6 + j];
   return C;
 }
-
-// ------------------------------------------------------------------------------------------------ LDS access
-// value part at P[idx]; tangent of direction k at T[idx * nd + k] (direction fastest -> conflict-free for
-// lanes = directions, broadcast for lanes = points).
-template <class T> struct Lds;
-template <> struct Lds<float> {
-  static __device__ __forceinline__ float ld(const float* P, const float*, int idx, int, int) { return P[idx]; }
-};
-template <> struct Lds<double> {
-  static __device__ __forceinline__ double ld(const double* P, const double*, int idx, int, int) { return P[idx]; }
-};
-template <class R> struct Lds<Du<R>> {
-  static __device__ __forceinline__ Du<R> ld(const R* P, const R* T, int idx, int nd, int k) { return Du<R>(P[idx], T[idx * nd + k]); }
-};
-template <class T, class R> __device__ __forceinline__ V3<T> ld3(const R* P, const R* Tg, int idx, int nd, int k) {
-  return mk3<T>(Lds<T>::ld(P, Tg, idx, nd, k), Lds<T>::ld(P, Tg, idx + 1, nd, k), Lds<T>::ld(P, Tg, idx + 2, nd, k));
-}
-template <class T, class R> __device__ __forceinline__ M3<T> ld9(const R* P, const R* Tg, int idx, int nd, int k) {
-  M3<T> A;
+template <class T> __device__ __forceinline__ V3<T> ldv(const T* p) { return mk3<T>(p[0], p[1], p[2]); }
+template <class T> __device__ __forceinline__ M3<T> ldm(const T* p) { M3<T> A;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) A.m[i] = Lds<T>::ld(P, Tg, idx + i, nd, k);
-  return A;
+  for (int i = 0; i < 9; ++i) A.m[i] = p[i];
+  return A; }
+template <class T> __device__ __forceinline__ void stv(T* p, V3<T> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+template <class T> __device__ __forceinline__ void stm(T* p, const M3<T>& A) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p[i] = A.m[i];
 }
-template <class R> __device__ __forceinline__ void st(R* P, R* T, int idx, int nd, int k, bool wp, Du<R> x) {
-  if (wp) P[idx] = x.v;
-  T[idx * nd + k] = x.d;
+// symmetric 3x3 stored as (xx yy zz xy xz yz) times a vector
+template <class T> __device__ __forceinline__ V3<T> symv(const T* s, V3<T> v) {
+  return mk3<T>(s[0] * v.x + s[3] * v.y + s[4] * v.z, s[3] * v.x + s[1] * v.y + s[5] * v.z, s[4] * v.x + s[5] * v.y + s[2] * v.z);
 }
-template <class R> __device__ __forceinline__ void st3(R* P, R* T, int idx, int nd, int k, bool wp, V3<Du<R>> x) {
-  st(P, T, idx, nd, k, wp, x.x); st(P, T, idx + 1, nd, k, wp, x.y); st(P, T, idx + 2, nd, k, wp, x.z);
+
+// ------------------------------------------------------------------------------------------------ spatial 6-vectors
+// motion vectors (angular; linear) and force vectors (moment; force), world frame, about the world origin
+template <class T> struct S6 { V3<T> a, l; };
+template <class T> __device__ __forceinline__ S6<T> mk6(V3<T> a, V3<T> l) { S6<T> r; r.a = a; r.l = l; return r; }
+template <class T> __device__ __forceinline__ S6<T> zero6() { return mk6<T>(zero3<T>(), zero3<T>()); }
+template <class T> __device__ __forceinline__ S6<T> operator+(S6<T> x, S6<T> y) { return mk6<T>(x.a + y.a, x.l + y.l); }
+template <class T> __device__ __forceinline__ S6<T> operator-(S6<T> x, S6<T> y) { return mk6<T>(x.a - y.a, x.l - y.l); }
+template <class T> __device__ __forceinline__ S6<T> operator*(S6<T> x, T s) { return mk6<T>(x.a * s, x.l * s); }
+template <class T> __device__ __forceinline__ T dot6(S6<T> m, S6<T> f) { return dot3(m.a, f.a) + dot3(m.l, f.l); }
+template <class T> __device__ __forceinline__ S6<T> crm(S6<T> v, S6<T> m) { return mk6<T>(cross3(v.a, m.a), cross3(v.a, m.l) + cross3(v.l, m.a)); }   // v x m
+template <class T> __device__ __forceinline__ S6<T> crf(S6<T> v, S6<T> f) { return mk6<T>(cross3(v.a, f.a) + cross3(v.l, f.l), cross3(v.a, f.l)); }   // v x* f
+template <class T> __device__ __forceinline__ S6<T> ld6(const T* p) { return mk6<T>(ldv(p), ldv(p + 3)); }
+template <class T> __device__ __forceinline__ void st6(T* p, S6<T> v) { stv(p, v.a); stv(p + 3, v.l); }
+// spatial inertia (mass, world COM c, world rotational inertia about the COM) times a motion vector
+template <class T> __device__ __forceinline__ S6<T> imul(T mass, V3<T> c, const T* Ic, S6<T> m) {
+  V3<T> f = (m.l + cross3(m.a, c)) * mass;
+  return mk6<T>(symv(Ic, m.a) + cross3(c, f), f);
+}
+// world twist about the world origin -> frame P (pose R, p) about P's origin, and the dual map for wrenches
+template <class T> __device__ __forceinline__ S6<T> to_frame(const M3<T>& R, V3<T> p, S6<T> m) {
+  return mk6<T>(mulMtv(R, m.a), mulMtv(R, m.l + cross3(m.a, p)));
+}
+template <class T> __device__ __forceinline__ S6<T> wrench_to_world(const M3<T>& R, V3<T> p, S6<T> w) {
+  V3<T> f = mulMv(R, w.l);
+  return mk6<T>(mulMv(R, w.a) + cross3(p, f), f);
 }
 
 // ------------------------------------------------------------------------------------------------ wave reductions
@@ -161,22 +154,23 @@ template <class R> struct Ctx {
   R h, gx, gy, gz, tol;
   int max_iter, max_ls;
   // LDS
-  R *q, *q0, *qd0, *u, *qd, *qa, *g, *dq, *dl, *H, *lamq, *lamv, *z, *rhs;
-  R *LP, *LT, *WP, *WT, *scr;
+  R *q, *q0, *qd0, *u, *qd, *qa, *g, *dq, *dl, *H, *H2, *lamq, *lamv, *z, *rhs;
+  R *LP, *WP, *DT, *PP, *PT, *scr;
 };
 
 // number of LDS reals a block needs (host and device must agree)
 __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu) {
   int nd = nr;
   int n = 0;
-  n += 10 * nr + nu;           // q q0 qd0 qd qa g dq dl-base(2) dl ; u
-  n += nr * nr;                // H
-  n += 4 * nr;                 // lamq lamv z rhs
-  n += (nl + 1) * LK_SIZE;     // LP
-  n += nr * 6;                 // WP
-  n += (nl + 1) * LK_SIZE * nd;  // LT
-  n += nr * 6 * nd;            // WT
-  n += (nl + 1) * 12;          // scratch (M z pass)
+  n += 11 * nr + nu;                       // q q0 qd0 qd qa g dq(2) dl(2) spare ; u
+  n += 2 * nr * nr;                        // H, H2 (taped Newton matrix in the adjoint kernel)
+  n += 4 * nr;                             // lamq lamv z rhs
+  n += (nl + 1) * LK_SIZE;                 // LP
+  n += nr * 6;                             // WP
+  n += (nl + 1) * nd * DT_SIZE;            // DT
+  n += TS_PAIR_GROUP * PP_SIZE;            // PP
+  n += TS_PAIR_GROUP * nd * PT_SIZE;       // PT
+  n += 16;                                 // scratch
   return n + 8;
 }
 
@@ -196,13 +190,14 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
   int nr = c.nr, nl = c.nl, nd = c.nd;
   R* p = lds;
   c.q = p; p += nr; c.q0 = p; p += nr; c.qd0 = p; p += nr; c.qd = p; p += nr; c.qa = p; p += nr;
-  c.g = p; p += nr; c.dq = p; p += 2 * nr; c.dl = p; p += nr; c.u = p; p += c.nu;
-  c.H = p; p += nr * nr;
+  c.g = p; p += nr; c.dq = p; p += 2 * nr; c.dl = p; p += 2 * nr; c.u = p; p += c.nu;
+  c.H = p; p += nr * nr; c.H2 = p; p += nr * nr;
   c.lamq = p; p += nr; c.lamv = p; p += nr; c.z = p; p += nr; c.rhs = p; p += nr;
   c.LP = p; p += (nl + 1) * LK_SIZE;
   c.WP = p; p += nr * 6;
-  c.LT = p; p += (nl + 1) * LK_SIZE * nd;
-  c.WT = p; p += nr * 6 * nd;
+  c.DT = p; p += (nl + 1) * nd * DT_SIZE;
+  c.PP = p; p += TS_PAIR_GROUP * PP_SIZE;
+  c.PT = p; p += TS_PAIR_GROUP * nd * PT_SIZE;
   c.scr = p;
 }
 
@@ -216,50 +211,78 @@ template <class R> __device__ inline void init_world(const Ctx<R>& c, int lane) 
     if (i == LK_AV + 2) v = -c.gz;
     c.LP[i] = v;
   }
-  for (int i = lane; i < LK_SIZE * c.nd; i += TS_WAVE) c.LT[i] = R(0);
+  for (int i = lane; i < c.nd * DT_SIZE; i += TS_WAVE) c.DT[i] = R(0);
+}
+
+__device__ __forceinline__ int anc_of(const int* I, int off_link, int link) {
+  return link > 0 ? I[off_link + (link - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ contact law
-// DiffHand penalty model: d < 0:  fn = (-kn + kd ddot) d,  ft = -min(kt |vt|, mu |fn|) vt/|vt|.
-// Force on the point of link A (world frame); link B receives the opposite force at the same point.
-template <class T, class R>
-__device__ __forceinline__ bool contact_law(int prim, const R* shape, R kn, R kt, R mu, R kd, const M3<T>& RP, V3<T> pP,
-                                            V3<T> xw, V3<T> vrel, V3<T>& Fw) {
-  V3<T> x = mulMtv(RP, xw - pP);
-  T d; V3<T> n;
-  if (prim == TSIM_P_PLANE) { d = x.z; n = mk3<T>(T(R(0)), T(R(0)), T(R(1))); }
+// DiffHand penalty model in the primitive's frame: d < 0:  fn = (-kn + kd ddot) d,  ft = -min(kt |vt|, mu |fn|) vt/|vt|.
+// x = point in the primitive frame, v = its velocity relative to the primitive (same frame).
+// Returns the force on the point; with JAC also Jx = dF/dx and Jv = dF/dv (exact: the law is piecewise smooth).
+template <class R, bool JAC>
+__device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv) {
+  const R kn = kp[0], kt = kp[1], mu = kp[2], kd = kp[3];
+  R d; V3<R> n;
+  R ncurv = R(0);          // N = dn/dx = ncurv * (Pm - n n^T), Pm = diag(1, 1, pz)
+  R pz = R(1);
+  if (prim == TSIM_P_PLANE) { d = x.z; n = mk3<R>(R(0), R(0), R(1)); }
   else if (prim == TSIM_P_CUBOID) {
-    R ex = t_abs(pv(x.x)) - shape[0], ey = t_abs(pv(x.y)) - shape[1], ez = t_abs(pv(x.z)) - shape[2];
-    if (ex >= ey && ex >= ez) { R s = pv(x.x) >= R(0) ? R(1) : R(-1); d = x.x * s - T(shape[0]); n = mk3<T>(T(s), T(R(0)), T(R(0))); }
-    else if (ey >= ez)        { R s = pv(x.y) >= R(0) ? R(1) : R(-1); d = x.y * s - T(shape[1]); n = mk3<T>(T(R(0)), T(s), T(R(0))); }
-    else                      { R s = pv(x.z) >= R(0) ? R(1) : R(-1); d = x.z * s - T(shape[2]); n = mk3<T>(T(R(0)), T(R(0)), T(s)); }
+    const R ex = t_abs(x.x) - shape[0], ey = t_abs(x.y) - shape[1], ez = t_abs(x.z) - shape[2];
+    if (ex >= ey && ex >= ez) { const R s = x.x >= R(0) ? R(1) : R(-1); d = ex; n = mk3<R>(s, R(0), R(0)); }
+    else if (ey >= ez)        { const R s = x.y >= R(0) ? R(1) : R(-1); d = ey; n = mk3<R>(R(0), s, R(0)); }
+    else                      { const R s = x.z >= R(0) ? R(1) : R(-1); d = ez; n = mk3<R>(R(0), R(0), s); }
   } else if (prim == TSIM_P_SPHERE) {
-    T r2 = dot3(x, x);
-    if (pv(r2) < R(1e-24)) return false;
-    T r = t_sqrt(r2); d = r - T(shape[0]); n = x * (T(R(1)) / r);
+    const R r2 = dot3(x, x);
+    if (r2 < R(1e-24)) return false;
+    const R r = t_sqrt(r2); d = r - shape[0]; n = x * (R(1) / r); ncurv = R(1) / r;
   } else {
-    T rho2 = x.x * x.x + x.y * x.y;
-    R rho = t_sqrt(pv(rho2));
-    R dr = rho - shape[0], dz = t_abs(pv(x.z)) - shape[1];
-    if (dr > dz && rho > R(1e-12)) { T rr = t_sqrt(rho2); d = rr - T(shape[0]); T ir = T(R(1)) / rr; n = mk3<T>(x.x * ir, x.y * ir, T(R(0))); }
-    else { R s = pv(x.z) >= R(0) ? R(1) : R(-1); d = x.z * s - T(shape[1]); n = mk3<T>(T(R(0)), T(R(0)), T(s)); }
+    const R rho = t_sqrt(x.x * x.x + x.y * x.y);
+    const R dr = rho - shape[0], dz = t_abs(x.z) - shape[1];
+    if (dr > dz && rho > R(1e-12)) { d = dr; const R ir = R(1) / rho; n = mk3<R>(x.x * ir, x.y * ir, R(0)); ncurv = ir; pz = R(0); }
+    else { const R s = x.z >= R(0) ? R(1) : R(-1); d = dz; n = mk3<R>(R(0), R(0), s); }
   }
-  if (!(pv(d) < R(0))) return false;
-  V3<T> xd = mulMtv(RP, vrel);
-  T ddot = dot3(n, xd);
-  T fn = (T(-kn) + ddot * kd) * d;
-  V3<T> vt = xd - n * ddot;
-  T vt2 = dot3(vt, vt);
-  V3<T> Fl = n * fn;
-  R vtn = t_sqrt(pv(vt2));
-  R fna = t_abs(pv(fn));
-  if (kt * vtn <= mu * fna || vtn < R(1e-14)) {
-    Fl = Fl - vt * T(kt);
-  } else {
-    T fabs_ = pv(fn) >= R(0) ? fn : -fn;
-    T s = fabs_ * mu / t_sqrt(vt2);
-    Fl = Fl - vt * s;
+  if (!(d < R(0))) return false;
+  const R dd = dot3(n, v);
+  const R a = -kn + kd * dd;
+  const R fn = a * d;
+  const V3<R> vt = v - n * dd;
+  const R vtn = t_sqrt(dot3(vt, vt));
+  const bool stick = kt * vtn <= mu * t_abs(fn) || vtn < R(1e-14);
+  R s = kt;
+  const R sg = fn >= R(0) ? R(1) : R(-1);
+  if (!stick) s = mu * sg * fn / vtn;
+  F = n * fn - vt * s;
+  if (JAC) {
+    // N w = ncurv (Pm w - n (n.w))
+    const V3<R> Nv = (mk3<R>(v.x, v.y, pz * v.z) - n * dd) * ncurv;
+    const V3<R> dfx = n * a + Nv * (kd * d);       // d fn / dx
+    const V3<R> dfv = n * (kd * d);                // d fn / dv
+    V3<R> dsx = zero3<R>(), dsv = zero3<R>();
+    if (!stick) {
+      const R c1 = mu * sg / vtn, c2 = s / (vtn * vtn);
+      const V3<R> Nvt = (mk3<R>(vt.x, vt.y, pz * vt.z)) * ncurv;     // n.vt = 0
+      dsx = dfx * c1 + Nvt * (c2 * dd);
+      dsv = dfv * c1 - vt * c2;
+    }
+    // Jx = n dfx^T + fn N - vt dsx^T - s dvt/dx ,  dvt/dx = -n Nv^T - dd N
+    // Jv = n dfv^T        - vt dsv^T - s (I - n n^T)
+    const R nn[3] = {n.x, n.y, n.z}, vv[3] = {vt.x, vt.y, vt.z};
+    const R ax[3] = {dfx.x + s * Nv.x, dfx.y + s * Nv.y, dfx.z + s * Nv.z};     // n (dfx + s Nv)^T
+    const R bx[3] = {dsx.x, dsx.y, dsx.z};
+    const R av[3] = {dfv.x, dfv.y, dfv.z}, bv[3] = {dsv.x, dsv.y, dsv.z};
+    const R kN = (fn + s * dd) * ncurv;                                          // (fn + s dd) N
+    const R pm[3] = {R(1), R(1), pz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const R nnij = nn[i] * nn[j];
+        Jx.m[3 * i + j] = nn[i] * ax[j] - vv[i] * bx[j] + kN * ((i == j ? pm[i] : R(0)) - nnij);
+        Jv.m[3 * i + j] = nn[i] * av[j] - vv[i] * bv[j] - s * ((i == j ? R(1) : R(0)) - nnij);
+      }
   }
-  Fw = mulMv(RP, Fl);
   return true;
 }

@@ -1,185 +1,305 @@
 // tsim_eval.h — one residual evaluation g(q1) with its exact tangents, and the small dense solve.
 // See tsim_device.h for the execution model.  Reference counterpart: the per-sub-step Newton body behind
-// `sim.forward()` (envs/redmax_torch_functions.py:132); formulation in DESIGN.md §Physics.
+// `sim.forward()` (envs/redmax_torch_functions.py:132); formulation in DESIGN.md §1.
+//
+// Tangents are propagated analytically with world-frame spatial algebra (constant joint-frame twists S):
+//   d(pose of link i)/d q_k   = W_k                        (as a spatial displacement)  if dof k is at or above link i
+//   d W_j / d q_k             = W_k x W_j                  (spatial cross product)       if dof k is at or above link(j)
+//   d V_i, d A_i              by the recursion that defines V_i, A_i
+//   d(I_i) m                  = dxi x* (I m) - I (dxi x m)
+// and are verified against the oracle's dual-number Jacobian to round-off (tests/test_gpu_parity.py).
 #pragma once
 #include "tsim_device.h"
 
-// ================================================================================================ phase 1
-// lanes = directions.  Lane k < nr walks the links root->leaf with dual numbers seeded on dof k:
-//   q_k += eps*sq, qd_k += eps*sv, qdd_k += eps*sa.
-// Writes per link: pose, spatial velocity / acceleration, inertial wrench (value by lane 0, tangent k by
-// lane k) and the world-frame twist columns W of the link's dofs.
+// ================================================================================================ phase 1 (values)
+// Every lane computes the same values (uniform control flow); lane 0 stores them.
 template <class R>
-__device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
-  typedef Du<R> D;
-  const int nd = c.nd, k = lane;
-  const bool act = lane < c.nr;
-  const bool wp = lane == 0;
+__device__ void phase1(const Ctx<R>& c, int lane) {
   for (int i = 1; i <= c.nl; ++i) {
-    if (act) {
-      const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
-      const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
-      const int par = li[TSIM_LI_PARENT], jt = li[TSIM_LI_JTYPE], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
-      const int pb = par * LK_SIZE, xb = i * LK_SIZE;
-      M3<D> XR; V3<D> Xp;
-      // joint twist V_J = sum W_k qd_k and the qdd part sum W_k qdd_k, accumulated while the columns are built
-      V3<D> jw = mk3<D>(D(R(0)), D(R(0)), D(R(0))), jv = jw, bw = jw, bv = jw;
-      {
-        M3<D> PR = ld9<D>(c.LP, c.LT, pb + LK_R, nd, k);
-        V3<D> Pp = ld3<D>(c.LP, c.LT, pb + LK_P, nd, k);
-        M3<D> R0 = mulMcM(PR, lf + TSIM_LF_R);
-        V3<D> p0 = mulMc(PR, lf + TSIM_LF_P) + Pp;
-        const R* ax = lf + TSIM_LF_AXES;
-        if (jt == TSIM_J_REVOLUTE) {
-          D th(c.q[k0], k == k0 ? sq : R(0));
-          D s, co; t_sincos(th, s, co);
-          D t = D(R(1)) - co;
-          M3<D> Q;
-          Q.m[0] = t * (ax[0] * ax[0]) + co;         Q.m[1] = t * (ax[0] * ax[1]) - s * ax[2];  Q.m[2] = t * (ax[0] * ax[2]) + s * ax[1];
-          Q.m[3] = t * (ax[0] * ax[1]) + s * ax[2];  Q.m[4] = t * (ax[1] * ax[1]) + co;         Q.m[5] = t * (ax[1] * ax[2]) - s * ax[0];
-          Q.m[6] = t * (ax[0] * ax[2]) - s * ax[1];  Q.m[7] = t * (ax[1] * ax[2]) + s * ax[0];  Q.m[8] = t * (ax[2] * ax[2]) + co;
-          XR = mulMM(R0, Q); Xp = p0;
-          V3<D> a = mulMc(R0, ax);          // the axis is invariant under its own rotation
-          V3<D> av = cross3(Xp, a);
-          st3(c.WP, c.WT, k0 * 6, nd, k, wp, a);
-          st3(c.WP, c.WT, k0 * 6 + 3, nd, k, wp, av);
-          D qd(c.qd[k0], k == k0 ? sv : R(0)), qa(c.qa[k0], k == k0 ? sa : R(0));
-          jw = a * qd; jv = av * qd; bw = a * qa; bv = av * qa;
-        } else {  // prismatic / planar / translational: pure translations along constant joint-frame axes
-          XR = R0; Xp = p0;
-          for (int kk = 0; kk < ndj; ++kk) {
-            R e[3] = {kk == 0 ? R(1) : R(0), kk == 1 ? R(1) : R(0), kk == 2 ? R(1) : R(0)};
-            V3<D> a = mulMc(R0, jt == TSIM_J_TRANSLATIONAL ? e : ax + 3 * kk);
-            const int kd = k0 + kk;
-            D qk(c.q[kd], k == kd ? sq : R(0));
-            Xp = Xp + a * qk;
-            st3(c.WP, c.WT, kd * 6, nd, k, wp, mk3<D>(D(R(0)), D(R(0)), D(R(0))));
-            st3(c.WP, c.WT, kd * 6 + 3, nd, k, wp, a);
-            D qd(c.qd[kd], k == kd ? sv : R(0)), qa(c.qa[kd], k == kd ? sa : R(0));
-            jv = jv + a * qd; bv = bv + a * qa;
-          }
-        }
+    const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
+    const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
+    const int par = li[TSIM_LI_PARENT], jt = li[TSIM_LI_JTYPE], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
+    const R* P = c.LP + par * LK_SIZE;
+    R* X = c.LP + i * LK_SIZE;
+    const M3<R> PR = ldm(P + LK_R);
+    const M3<R> R0 = mulMM(PR, ldm(lf + TSIM_LF_R));
+    V3<R> Xp = mulMv(PR, ldv(lf + TSIM_LF_P)) + ldv(P + LK_P);
+    M3<R> XR = R0;
+    const R* ax = lf + TSIM_LF_AXES;
+    S6<R> VJ = zero6<R>(), AJ = zero6<R>();
+    if (jt == TSIM_J_REVOLUTE) {
+      R s, co; t_sincos(c.q[k0], s, co);
+      const R t = R(1) - co;
+      M3<R> Q;
+      Q.m[0] = t * ax[0] * ax[0] + co;         Q.m[1] = t * ax[0] * ax[1] - s * ax[2];  Q.m[2] = t * ax[0] * ax[2] + s * ax[1];
+      Q.m[3] = t * ax[0] * ax[1] + s * ax[2];  Q.m[4] = t * ax[1] * ax[1] + co;         Q.m[5] = t * ax[1] * ax[2] - s * ax[0];
+      Q.m[6] = t * ax[0] * ax[2] - s * ax[1];  Q.m[7] = t * ax[1] * ax[2] + s * ax[0];  Q.m[8] = t * ax[2] * ax[2] + co;
+      XR = mulMM(R0, Q);
+      const V3<R> a = mulMv(R0, ldv(ax));          // the axis is invariant under its own rotation
+      const S6<R> W = mk6<R>(a, cross3(Xp, a));
+      if (lane == 0) st6(c.WP + k0 * 6, W);
+      VJ = W * c.qd[k0]; AJ = W * c.qa[k0];
+    } else {   // prismatic / planar / translational
+      for (int kk = 0; kk < ndj; ++kk) {
+        const R e[3] = {kk == 0 ? R(1) : R(0), kk == 1 ? R(1) : R(0), kk == 2 ? R(1) : R(0)};
+        const V3<R> a = mulMv(R0, ldv(jt == TSIM_J_TRANSLATIONAL ? e : ax + 3 * kk));
+        Xp = Xp + a * c.q[k0 + kk];
+        const S6<R> W = mk6<R>(zero3<R>(), a);
+        if (lane == 0) st6(c.WP + (k0 + kk) * 6, W);
+        VJ = VJ + W * c.qd[k0 + kk]; AJ = AJ + W * c.qa[k0 + kk];
       }
+    }
+    const S6<R> V = ld6(P + LK_W) + VJ;
+    const S6<R> A = ld6(P + LK_AW) + AJ + crm(V, VJ);
+    const V3<R> cw = mulMv(XR, ldv(lf + TSIM_LF_COM)) + Xp;
+    // world rotational inertia  Ic = XR Il XR^T  (symmetric, 6 entries)
+    const R* il = lf + TSIM_LF_INERTIA;
+    M3<R> T;        // T = XR * Il
 #pragma unroll
-      for (int e = 0; e < 9; ++e) st(c.LP, c.LT, xb + LK_R + e, nd, k, wp, XR.m[e]);
-      st3(c.LP, c.LT, xb + LK_P, nd, k, wp, Xp);
-      // V_i = V_p + V_J ;  A_i = A_p + sum W_k qdd_k + V_i x^ V_J   (constant joint-frame S)
-      V3<D> Xw = ld3<D>(c.LP, c.LT, pb + LK_W, nd, k) + jw;
-      V3<D> Xv = ld3<D>(c.LP, c.LT, pb + LK_V, nd, k) + jv;
-      V3<D> Xaw = ld3<D>(c.LP, c.LT, pb + LK_AW, nd, k) + bw + cross3(Xw, jw);
-      V3<D> Xav = ld3<D>(c.LP, c.LT, pb + LK_AV, nd, k) + bv + cross3(Xw, jv) + cross3(Xv, jw);
-      st3(c.LP, c.LT, xb + LK_W, nd, k, wp, Xw);
-      st3(c.LP, c.LT, xb + LK_V, nd, k, wp, Xv);
-      st3(c.LP, c.LT, xb + LK_AW, nd, k, wp, Xaw);
-      st3(c.LP, c.LT, xb + LK_AV, nd, k, wp, Xav);
-      // inertial wrench about the world origin
-      V3<D> cw = mulMc(XR, lf + TSIM_LF_COM) + Xp;
-      V3<D> vc = Xv + cross3(Xw, cw);
-      V3<D> ac = Xav + cross3(Xaw, cw) + cross3(Xw, vc);
-      V3<D> f = ac * D(lf[TSIM_LF_MASS]);
-      const R* ii = lf + TSIM_LF_INERTIA;
-      V3<D> wl = mulMtv(XR, Xw), al = mulMtv(XR, Xaw);
-      V3<D> Iw = mk3<D>(wl.x * ii[0] + wl.y * ii[3] + wl.z * ii[4], wl.x * ii[3] + wl.y * ii[1] + wl.z * ii[5], wl.x * ii[4] + wl.y * ii[5] + wl.z * ii[2]);
-      V3<D> Ia = mk3<D>(al.x * ii[0] + al.y * ii[3] + al.z * ii[4], al.x * ii[3] + al.y * ii[1] + al.z * ii[5], al.x * ii[4] + al.y * ii[5] + al.z * ii[2]);
-      V3<D> nc = mulMv(XR, Ia + cross3(wl, Iw));
-      st3(c.LP, c.LT, xb + LK_FF, nd, k, wp, f);
-      st3(c.LP, c.LT, xb + LK_FN, nd, k, wp, nc + cross3(cw, f));
+    for (int r = 0; r < 3; ++r) {
+      T.m[3 * r + 0] = XR.m[3 * r] * il[0] + XR.m[3 * r + 1] * il[3] + XR.m[3 * r + 2] * il[4];
+      T.m[3 * r + 1] = XR.m[3 * r] * il[3] + XR.m[3 * r + 1] * il[1] + XR.m[3 * r + 2] * il[5];
+      T.m[3 * r + 2] = XR.m[3 * r] * il[4] + XR.m[3 * r + 1] * il[5] + XR.m[3 * r + 2] * il[2];
+    }
+    R Ic[6];
+    Ic[0] = T.m[0] * XR.m[0] + T.m[1] * XR.m[1] + T.m[2] * XR.m[2];
+    Ic[1] = T.m[3] * XR.m[3] + T.m[4] * XR.m[4] + T.m[5] * XR.m[5];
+    Ic[2] = T.m[6] * XR.m[6] + T.m[7] * XR.m[7] + T.m[8] * XR.m[8];
+    Ic[3] = T.m[0] * XR.m[3] + T.m[1] * XR.m[4] + T.m[2] * XR.m[5];
+    Ic[4] = T.m[0] * XR.m[6] + T.m[1] * XR.m[7] + T.m[2] * XR.m[8];
+    Ic[5] = T.m[3] * XR.m[6] + T.m[4] * XR.m[7] + T.m[5] * XR.m[8];
+    const R mass = lf[TSIM_LF_MASS];
+    const S6<R> Fi = imul(mass, cw, Ic, A) + crf(V, imul(mass, cw, Ic, V));
+    if (lane == 0) {
+      stm(X + LK_R, XR); stv(X + LK_P, Xp); st6(X + LK_W, V); st6(X + LK_AW, A); st6(X + LK_FN, Fi);
+      stv(X + LK_C, cw);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) X[LK_IC + e] = Ic[e];
+      st6(X + LK_JW, VJ);
     }
     __syncthreads();
   }
 }
 
-// ================================================================================================ phase 2
-// lanes = contact points.  For every dynamics-active pair: value pass (which points penetrate, value
-// wrench), then one dual pass per relevant direction; wave butterfly sums; lane 0 folds the pair's wrench
-// into link A (minus) and link B (plus).
-// Force on a point fixed to link A (link-frame coordinates xa) against the primitive of a pair fixed to link B.
-// kp = {kn, kt, mu, kd}.  Link quantities are passed by value so that callers choose where tangents come from.
-template <class T, class R>
-__device__ __forceinline__ bool point_force(int prim, const R* pf, const R* kp, bool sphere_plane, const M3<T>& RA, V3<T> pA,
-                                            V3<T> wA, V3<T> vA, const M3<T>& RB, V3<T> pB, V3<T> wB, V3<T> vB, V3<R> xa,
-                                            V3<T>& Fw, V3<T>& xw) {
-  M3<T> RP = mulMcM(RB, pf + TSIM_PF_R);
-  V3<T> pP = mulMc(RB, pf + TSIM_PF_P) + pB;
-  R xac[3] = {xa.x, xa.y, xa.z};
-  xw = mulMc(RA, xac) + pA;
-  if (sphere_plane) xw = xw - mk3<T>(RP.m[2], RP.m[5], RP.m[8]) * T(pf[TSIM_PF_SHAPE]);
-  V3<T> vrel = (vA + cross3(wA, xw)) - (vB + cross3(wB, xw));
-  return contact_law<T, R>(prim, pf + TSIM_PF_SHAPE, kp[0], kp[1], kp[2], kp[3], RP, pP, xw, vrel, Fw);
-}
-// same, link quantities (value + tangent of direction dir) read from LDS
-template <class T, class R>
-__device__ __forceinline__ bool pair_point_force(const Ctx<R>& c, const int* pi, const R* pf, const R* kp, int la, int lb, int dir,
-                                                 V3<R> xa, bool sphere_plane, V3<T>& Fw, V3<T>& mo) {
-  const int nd = c.nd, ab = la * LK_SIZE, bb = lb * LK_SIZE;
-  M3<T> RA = ld9<T>(c.LP, c.LT, ab + LK_R, nd, dir);
-  M3<T> RB = ld9<T>(c.LP, c.LT, bb + LK_R, nd, dir);
-  V3<T> xw;
-  bool hit = point_force<T, R>(pi[TSIM_PI_PRIM], pf, kp, sphere_plane, RA, ld3<T>(c.LP, c.LT, ab + LK_P, nd, dir),
-                               ld3<T>(c.LP, c.LT, ab + LK_W, nd, dir), ld3<T>(c.LP, c.LT, ab + LK_V, nd, dir), RB,
-                               ld3<T>(c.LP, c.LT, bb + LK_P, nd, dir), ld3<T>(c.LP, c.LT, bb + LK_W, nd, dir),
-                               ld3<T>(c.LP, c.LT, bb + LK_V, nd, dir), xa, Fw, xw);
-  if (hit) mo = cross3(xw, Fw);
-  return hit;
+// ================================================================================================ phase 1t (tangents)
+// lanes = directions.  Seeds on dof k: q_k += eps*sq, qd_k += eps*sv, qdd_k += eps*sa.
+template <class R>
+__device__ void phase1t(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+  const int k = lane, nd = c.nd;
+  if (k >= c.nr) return;
+  const S6<R> Wk = ld6(c.WP + k * 6);
+  for (int i = 1; i <= c.nl; ++i) {
+    const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
+    R* D = c.DT + (i * nd + k) * DT_SIZE;
+    if (!((li[TSIM_LI_ANCMASK] >> k) & 1)) {      // dof k does not move link i
+#pragma unroll
+      for (int e = 0; e < DT_SIZE; ++e) D[e] = R(0);
+      continue;
+    }
+    const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
+    const int par = li[TSIM_LI_PARENT], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
+    const R* X = c.LP + i * LK_SIZE;
+    const R* Dp = c.DT + (par * nd + k) * DT_SIZE;
+    const S6<R> dxi = Wk * sq;                                  // displacement of link i
+    const S6<R> V = ld6(X + LK_W), A = ld6(X + LK_AW), VJ = ld6(X + LK_JW);
+    // joint part: dW_j = dxi x W_j ;  d(VJ) = sum dW_j qd_j + W_k sv ;  d(AJ) = sum dW_j qdd_j + W_k sa
+    S6<R> dVJ = zero6<R>(), dAJ = zero6<R>();
+    for (int j = k0; j < k0 + ndj; ++j) {
+      const S6<R> dW = crm(dxi, ld6(c.WP + j * 6));
+      dVJ = dVJ + dW * c.qd[j]; dAJ = dAJ + dW * c.qa[j];
+    }
+    if (k >= k0 && k < k0 + ndj) { dVJ = dVJ + Wk * sv; dAJ = dAJ + Wk * sa; }
+    const S6<R> dV = ld6(Dp + DT_VW) + dVJ;
+    const S6<R> dA = ld6(Dp + DT_AW) + dAJ + crm(dV, VJ) + crm(V, dVJ);
+    // inertial wrench  F = I A + V x* (I V)
+    const R mass = lf[TSIM_LF_MASS];
+    const V3<R> cw = ldv(X + LK_C);
+    const R* Ic = X + LK_IC;
+    const S6<R> h = imul(mass, cw, Ic, V), IA = imul(mass, cw, Ic, A);
+    const S6<R> dh = crf(dxi, h) - imul(mass, cw, Ic, crm(dxi, V)) + imul(mass, cw, Ic, dV);
+    const S6<R> dF = crf(dxi, IA) - imul(mass, cw, Ic, crm(dxi, A)) + imul(mass, cw, Ic, dA) + crf(dV, h) + crf(V, dh);
+    st6(D + DT_VW, dV); st6(D + DT_AW, dA); st6(D + DT_FN, dF);
+  }
 }
 
+// ================================================================================================ staged pairs
+// value record of pair pk in slot: pose of A in the primitive frame, relative twist (A w.r.t. B) in that frame
 template <class R>
-__device__ void phase2(const Ctx<R>& c, int lane) {
-  typedef Du<R> D;
+__device__ void pair_stage_value(const Ctx<R>& c, int pk, int slot, int lane) {
+  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+  const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+  const R* A = c.LP + pi[TSIM_PI_LINKA] * LK_SIZE;
+  const R* B = c.LP + pi[TSIM_PI_LINKB] * LK_SIZE;
+  const M3<R> RB = ldm(B + LK_R);
+  const M3<R> RP = mulMM(RB, ldm(pf + TSIM_PF_R));
+  const V3<R> pP = mulMv(RB, ldv(pf + TSIM_PF_P)) + ldv(B + LK_P);
+  const M3<R> RPA = mulMtM(RP, ldm(A + LK_R));
+  const V3<R> pPA = mulMtv(RP, ldv(A + LK_P) - pP);
+  const S6<R> Vrel = to_frame(RP, pP, ld6(A + LK_W) - ld6(B + LK_W));
+  if (lane == 0) {
+    R* S = c.PP + slot * PP_SIZE;
+    stm(S + PP_RPA, RPA); stv(S + PP_PPA, pPA); st6(S + PP_WREL, Vrel); stm(S + PP_RP, RP); stv(S + PP_PP, pP);
+    st6(S + PP_WN, zero6<R>());
+  }
+}
+// per-direction record (lane = direction k): relative displacement and d(relative twist), both in the primitive frame.
+// vmode 0: tangents of the current seeds (link records DT);  vmode 1: d/d(qd_k) only (d twist = W_k, poses fixed).
+template <class R>
+__device__ void pair_stage_tangent(const Ctx<R>& c, int pk, int slot, int lane, R sq, int vmode) {
+  const int k = lane, nd = c.nd;
+  if (k >= c.nr) return;
+  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+  const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB];
+  const R* S = c.PP + slot * PP_SIZE;
+  R* T = c.PT + (slot * nd + k) * PT_SIZE;
+  const R inA = ((anc_of(c.I, c.off_link, la) >> k) & 1) ? R(1) : R(0);
+  const R inB = ((anc_of(c.I, c.off_link, lb) >> k) & 1) ? R(1) : R(0);
+  const M3<R> RP = ldm(S + PP_RP);
+  const V3<R> pP = ldv(S + PP_PP);
+  const S6<R> Wk = ld6(c.WP + k * 6);
+  S6<R> dxiP = zero6<R>(), dVrel;
+  if (vmode == 0) {
+    dxiP = to_frame(RP, pP, Wk * (sq * (inA - inB)));
+    const S6<R> dxiB = to_frame(RP, pP, Wk * (sq * inB));
+    dVrel = to_frame(RP, pP, ld6(c.DT + (la * nd + k) * DT_SIZE + DT_VW) - ld6(c.DT + (lb * nd + k) * DT_SIZE + DT_VW))
+            - crm(dxiB, ld6(S + PP_WREL));
+  } else {
+    dVrel = to_frame(RP, pP, Wk * (inA - inB));
+  }
+  st6(T + PT_DTH, dxiP); st6(T + PT_DW, dVrel); st6(T + PT_WN, zero6<R>());
+}
+
+// ================================================================================================ phase 2
+// lanes = contact points of the staged pairs.  Value wrench and, per relevant direction, its tangent — both in the
+// primitive frame — are accumulated per lane over the pair's chunks and reduced once per pair.
+template <class R, int NRM>
+__device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
   const int nd = c.nd;
-  for (int pk = 0; pk < c.npair; ++pk) {
-    const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
-    const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-    const int flags = pi[TSIM_PI_FLAGS];
-    if (!(flags & 1)) continue;
-    const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB], pt0 = pi[TSIM_PI_PT0], npt = pi[TSIM_PI_NPT];
-    const int ancA = la > 0 ? c.I[c.off_link + (la - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
-    const int ancB = lb > 0 ? c.I[c.off_link + (lb - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
-    const int anc = ancA | ancB;
-    for (int base = 0; base < npt; base += TS_WAVE) {
-      const int pidx = base + lane;
-      const bool valid = pidx < npt;
-      V3<R> xa = mk3<R>(R(0), R(0), R(0));
-      if (valid) {
-        const R* cp = c.F + c.foff_cpt + pt0 + pidx;    // SoA: consecutive lanes -> consecutive addresses
-        xa = mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt]);
-      }
-      V3<R> F0 = mk3<R>(R(0), R(0), R(0)), M0 = F0;
-      bool hit = false;
-      if (valid) {
-        V3<R> Fw, mo;
-        hit = pair_point_force<R, R>(c, pi, pf, pf + TSIM_PF_KN, la, lb, 0, xa, (flags & 2) != 0, Fw, mo);
-        if (hit) { F0 = Fw; M0 = mo; }
-      }
-      if (!__any(hit)) continue;
-      R s0 = wave_sum(M0.x), s1 = wave_sum(M0.y), s2 = wave_sum(M0.z), s3 = wave_sum(F0.x), s4 = wave_sum(F0.y), s5 = wave_sum(F0.z);
-      if (lane == 0) {
-        R* a = c.LP + la * LK_SIZE + LK_FN;
-        a[0] -= s0; a[1] -= s1; a[2] -= s2; a[3] -= s3; a[4] -= s4; a[5] -= s5;
-        if (lb > 0) { R* b = c.LP + lb * LK_SIZE + LK_FN; b[0] += s0; b[1] += s1; b[2] += s2; b[3] += s3; b[4] += s4; b[5] += s5; }
-      }
-      for (int dir = 0; dir < nd; ++dir) {
-        if (!((anc >> dir) & 1)) continue;
-        V3<D> Fw, mo;
-        R t0 = R(0), t1 = R(0), t2 = R(0), t3 = R(0), t4 = R(0), t5 = R(0);
+  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+  const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+  const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB], pt0 = pi[TSIM_PI_PT0], npt = pi[TSIM_PI_NPT];
+  const int prim = pi[TSIM_PI_PRIM];
+  const bool sphere_plane = (pi[TSIM_PI_FLAGS] & 2) != 0;
+  const int anc = anc_of(c.I, c.off_link, la) | anc_of(c.I, c.off_link, lb);
+  R* S = c.PP + slot * PP_SIZE;
+  const M3<R> RPA = ldm(S + PP_RPA);
+  const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+  R acc[NRM + 1][6];
+#pragma unroll
+  for (int d = 0; d <= NRM; ++d)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) acc[d][e] = R(0);
+  bool any_hit = false;
+  for (int base = 0; base < npt; base += TS_WAVE) {
+    const int pidx = base + lane;
+    bool hit = false;
+    V3<R> cP = zero3<R>(), xP = cP, F = cP;
+    M3<R> Jx, Jv;
+    if (pidx < npt) {
+      const R* cp = c.F + c.foff_cpt + pt0 + pidx;        // SoA: consecutive lanes -> consecutive addresses
+      cP = mulMv(RPA, mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt])) + pPA;
+      xP = cP;
+      if (sphere_plane) xP.z -= pf[TSIM_PF_SHAPE];         // lowest point of the sphere (plane normal = +z of P)
+      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv);
+    }
+    if (!__any(hit)) continue;
+    any_hit = true;
+    if (hit) {
+      const V3<R> n0 = cross3(xP, F);
+      acc[0][0] += n0.x; acc[0][1] += n0.y; acc[0][2] += n0.z; acc[0][3] += F.x; acc[0][4] += F.y; acc[0][5] += F.z;
+    }
+#pragma unroll
+    for (int d = 0; d < NRM; ++d) {
+      if (d < nd && ((anc >> d) & 1)) {
+        const R* T = c.PT + (slot * nd + d) * PT_SIZE;                       // LDS broadcast, 12 reals
+        const V3<R> dth = ldv(T + PT_DTH), drho = ldv(T + PT_DRHO), dw = ldv(T + PT_DW), dv = ldv(T + PT_DV);
         if (hit) {
-          if (pair_point_force<D, R>(c, pi, pf, pf + TSIM_PF_KN, la, lb, dir, xa, (flags & 2) != 0, Fw, mo)) {
-            t0 = mo.x.d; t1 = mo.y.d; t2 = mo.z.d; t3 = Fw.x.d; t4 = Fw.y.d; t5 = Fw.z.d;
-          }
-        }
-        t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); t3 = wave_sum(t3); t4 = wave_sum(t4); t5 = wave_sum(t5);
-        if (lane == 0) {
-          R* a = c.LT + (la * LK_SIZE + LK_FN) * nd + dir;
-          a[0] -= t0; a[nd] -= t1; a[2 * nd] -= t2; a[3 * nd] -= t3; a[4 * nd] -= t4; a[5 * nd] -= t5;
-          if (lb > 0) {
-            R* b = c.LT + (lb * LK_SIZE + LK_FN) * nd + dir;
-            b[0] += t0; b[nd] += t1; b[2 * nd] += t2; b[3 * nd] += t3; b[4 * nd] += t4; b[5 * nd] += t5;
-          }
+          const V3<R> dx = cross3(dth, cP) + drho;                           // displacement of the material point
+          const V3<R> dxd = dv + cross3(dw, xP) + cross3(wrel, dx);
+          const V3<R> dF = mulMv(Jx, dx) + mulMv(Jv, dxd);
+          const V3<R> dn = cross3(dx, F) + cross3(xP, dF);
+          acc[d + 1][0] += dn.x; acc[d + 1][1] += dn.y; acc[d + 1][2] += dn.z;
+          acc[d + 1][3] += dF.x; acc[d + 1][4] += dF.y; acc[d + 1][5] += dF.z;
         }
       }
     }
   }
-  __syncthreads();
+  if (!any_hit) return;
+  {
+    R s[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) s[e] = wave_sum(acc[0][e]);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) S[PP_WN + e] = s[e];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < NRM; ++d) {
+    if (d < nd && ((anc >> d) & 1)) {
+      R s[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s[e] = wave_sum(acc[d + 1][e]);
+      if (lane == 0) {
+        R* T = c.PT + (slot * nd + d) * PT_SIZE;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) T[PT_WN + e] = s[e];
+      }
+    }
+  }
+}
+
+// lanes = directions: bring the staged pair's wrench (value + tangent k) to the world frame and fold it into the links
+template <class R>
+__device__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
+  const int k = lane, nd = c.nd;
+  if (k >= c.nr) return;
+  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+  const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB];
+  const R* S = c.PP + slot * PP_SIZE;
+  const R* T = c.PT + (slot * nd + k) * PT_SIZE;
+  const M3<R> RP = ldm(S + PP_RP);
+  const V3<R> pP = ldv(S + PP_PP);
+  const S6<R> Ww = wrench_to_world(RP, pP, ld6(S + PP_WN));
+  const R inB = ((anc_of(c.I, c.off_link, lb) >> k) & 1) ? R(1) : R(0);
+  const S6<R> dWw = wrench_to_world(RP, pP, ld6(T + PT_WN)) + crf(ld6(c.WP + k * 6) * (sq * inB), Ww);
+  R* Da = c.DT + (la * nd + k) * DT_SIZE + DT_FN;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) { Da[e] -= (&dWw.a.x)[e]; Da[3 + e] -= (&dWw.l.x)[e]; }
+  if (lb > 0) {
+    R* Db = c.DT + (lb * nd + k) * DT_SIZE + DT_FN;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { Db[e] += (&dWw.a.x)[e]; Db[3 + e] += (&dWw.l.x)[e]; }
+  }
+  if (k == 0) {
+    R* Fa = c.LP + la * LK_SIZE + LK_FN;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { Fa[e] -= (&Ww.a.x)[e]; Fa[3 + e] -= (&Ww.l.x)[e]; }
+    if (lb > 0) {
+      R* Fb = c.LP + lb * LK_SIZE + LK_FN;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) { Fb[e] += (&Ww.a.x)[e]; Fb[3 + e] += (&Ww.l.x)[e]; }
+    }
+  }
+}
+
+template <class R, int NRM>
+__device__ void phase2(const Ctx<R>& c, int lane, R sq) {
+  for (int p0 = 0; p0 < c.npair; p0 += TS_PAIR_GROUP) {
+    const int pe = min(p0 + TS_PAIR_GROUP, c.npair);
+    for (int pk = p0; pk < pe; ++pk)
+      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_stage_value(c, pk, pk - p0, lane);
+    __syncthreads();
+    for (int pk = p0; pk < pe; ++pk)
+      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_stage_tangent(c, pk, pk - p0, lane, sq, 0);
+    __syncthreads();
+    for (int pk = p0; pk < pe; ++pk)
+      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_contacts<R, NRM>(c, pk, pk - p0, lane);
+    __syncthreads();
+    for (int pk = p0; pk < pe; ++pk)        // serial over pairs: two pairs may touch the same link
+      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_fold(c, pk, pk - p0, lane, sq);
+    __syncthreads();
+  }
 }
 
 // ================================================================================================ phase 3
@@ -188,27 +308,32 @@ __device__ void phase2(const Ctx<R>& c, int lane) {
 // column k).  Both are scaled by h^2.
 template <class R>
 __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
-  typedef Du<R> D;
   const int nd = c.nd, k = lane, nr = c.nr;
   const bool act = lane < nr;
   const R h2 = c.h * c.h;
+  const S6<R> Wk = act ? ld6(c.WP + k * 6) : zero6<R>();
   for (int i = c.nl; i >= 1; --i) {
     const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
     const int par = li[TSIM_LI_PARENT], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
     if (act) {
-      V3<D> fn = ld3<D>(c.LP, c.LT, i * LK_SIZE + LK_FN, nd, k), ff = ld3<D>(c.LP, c.LT, i * LK_SIZE + LK_FF, nd, k);
+      const S6<R> F = ld6(c.LP + i * LK_SIZE + LK_FN);
+      const S6<R> dF = ld6(c.DT + (i * nd + k) * DT_SIZE + DT_FN);
+      const bool moves = (li[TSIM_LI_ANCMASK] >> k) & 1;
       for (int j = k0; j < k0 + ndj; ++j) {
-        V3<D> Ww = ld3<D>(c.WP, c.WT, j * 6, nd, k), Wv = ld3<D>(c.WP, c.WT, j * 6 + 3, nd, k);
-        D tau = dot3(Ww, fn) + dot3(Wv, ff);
-        if (lane == 0) c.g[j] = tau.v;
-        c.H[j * nr + k] = tau.d;
+        const S6<R> Wj = ld6(c.WP + j * 6);
+        R dtau = dot6(Wj, dF);
+        if (moves) dtau += sq * dot6(crm(Wk, Wj), F);
+        c.H[j * nr + k] = dtau;
+        if (lane == 0) c.g[j] = dot6(Wj, F);
       }
       if (par > 0) {
-        R* pt = c.LT + (par * LK_SIZE + LK_FN) * nd + k;
-        pt[0] += fn.x.d; pt[nd] += fn.y.d; pt[2 * nd] += fn.z.d; pt[3 * nd] += ff.x.d; pt[4 * nd] += ff.y.d; pt[5 * nd] += ff.z.d;
+        R* pt = c.DT + (par * nd + k) * DT_SIZE + DT_FN;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { pt[e] += (&dF.a.x)[e]; pt[3 + e] += (&dF.l.x)[e]; }
         if (lane == 0) {
           R* pp = c.LP + par * LK_SIZE + LK_FN;
-          pp[0] += fn.x.v; pp[1] += fn.y.v; pp[2] += fn.z.v; pp[3] += ff.x.v; pp[4] += ff.y.v; pp[5] += ff.z.v;
+#pragma unroll
+          for (int e = 0; e < 3; ++e) { pp[e] += (&F.a.x)[e]; pp[3 + e] += (&F.l.x)[e]; }
         }
       }
     }
@@ -248,7 +373,7 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
 // The Newton unknown is the increment  dl = q1 - q0 - h qd0  (O(h^2 * acceleration)), not q1 itself, so that the
 // discrete acceleration dl/h^2 and velocity qd0 + dl/h keep full relative precision in fp32 (no q1 - q0 cancellation).
 // forward seeds: (1, 1/h, 1/h^2) -> H = dg/dq1 ;  adjoint seeds: (1, 0, 0) -> H = h^2 dr/dq.
-template <class R>
+template <class R, int NRM>
 __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   if (lane < c.nr) {
     const R d = c.dl[lane];
@@ -257,8 +382,10 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
     c.q[lane] = c.q0[lane] + (c.h * c.qd0[lane] + d);
   }
   __syncthreads();
-  phase1(c, lane, sq, sv, sa);
-  phase2(c, lane);
+  phase1(c, lane);
+  phase1t(c, lane, sq, sv, sa);
+  __syncthreads();
+  phase2<R, NRM>(c, lane, sq);
   phase3(c, lane, sq, sv);
 }
 

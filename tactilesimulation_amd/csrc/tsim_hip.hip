@@ -22,15 +22,13 @@ __host__ __device__ inline int ts_rec(int nr, int nu) { return 2 * nr + nr * nr 
 
 // ================================================================================================ read-out
 // variables: lanes = end-effector points; tactile: lanes = taxels (coalesced SoA loads of position / frame,
-// 12 B per lane contiguous stores).
+// 12 B per lane contiguous stores).  Each taxel is evaluated in the frame of the primitive it is tested against.
 template <class R>
 __device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_out) {
   if (var_out) {
     for (int e = lane; e < c.nvar; e += TS_WAVE) {
       const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
-      const R* vp = c.F + c.foff_var + e * TSIM_VF_SIZE;
-      M3<R> RA = ld9<R>(c.LP, c.LT, l * LK_SIZE + LK_R, c.nd, 0);
-      V3<R> x = mulMc(RA, vp) + ld3<R>(c.LP, c.LT, l * LK_SIZE + LK_P, c.nd, 0);
+      const V3<R> x = mulMv(ldm(c.LP + l * LK_SIZE + LK_R), ldv(c.F + c.foff_var + e * TSIM_VF_SIZE)) + ldv(c.LP + l * LK_SIZE + LK_P);
       R* o = var_out + (size_t)env * 3 * c.nvar + 3 * e;
       o[0] = x.x; o[1] = x.y; o[2] = x.z;
     }
@@ -39,26 +37,35 @@ __device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_o
   for (int s = 0; s < c.nsensor; ++s) {
     const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
     const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
-    const int la = si[TSIM_SI_LINK], t0 = si[TSIM_SI_TAX0], nt = si[TSIM_SI_NTAX], sp0 = si[TSIM_SI_SPRIM0], nsp = si[TSIM_SI_NSPRIM];
-    M3<R> RA = ld9<R>(c.LP, c.LT, la * LK_SIZE + LK_R, c.nd, 0);
-    for (int base = 0; base < nt; base += TS_WAVE) {
-      const int t = t0 + base + lane;
-      if (base + lane >= nt) continue;
-      const R* tp = c.F + c.foff_tax + t;
-      V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
-      V3<R> F = mk3<R>(R(0), R(0), R(0));
-      for (int j = 0; j < nsp; ++j) {
-        const int pk = c.I[c.off_sprim + sp0 + j];
-        const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
-        const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-        V3<R> Fw, mo;
-        if (pair_point_force<R, R>(c, pi, pf, sf, la, pi[TSIM_PI_LINKB], 0, xa, false, Fw, mo)) F = F + Fw;
+    const int t0 = si[TSIM_SI_TAX0], nt = si[TSIM_SI_NTAX], sp0 = si[TSIM_SI_SPRIM0], nsp = si[TSIM_SI_NSPRIM];
+    for (int j0 = 0; j0 < nsp || j0 == 0; j0 += TS_PAIR_GROUP) {
+      const int je = min(j0 + TS_PAIR_GROUP, nsp);
+      __syncthreads();
+      for (int j = j0; j < je; ++j) pair_stage_value(c, c.I[c.off_sprim + sp0 + j], j - j0, lane);
+      __syncthreads();
+      for (int base = 0; base < nt; base += TS_WAVE) {
+        const int t = t0 + base + lane;
+        if (base + lane >= nt) continue;
+        const R* tp = c.F + c.foff_tax + t;
+        const V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
+        V3<R> Fl = zero3<R>();                          // force on the taxel, sensor-link frame
+        for (int j = j0; j < je; ++j) {
+          const int pk = c.I[c.off_sprim + sp0 + j];
+          const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+          const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+          const R* S = c.PP + (j - j0) * PP_SIZE;
+          const M3<R> RPA = ldm(S + PP_RPA);
+          const V3<R> xP = mulMv(RPA, xa) + ldv(S + PP_PPA);
+          V3<R> F; M3<R> Jx, Jv;
+          if (contact_law<R, false>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, ldv(S + PP_VREL) + cross3(ldv(S + PP_WREL), xP), F, Jx, Jv))
+            Fl = Fl + mulMtv(RPA, F);
+        }
+        R* o = tac_out + (size_t)env * 3 * c.ntax + 3 * t;
+        const R o0 = Fl.x * tp[3 * c.ntax] + Fl.y * tp[4 * c.ntax] + Fl.z * tp[5 * c.ntax];
+        const R o1 = Fl.x * tp[6 * c.ntax] + Fl.y * tp[7 * c.ntax] + Fl.z * tp[8 * c.ntax];
+        const R o2 = Fl.x * tp[9 * c.ntax] + Fl.y * tp[10 * c.ntax] + Fl.z * tp[11 * c.ntax];
+        if (j0 == 0) { o[0] = o0; o[1] = o1; o[2] = o2; } else { o[0] += o0; o[1] += o1; o[2] += o2; }
       }
-      V3<R> Fl = mulMtv(RA, F);
-      R* o = tac_out + (size_t)env * 3 * c.ntax + 3 * t;
-      o[0] = Fl.x * tp[3 * c.ntax] + Fl.y * tp[4 * c.ntax] + Fl.z * tp[5 * c.ntax];
-      o[1] = Fl.x * tp[6 * c.ntax] + Fl.y * tp[7 * c.ntax] + Fl.z * tp[8 * c.ntax];
-      o[2] = Fl.x * tp[9 * c.ntax] + Fl.y * tp[10 * c.ntax] + Fl.z * tp[11 * c.ntax];
     }
   }
 }
@@ -92,7 +99,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   for (int s = 0; s < a.nsub; ++s) {
     if (lane < nr) c.dl[lane] = R(0);          // initial guess q1 = q0 + h qd0
     __syncthreads();
-    evaluate(c, lane, sq, sv, sa); ++evals;
+    evaluate<R, NRM>(c, lane, sq, sv, sa); ++evals;
     R gn = block_norm2(c.g, nr, lane);
     int iter = 0; bool conv = false;
     while (true) {
@@ -107,7 +114,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
       for (int ls = 0; ls <= c.max_ls; ++ls) {
         if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
         __syncthreads();
-        evaluate(c, lane, sq, sv, sa); ++evals;
+        evaluate<R, NRM>(c, lane, sq, sv, sa); ++evals;
         gn2 = block_norm2(c.g, nr, lane);
         if (gn2 < gn) break;
         if (ls == c.max_ls) { stalled = true; break; }
@@ -159,7 +166,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
   if (lane < nr) { c.q[lane] = st[lane]; c.qd[lane] = st[nr + lane]; c.qa[lane] = R(0); }
   __syncthreads();
-  phase1(c, lane, R(0), R(0), R(0));
+  phase1(c, lane);
   readout(c, lane, env, a.var_out, a.tac_out);
 }
 
@@ -188,9 +195,11 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
       c.qd[lane] = c.qd0[lane] + d / c.h; c.qa[lane] = d / (c.h * c.h); c.q[lane] = c.q0[lane] + (c.h * c.qd0[lane] + d);
     }
     __syncthreads();
-    phase1(c, lane, sq, sv, sa);
+    phase1(c, lane);
+    phase1t(c, lane, sq, sv, sa);
+    __syncthreads();
     long long t1 = clock64();
-    phase2(c, lane);
+    phase2<R, 16>(c, lane, sq);
     long long t2 = clock64();
     phase3(c, lane, sq, sv);
     long long t3 = clock64();
@@ -200,7 +209,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
     long long t4 = clock64();
     if (lane == 0) { long long* o = a.cyc + (size_t)env * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t4 - t3; }
   } else {
-    evaluate(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    evaluate<R, 16>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
   }
   if (lane < nr) a.g[(size_t)env * nr + lane] = c.g[lane];
   for (int e = lane; e < nr * nr; e += TS_WAVE) a.H[(size_t)env * nr * nr + e] = c.H[e];
@@ -219,47 +228,34 @@ template <class R> struct BwdArgs {
 template <class R>
 __device__ R mass_times_z(const Ctx<R>& c, int j) {
   R tau = R(0);
+  const S6<R> Wj = ld6(c.WP + j * 6);
   for (int i = 1; i <= c.nl; ++i) {
-    const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
-    const int anc = li[TSIM_LI_ANCMASK];
+    const int anc = c.I[c.off_link + (i - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK];
     if (!((anc >> j) & 1)) continue;
-    const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
-    V3<R> aw = mk3<R>(R(0), R(0), R(0)), av = aw;
-    for (int k = 0; k < c.nr; ++k) {
-      if (!((anc >> k) & 1)) continue;
-      const R zk = c.z[k];
-      aw = aw + ld3<R>(c.WP, c.WT, k * 6, c.nd, 0) * zk;
-      av = av + ld3<R>(c.WP, c.WT, k * 6 + 3, c.nd, 0) * zk;
-    }
-    M3<R> XR = ld9<R>(c.LP, c.LT, i * LK_SIZE + LK_R, c.nd, 0);
-    V3<R> cw = mulMc(XR, lf + TSIM_LF_COM) + ld3<R>(c.LP, c.LT, i * LK_SIZE + LK_P, c.nd, 0);
-    V3<R> f = (av + cross3(aw, cw)) * lf[TSIM_LF_MASS];
-    const R* ii = lf + TSIM_LF_INERTIA;
-    V3<R> al = mulMtv(XR, aw);
-    V3<R> Ia = mk3<R>(al.x * ii[0] + al.y * ii[3] + al.z * ii[4], al.x * ii[3] + al.y * ii[1] + al.z * ii[5], al.x * ii[4] + al.y * ii[5] + al.z * ii[2]);
-    V3<R> n = mulMv(XR, Ia) + cross3(cw, f);
-    tau += dot3(ld3<R>(c.WP, c.WT, j * 6, c.nd, 0), n) + dot3(ld3<R>(c.WP, c.WT, j * 6 + 3, c.nd, 0), f);
+    S6<R> A = zero6<R>();
+    for (int k = 0; k < c.nr; ++k)
+      if ((anc >> k) & 1) A = A + ld6(c.WP + k * 6) * c.z[k];
+    const R* X = c.LP + i * LK_SIZE;
+    tau += dot6(Wj, imul(c.F[c.foff_link + (i - 1) * TSIM_LF_SIZE + TSIM_LF_MASS], ldv(X + LK_C), X + LK_IC, A));
   }
   return tau;
 }
 
 // lam_q += (dvar/dq)^T w_var + (dtac/dq)^T w_tac ; lam_v += (dtac/dqd)^T w_tac, at the state whose link values and
-// q-tangents are in LDS (phase 1 with seeds (1,0,0)).
+// q-tangents (seeds (1,0,0)) are in LDS.  Tactile: reverse mode at the taxel level — each lane forms the gradient of
+// w . out w.r.t. the pair's relative displacement and relative twist (12 numbers, primitive frame); one reduction
+// per (sensor, primitive); lanes = directions then dot it with the pair's per-direction records.
 template <class R>
 __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac) {
-  typedef Du<R> D;
   const int nd = c.nd, nr = c.nr;
   if (wvar && lane < nr) {
     R acc = R(0);
+    const S6<R> Wk = ld6(c.WP + lane * 6);
     for (int e = 0; e < c.nvar; ++e) {
       const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
-      if (l == 0) continue;
-      const int anc = c.I[c.off_link + (l - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK];
-      if (!((anc >> lane) & 1)) continue;
-      const R* vp = c.F + c.foff_var + e * TSIM_VF_SIZE;
-      M3<R> RA = ld9<R>(c.LP, c.LT, l * LK_SIZE + LK_R, nd, 0);
-      V3<R> x = mulMc(RA, vp) + ld3<R>(c.LP, c.LT, l * LK_SIZE + LK_P, nd, 0);
-      V3<R> J = cross3(ld3<R>(c.WP, c.WT, lane * 6, nd, 0), x) + ld3<R>(c.WP, c.WT, lane * 6 + 3, nd, 0);
+      if (!((anc_of(c.I, c.off_link, l) >> lane) & 1)) continue;
+      const V3<R> x = mulMv(ldm(c.LP + l * LK_SIZE + LK_R), ldv(c.F + c.foff_var + e * TSIM_VF_SIZE)) + ldv(c.LP + l * LK_SIZE + LK_P);
+      const V3<R> J = cross3(Wk.a, x) + Wk.l;
       acc += wvar[3 * e] * J.x + wvar[3 * e + 1] * J.y + wvar[3 * e + 2] * J.z;
     }
     c.lamq[lane] += acc;
@@ -269,78 +265,68 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
   for (int s = 0; s < c.nsensor; ++s) {
     const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
     const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
-    const int la = si[TSIM_SI_LINK], t0 = si[TSIM_SI_TAX0], nt = si[TSIM_SI_NTAX], sp0 = si[TSIM_SI_SPRIM0], nsp = si[TSIM_SI_NSPRIM];
-    const int ancA = la > 0 ? c.I[c.off_link + (la - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
-    int ancAll = ancA;
+    const int t0 = si[TSIM_SI_TAX0], nt = si[TSIM_SI_NTAX], sp0 = si[TSIM_SI_SPRIM0], nsp = si[TSIM_SI_NSPRIM];
     for (int j = 0; j < nsp; ++j) {
-      const int lb = c.I[c.off_pair + c.I[c.off_sprim + sp0 + j] * TSIM_PI_SIZE + TSIM_PI_LINKB];
-      if (lb > 0) ancAll |= c.I[c.off_link + (lb - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK];
-    }
-    for (int base = 0; base < nt; base += TS_WAVE) {
-      const bool valid = base + lane < nt;
-      const int t = t0 + (valid ? base + lane : 0);
-      const R* tp = c.F + c.foff_tax + t;
-      V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
-      R w0 = R(0), w1 = R(0), w2 = R(0);
-      if (valid) { w0 = wtac[3 * t]; w1 = wtac[3 * t + 1]; w2 = wtac[3 * t + 2]; }
-      // weight vector in the sensor-link frame: sum_c w_c axis_c
-      V3<R> wl = mk3<R>(w0 * tp[3 * c.ntax] + w1 * tp[6 * c.ntax] + w2 * tp[9 * c.ntax],
-                        w0 * tp[4 * c.ntax] + w1 * tp[7 * c.ntax] + w2 * tp[10 * c.ntax],
-                        w0 * tp[5 * c.ntax] + w1 * tp[8 * c.ntax] + w2 * tp[11 * c.ntax]);
-      const bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
-      if (!__any(live)) continue;
-      for (int dir = 0; dir < nr; ++dir) {
-        if (!((ancAll >> dir) & 1)) continue;
-        R sq_ = R(0), sv_ = R(0);
+      const int pk = c.I[c.off_sprim + sp0 + j];
+      const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+      const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+      __syncthreads();
+      pair_stage_value(c, pk, 0, lane);
+      __syncthreads();
+      const R* S = c.PP;
+      const M3<R> RPA = ldm(S + PP_RPA);
+      const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+      R g[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) g[e] = R(0);
+      bool any_live = false;
+      for (int base = 0; base < nt; base += TS_WAVE) {
+        const bool valid = base + lane < nt;
+        const int t = t0 + (valid ? base + lane : 0);
+        const R* tp = c.F + c.foff_tax + t;
+        R w0 = R(0), w1 = R(0), w2 = R(0);
+        if (valid) { w0 = wtac[3 * t]; w1 = wtac[3 * t + 1]; w2 = wtac[3 * t + 2]; }
+        bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
+        V3<R> xP, F; M3<R> Jx, Jv;
         if (live) {
-          // (a) q-tangent: link tangents from LDS
-          {
-            M3<D> RA = ld9<D>(c.LP, c.LT, la * LK_SIZE + LK_R, nd, dir);
-            V3<D> F = mk3<D>(D(R(0)), D(R(0)), D(R(0)));
-            for (int j = 0; j < nsp; ++j) {
-              const int pk = c.I[c.off_sprim + sp0 + j];
-              const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
-              const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-              V3<D> Fw, mo;
-              if (pair_point_force<D, R>(c, pi, pf, sf, la, pi[TSIM_PI_LINKB], dir, xa, false, Fw, mo)) F = F + Fw;
-            }
-            V3<D> Fl = mulMtv(RA, F);
-            sq_ = Fl.x.d * wl.x + Fl.y.d * wl.y + Fl.z.d * wl.z;
-          }
-          // (b) qd-tangent: poses fixed, d(V_link)/d(qd_dir) = W_dir for links below dof dir
-          {
-            const int ab = la * LK_SIZE;
-            M3<R> RAv = ld9<R>(c.LP, c.LT, ab + LK_R, nd, 0);
-            M3<D> RA; for (int e = 0; e < 9; ++e) RA.m[e] = D(RAv.m[e]);
-            V3<R> Ww = ld3<R>(c.WP, c.WT, dir * 6, nd, 0), Wv = ld3<R>(c.WP, c.WT, dir * 6 + 3, nd, 0);
-            const R ina = ((ancA >> dir) & 1) ? R(1) : R(0);
-            V3<R> pAv = ld3<R>(c.LP, c.LT, ab + LK_P, nd, 0), wAv = ld3<R>(c.LP, c.LT, ab + LK_W, nd, 0), vAv = ld3<R>(c.LP, c.LT, ab + LK_V, nd, 0);
-            V3<D> pA = mk3<D>(D(pAv.x), D(pAv.y), D(pAv.z));
-            V3<D> wA = mk3<D>(D(wAv.x, Ww.x * ina), D(wAv.y, Ww.y * ina), D(wAv.z, Ww.z * ina));
-            V3<D> vA = mk3<D>(D(vAv.x, Wv.x * ina), D(vAv.y, Wv.y * ina), D(vAv.z, Wv.z * ina));
-            V3<D> F = mk3<D>(D(R(0)), D(R(0)), D(R(0)));
-            for (int j = 0; j < nsp; ++j) {
-              const int pk = c.I[c.off_sprim + sp0 + j];
-              const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
-              const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-              const int lb = pi[TSIM_PI_LINKB], bb = lb * LK_SIZE;
-              const int ancB = lb > 0 ? c.I[c.off_link + (lb - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
-              const R inb = ((ancB >> dir) & 1) ? R(1) : R(0);
-              M3<R> RBv = ld9<R>(c.LP, c.LT, bb + LK_R, nd, 0);
-              M3<D> RB; for (int e = 0; e < 9; ++e) RB.m[e] = D(RBv.m[e]);
-              V3<R> pBv = ld3<R>(c.LP, c.LT, bb + LK_P, nd, 0), wBv = ld3<R>(c.LP, c.LT, bb + LK_W, nd, 0), vBv = ld3<R>(c.LP, c.LT, bb + LK_V, nd, 0);
-              V3<D> pB = mk3<D>(D(pBv.x), D(pBv.y), D(pBv.z));
-              V3<D> wB = mk3<D>(D(wBv.x, Ww.x * inb), D(wBv.y, Ww.y * inb), D(wBv.z, Ww.z * inb));
-              V3<D> vB = mk3<D>(D(vBv.x, Wv.x * inb), D(vBv.y, Wv.y * inb), D(vBv.z, Wv.z * inb));
-              V3<D> Fw, xw;
-              if (point_force<D, R>(pi[TSIM_PI_PRIM], pf, sf, false, RA, pA, wA, vA, RB, pB, wB, vB, xa, Fw, xw)) F = F + Fw;
-            }
-            V3<D> Fl = mulMtv(RA, F);
-            sv_ = Fl.x.d * wl.x + Fl.y.d * wl.y + Fl.z.d * wl.z;
-          }
+          xP = mulMv(RPA, mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax])) + pPA;
+          live = contact_law<R, true>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv);
         }
-        sq_ = wave_sum(sq_); sv_ = wave_sum(sv_);
-        if (lane == 0) { c.lamq[dir] += sq_; c.lamv[dir] += sv_; }
+        if (!__any(live)) continue;
+        any_live = true;
+        if (live) {
+          // weight in the sensor-link frame, then in the primitive frame:  s = wP . F
+          const V3<R> wl = mk3<R>(w0 * tp[3 * c.ntax] + w1 * tp[6 * c.ntax] + w2 * tp[9 * c.ntax],
+                                  w0 * tp[4 * c.ntax] + w1 * tp[7 * c.ntax] + w2 * tp[10 * c.ntax],
+                                  w0 * tp[5 * c.ntax] + w1 * tp[8 * c.ntax] + w2 * tp[11 * c.ntax]);
+          const V3<R> wP = mulMv(RPA, wl);
+          const V3<R> gv = mulMtv(Jv, wP);
+          const V3<R> gx = mulMtv(Jx, wP) + cross3(gv, wrel);       // d s / d(point displacement)
+          const V3<R> ath = cross3(xP, gx) + cross3(wP, F);         // d s / d(relative rotation)
+          const V3<R> bw = cross3(xP, gv);                           // d s / d(relative angular velocity)
+          g[0] += ath.x; g[1] += ath.y; g[2] += ath.z; g[3] += gx.x; g[4] += gx.y; g[5] += gx.z;
+          g[6] += bw.x; g[7] += bw.y; g[8] += bw.z; g[9] += gv.x; g[10] += gv.y; g[11] += gv.z;
+        }
+      }
+      if (!any_live) continue;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) g[e] = wave_sum(g[e]);
+      // lanes = directions
+      pair_stage_tangent(c, pk, 0, lane, R(1), 0);
+      if (lane < nr) {
+        const R* T = c.PT + lane * PT_SIZE;
+        R sq_ = R(0);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) sq_ += g[e] * T[e];
+        c.lamq[lane] += sq_;
+      }
+      pair_stage_tangent(c, pk, 0, lane, R(1), 1);
+      if (lane < nr) {
+        const R* T = c.PT + lane * PT_SIZE;
+        R sv_ = R(0);
+#pragma unroll
+        for (int e = 6; e < 12; ++e) sv_ += g[e] * T[e];
+        c.lamv[lane] += sv_;
       }
     }
   }
@@ -355,7 +341,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
   Ctx<R> c; ctx_init(c, a.I, a.F, lds);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
-  R* H2 = c.scr;   // nr*nr reals: taped Newton matrix of the sub-step (scratch region is (nl+1)*12 + 8 >= ... checked on host)
+  R* H2 = c.H2;    // taped Newton matrix of the sub-step
   init_world(c, lane);
   if (lane < nr) { c.lamq[lane] = a.lamq[(size_t)env * nr + lane]; c.lamv[lane] = a.lamv[(size_t)env * nr + lane]; }
   __syncthreads();
@@ -371,7 +357,9 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
     if (lane < nu) c.u[lane] = r1[2 * nr + nr * nr + lane];
     for (int e = lane; e < nr * nr; e += TS_WAVE) H2[e] = r1[2 * nr + e];
     __syncthreads();
-    phase1(c, lane, R(1), R(0), R(0));
+    phase1(c, lane);
+    phase1t(c, lane, R(1), R(0), R(0));
+    __syncthreads();
     // direct partials of the loss w.r.t. this sub-step's outputs
     const bool seeded = a.seed_mode == 1 || j == a.n - 1;
     if (seeded) {
@@ -383,7 +371,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.lamv[lane] / c.h;
     __syncthreads();
     solve_lanes<R, NRM>(H2, c.rhs, c.z, nr, true, lane);
-    phase2(c, lane);
+    phase2<R, NRM>(c, lane, R(1));
     phase3(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
     if (lane < nr) {
       R yq = R(0);
@@ -504,8 +492,6 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->rec = ts_rec(nr, nu);
   b->esz = dtype == TSIM_F32 ? 4 : 8;
   int reals = ts_lds_reals(nl, nr, nu);
-  int scr_have = (nl + 1) * 12 + 8;
-  if (scr_have < nr * nr) reals += nr * nr - scr_have;     // the adjoint kernel keeps the taped H in the scratch region
   b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
   if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   b->t_cur = 0; b->record = 0;
