@@ -91,7 +91,7 @@ int tsim_cache_clear(tsim_batch* b);
 
 /* Diagnostics (no reference counterpart): one residual evaluation g(q1; q0, qd0, u) and its Newton matrix
  * H = dg/dq1 for env 0..B-1; g_out [B][nr], H_out [B][nr][nr] (row-major). Used by the parity tests.
- * cycles (device int64 [B][4], may be NULL): shader-clock cycles of phase 1 / 2 / 3 / dense solve. */
+ * cycles (device int64 [B][32], may be NULL): shader-clock stamps taken inside the evaluation (models with ndof_r <= 8). */
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u,
                     void* g_out, void* H_out, long long* cycles, void* stream);
 

@@ -147,7 +147,8 @@ template <class R> __device__ __forceinline__ R wave_sum(R x) {
 
 // ------------------------------------------------------------------------------------------------ per-block context
 template <class R> struct Ctx {
-  const int* I; const R* F;               // model blob (global memory, shared by all environments)
+  const int* I; const R* F;               // model records (link / dof / motor / pair / sensor tables): staged in LDS
+  const R* Fg;                            // whole float blob in global memory (contact-point and taxel SoA arrays)
   int nl, nr, nu, nvar, npair, ncpt, nsensor, ntax, nd;
   int off_link, off_dof, off_motor, off_var, off_pair, off_sensor, off_sprim;
   int foff_link, foff_dof, foff_motor, foff_var, foff_pair, foff_sensor, foff_cpt, foff_tax;
@@ -156,12 +157,16 @@ template <class R> struct Ctx {
   // LDS
   R *q, *q0, *qd0, *u, *qd, *qa, *g, *dq, *dl, *H, *H2, *lamq, *lamv, *z, *rhs;
   R *LP, *WP, *DT, *PP, *PT, *scr;
+  long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
+  mutable int nstamp;
 };
+#define TS_STAMP(c) do { if ((c).stamps) { if (threadIdx.x == 0 && (c).nstamp < 32) (c).stamps[(c).nstamp] = clock64(); (c).nstamp++; } } while (0)
 
-// number of LDS reals a block needs (host and device must agree)
-__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu) {
+// number of LDS reals a block needs (host and device must agree). ni / nfrec: ints and leading reals of the model
+// blob that are staged in LDS (everything except the per-point SoA arrays); esz = sizeof(real).
+__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int ni, int nfrec, int esz) {
   int nd = nr;
-  int n = 0;
+  int n = nfrec + 2; (void)ni; (void)esz;
   n += 11 * nr + nu;                       // q q0 qd0 qd qa g dq(2) dl(2) spare ; u
   n += 2 * nr * nr;                        // H, H2 (taped Newton matrix in the adjoint kernel)
   n += 4 * nr;                             // lamq lamv z rhs
@@ -175,7 +180,19 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu) {
 }
 
 template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds) {
-  c.I = I; c.F = F;
+  // Stage the model's FLOAT tables in LDS (link / dof / motor / pair / sensor records): later reads are ds_read
+  // broadcasts instead of ~500-cycle global loads.  The INT tables stay in global memory on purpose: they are
+  // wave-uniform, so they travel through the scalar cache and all indexing / control flow stays on the SALU.
+  {
+    const int nfrec = I[TSIM_IH_FOFF_CPT];
+    R* mf = lds;
+    for (int i = threadIdx.x; i < nfrec; i += TS_WAVE) mf[i] = F[i];
+    __syncthreads();
+    c.Fg = F; c.F = mf; c.I = I;
+    lds += nfrec + 2;
+    F = mf;
+  }
+  c.stamps = nullptr; c.nstamp = 0;
   c.nl = I[TSIM_IH_NL]; c.nr = I[TSIM_IH_NR]; c.nu = I[TSIM_IH_NU]; c.nvar = I[TSIM_IH_NVAR];
   c.npair = I[TSIM_IH_NPAIR]; c.ncpt = I[TSIM_IH_NCPT]; c.nsensor = I[TSIM_IH_NSENSOR]; c.ntax = I[TSIM_IH_NTAXEL];
   c.nd = c.nr;

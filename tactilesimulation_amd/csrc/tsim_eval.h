@@ -196,7 +196,7 @@ __device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
     V3<R> cP = zero3<R>(), xP = cP, F = cP;
     M3<R> Jx, Jv;
     if (pidx < npt) {
-      const R* cp = c.F + c.foff_cpt + pt0 + pidx;        // SoA: consecutive lanes -> consecutive addresses
+      const R* cp = c.Fg + c.foff_cpt + pt0 + pidx;        // SoA: consecutive lanes -> consecutive addresses
       cP = mulMv(RPA, mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt])) + pPA;
       xP = cP;
       if (sphere_plane) xP.z -= pf[TSIM_PF_SHAPE];         // lowest point of the sphere (plane normal = +z of P)
@@ -290,12 +290,15 @@ __device__ void phase2(const Ctx<R>& c, int lane, R sq) {
     for (int pk = p0; pk < pe; ++pk)
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_stage_value(c, pk, pk - p0, lane);
     __syncthreads();
+    TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_stage_tangent(c, pk, pk - p0, lane, sq, 0);
     __syncthreads();
+    TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_contacts<R, NRM>(c, pk, pk - p0, lane);
     __syncthreads();
+    TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // serial over pairs: two pairs may touch the same link
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_fold(c, pk, pk - p0, lane, sq);
     __syncthreads();
@@ -382,11 +385,16 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
     c.q[lane] = c.q0[lane] + (c.h * c.qd0[lane] + d);
   }
   __syncthreads();
+  TS_STAMP(c);
   phase1(c, lane);
+  TS_STAMP(c);
   phase1t(c, lane, sq, sv, sa);
   __syncthreads();
+  TS_STAMP(c);
   phase2<R, NRM>(c, lane, sq);
+  TS_STAMP(c);
   phase3(c, lane, sq, sv);
+  TS_STAMP(c);
 }
 
 // ================================================================================================ dense solve

@@ -17,6 +17,10 @@
 #include "../../include/tsim.h"
 #include "tsim_eval.h"
 
+#ifndef TS_MIN_WAVES
+#define TS_MIN_WAVES 1     // second __launch_bounds__ argument (waves per SIMD the register allocator must allow)
+#endif
+
 // tape record per (sub-step, env): q[nr] qd[nr] H[nr*nr] u[nu]
 __host__ __device__ inline int ts_rec(int nr, int nu) { return 2 * nr + nr * nr + nu; }
 
@@ -46,7 +50,7 @@ __device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_o
       for (int base = 0; base < nt; base += TS_WAVE) {
         const int t = t0 + base + lane;
         if (base + lane >= nt) continue;
-        const R* tp = c.F + c.foff_tax + t;
+        const R* tp = c.Fg + c.foff_tax + t;
         const V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
         V3<R> Fl = zero3<R>();                          // force on the taxel, sensor-link frame
         for (int j = j0; j < je; ++j) {
@@ -79,7 +83,7 @@ template <class R> struct FwdArgs {
 };
 
 template <class R, int NRM>
-__global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
+__global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
@@ -99,32 +103,39 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   for (int s = 0; s < a.nsub; ++s) {
     if (lane < nr) c.dl[lane] = R(0);          // initial guess q1 = q0 + h qd0
     __syncthreads();
-    evaluate<R, NRM>(c, lane, sq, sv, sa); ++evals;
-    R gn = block_norm2(c.g, nr, lane);
-    int iter = 0; bool conv = false;
+    // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
+    // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).
+    R gn = R(0), alpha = R(1);
+    int iter = 0, ls = -1;                     // ls < 0: the evaluation is the first one of the sub-step
+    bool conv = false;
     while (true) {
+      evaluate<R, NRM>(c, lane, sq, sv, sa); ++evals;
+      const R gnew = block_norm2(c.g, nr, lane);
+      if (ls >= 0) {                           // this was a line-search trial
+        if (!(gnew < gn)) {
+          if (ls == c.max_ls) {
+            // No step length down to 2^-max_ls reduces ||g||: the iterate sits on the round-off floor of the residual
+            // (or on a kink). Repeating the same failed search max_iter times cannot move it by more than
+            // 2^-max_ls |dq| per pass, so stop; it counts as converged when it is within two decades of tol.
+            conv = gnew < R(100) * c.tol; break;
+          }
+          alpha *= R(0.5); ++ls;
+          if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
+          __syncthreads();
+          continue;
+        }
+        ++iter;
+      }
+      gn = gnew;
       if (!(gn == gn)) { nonfinite = true; break; }
       if (gn < c.tol) { conv = true; break; }
       if (iter >= c.max_iter) break;
       if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
       __syncthreads();
       solve_lanes<R, NRM>(c.H, c.rhs, c.dq, nr, false, lane);
-      R alpha = R(1), gn2 = gn;
-      bool stalled = false;
-      for (int ls = 0; ls <= c.max_ls; ++ls) {
-        if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
-        __syncthreads();
-        evaluate<R, NRM>(c, lane, sq, sv, sa); ++evals;
-        gn2 = block_norm2(c.g, nr, lane);
-        if (gn2 < gn) break;
-        if (ls == c.max_ls) { stalled = true; break; }
-        alpha *= R(0.5);
-      }
-      gn = gn2; ++iter;
-      // No step length down to 2^-max_ls reduces ||g||: the iterate sits on the round-off floor of the residual (or on
-      // a kink).  Repeating the same failed search max_iter times cannot change it by more than 2^-max_ls |dq| per
-      // pass, so stop here; it counts as converged when it is within two decades of tol.
-      if (stalled) { conv = gn < R(100) * c.tol; break; }
+      alpha = R(1); ls = 0;
+      if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+      __syncthreads();
     }
     if (!conv) ++bad;
     // commit the sub-step: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
@@ -187,27 +198,14 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   }
   if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
   __syncthreads();
-  if (a.cyc) {   // phase-by-phase shader-clock stamps (s_memtime), under whatever load the launch creates
-    const R sq = R(1), sv = R(1) / c.h, sa = R(1) / (c.h * c.h);
-    long long t0 = clock64();
-    if (lane < nr) {
-      const R d = c.dl[lane];
-      c.qd[lane] = c.qd0[lane] + d / c.h; c.qa[lane] = d / (c.h * c.h); c.q[lane] = c.q0[lane] + (c.h * c.qd0[lane] + d);
-    }
-    __syncthreads();
-    phase1(c, lane);
-    phase1t(c, lane, sq, sv, sa);
-    __syncthreads();
-    long long t1 = clock64();
-    phase2<R, 16>(c, lane, sq);
-    long long t2 = clock64();
-    phase3(c, lane, sq, sv);
-    long long t3 = clock64();
+  if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve
+    c.stamps = a.cyc + (size_t)env * 32;
+    evaluate<R, 8>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
     if (lane < nr) c.rhs[lane] = -c.g[lane];
     __syncthreads();
-    solve_lanes<R, 16>(c.H, c.rhs, c.dq, nr, false, lane);
-    long long t4 = clock64();
-    if (lane == 0) { long long* o = a.cyc + (size_t)env * 4; o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t4 - t3; }
+    solve_lanes<R, 8>(c.H, c.rhs, c.dq, nr, false, lane);
+    TS_STAMP(c);
+    if (lane == 0) for (int i = c.nstamp; i < 32; ++i) c.stamps[i] = 0;
   } else {
     evaluate<R, 16>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
   }
@@ -283,7 +281,7 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
       for (int base = 0; base < nt; base += TS_WAVE) {
         const bool valid = base + lane < nt;
         const int t = t0 + (valid ? base + lane : 0);
-        const R* tp = c.F + c.foff_tax + t;
+        const R* tp = c.Fg + c.foff_tax + t;
         R w0 = R(0), w1 = R(0), w2 = R(0);
         if (valid) { w0 = wtac[3 * t]; w1 = wtac[3 * t + 1]; w2 = wtac[3 * t + 2]; }
         bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
@@ -334,7 +332,7 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
 }
 
 template <class R, int NRM>
-__global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
+__global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
@@ -491,7 +489,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->nl = nl; b->nr = nr; b->nu = nu; b->nvar = I[TSIM_IH_NVAR]; b->ntax = I[TSIM_IH_NTAXEL];
   b->rec = ts_rec(nr, nu);
   b->esz = dtype == TSIM_F32 ? 4 : 8;
-  int reals = ts_lds_reals(nl, nr, nu);
+  int reals = ts_lds_reals(nl, nr, nu, I[TSIM_IH_NI], I[TSIM_IH_FOFF_CPT], (int)b->esz);
   b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
   if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   b->t_cur = 0; b->record = 0;

@@ -148,7 +148,7 @@ class BatchSim:
         q1, q0, qd0 = (self._chk(x, self.ndof_r, "q") for x in (q1, q0, qd0))
         u = self._chk(u, self.ndof_u, "u")
         g, H = self.empty(self.ndof_r), self.empty(self.ndof_r, self.ndof_r)
-        cyc = torch.zeros(self.B, 4, device=self.device, dtype=torch.int64) if cycles else None
+        cyc = torch.zeros(self.B, 32, device=self.device, dtype=torch.int64) if cycles else None
         capi.check(capi.lib().tsim_debug_eval(self._h, _ptr(q1), _ptr(q0), _ptr(qd0), _ptr(u), _ptr(g), _ptr(H), _ptr(cyc),
                                               self._stream()))
         return (g, H, cyc) if cycles else (g, H)

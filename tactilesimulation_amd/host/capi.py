@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
-LIB_PATH = os.path.abspath(os.path.join(_DIR, "libtsim_hip.so"))
+LIB_PATH = os.environ.get("TSIM_HIP_LIB") or os.path.abspath(os.path.join(_DIR, "libtsim_hip.so"))   # override: A/B builds
 _lib = None
 
 TSIM_F32, TSIM_F64 = 0, 1

@@ -77,14 +77,17 @@ def phase_cycles(dtype, B=4096):
     for _ in range(3):
         g, H, cyc = sim.debug_eval(q1, q0, qd0, u, cycles=True)
     c = cyc.double().cpu().numpy()
-    return {"dtype": str(dtype), "B": B, "phase1_kinematics": float(c[:, 0].mean()), "phase2_contacts": float(c[:, 1].mean()),
-            "phase3_projection": float(c[:, 2].mean()), "dense_solve": float(c[:, 3].mean()), "unit": "shader cycles per evaluation (mean over waves, all resident waves running)"}
+    n = int((c[0] != 0).sum())
+    d = np.diff(c[:, :n], axis=1).mean(0)
+    # stamp order: start | phase1 | phase1t | per pair group: stage value, stage tangent, contacts, (fold ends at phase2 end) | phase3 | solve
+    return {"dtype": str(dtype), "B": B, "stamp_deltas": [float(x) for x in d], "total": float(d.sum()),
+            "unit": "shader cycles between consecutive stamps of one evaluation + solve, mean over waves"}
 
 
 if __name__ == "__main__":
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     res = {"accuracy": [report(torch.float32), report(torch.float64)],
-           "phase_cycles": [phase_cycles(torch.float32), phase_cycles(torch.float64)]}
+           "phase_cycles": [phase_cycles(torch.float32), phase_cycles(torch.float64), phase_cycles(torch.float32, 256), phase_cycles(torch.float64, 256)]}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "accuracy_%s.json" % tag), "w") as f:
         json.dump(res, f, indent=1)
