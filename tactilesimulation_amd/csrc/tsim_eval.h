@@ -11,22 +11,37 @@
 #pragma once
 #include "tsim_device.h"
 
-// ================================================================================================ phase 1 (values)
-// Every lane computes the same values (uniform control flow); lane 0 stores them.
-template <class R>
-__device__ void phase1(const Ctx<R>& c, int lane) {
+// ================================================================================================ phase 1 (+ 1t)
+// One root -> leaf sweep does both the values (every lane computes the same numbers, lane 0 stores them) and, on
+// lanes k < nr, the tangents w.r.t. dof k (seeds: q_k += eps*sq, qd_k += eps*sv, qdd_k += eps*sa).
+// The parent's state is carried in registers when the parent is the previous link of the sweep (chains) or the world,
+// so the common case has no LDS round trip and no barrier inside the sweep.
+template <class R, bool TANGENT>
+__device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+  const int k = lane, nd = c.nd;
+  const bool act = TANGENT && lane < c.nr;
+  M3<R> pR; V3<R> pp; S6<R> pV, pA, pdV, pdA;        // state of the previously processed link
+  S6<R> Wk = zero6<R>();                             // twist column of this lane's own dof, once its link has been swept
+  pR = ldm(c.LP + LK_R); pp = zero3<R>(); pV = zero6<R>(); pA = zero6<R>(); pdV = zero6<R>(); pdA = zero6<R>();
   for (int i = 1; i <= c.nl; ++i) {
     const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
     const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
     const int par = li[TSIM_LI_PARENT], jt = li[TSIM_LI_JTYPE], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
-    const R* P = c.LP + par * LK_SIZE;
     R* X = c.LP + i * LK_SIZE;
-    const M3<R> PR = ldm(P + LK_R);
+    M3<R> PR; V3<R> Pp; S6<R> PV, PA, PdV = zero6<R>(), PdA = zero6<R>();
+    if (par == i - 1 && i > 1) { PR = pR; Pp = pp; PV = pV; PA = pA; PdV = pdV; PdA = pdA; }
+    else {
+      if (par > 0) __syncthreads();                 // a non-adjacent parent was stored by lane 0 earlier in this sweep
+      const R* P = c.LP + par * LK_SIZE;
+      PR = ldm(P + LK_R); Pp = ldv(P + LK_P); PV = ld6(P + LK_W); PA = ld6(P + LK_AW);
+      if (act && par > 0) { const R* Dp = c.DT + (par * nd + k) * DT_SIZE; PdV = ld6(Dp + DT_VW); PdA = ld6(Dp + DT_AW); }
+    }
     const M3<R> R0 = mulMM(PR, ldm(lf + TSIM_LF_R));
-    V3<R> Xp = mulMv(PR, ldv(lf + TSIM_LF_P)) + ldv(P + LK_P);
+    V3<R> Xp = mulMv(PR, ldv(lf + TSIM_LF_P)) + Pp;
     M3<R> XR = R0;
     const R* ax = lf + TSIM_LF_AXES;
     S6<R> VJ = zero6<R>(), AJ = zero6<R>();
+    S6<R> Wj[3];                                     // twist columns of this joint (<= 3 dofs on the HIP path)
     if (jt == TSIM_J_REVOLUTE) {
       R s, co; t_sincos(c.q[k0], s, co);
       const R t = R(1) - co;
@@ -36,21 +51,23 @@ __device__ void phase1(const Ctx<R>& c, int lane) {
       Q.m[6] = t * ax[0] * ax[2] - s * ax[1];  Q.m[7] = t * ax[1] * ax[2] + s * ax[0];  Q.m[8] = t * ax[2] * ax[2] + co;
       XR = mulMM(R0, Q);
       const V3<R> a = mulMv(R0, ldv(ax));          // the axis is invariant under its own rotation
-      const S6<R> W = mk6<R>(a, cross3(Xp, a));
-      if (lane == 0) st6(c.WP + k0 * 6, W);
-      VJ = W * c.qd[k0]; AJ = W * c.qa[k0];
+      Wj[0] = mk6<R>(a, cross3(Xp, a)); Wj[1] = zero6<R>(); Wj[2] = zero6<R>();
+      VJ = Wj[0] * c.qd[k0]; AJ = Wj[0] * c.qa[k0];
     } else {   // prismatic / planar / translational
-      for (int kk = 0; kk < ndj; ++kk) {
-        const R e[3] = {kk == 0 ? R(1) : R(0), kk == 1 ? R(1) : R(0), kk == 2 ? R(1) : R(0)};
-        const V3<R> a = mulMv(R0, ldv(jt == TSIM_J_TRANSLATIONAL ? e : ax + 3 * kk));
-        Xp = Xp + a * c.q[k0 + kk];
-        const S6<R> W = mk6<R>(zero3<R>(), a);
-        if (lane == 0) st6(c.WP + (k0 + kk) * 6, W);
-        VJ = VJ + W * c.qd[k0 + kk]; AJ = AJ + W * c.qa[k0 + kk];
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        Wj[kk] = zero6<R>();
+        if (kk < ndj) {
+          const R e[3] = {kk == 0 ? R(1) : R(0), kk == 1 ? R(1) : R(0), kk == 2 ? R(1) : R(0)};
+          const V3<R> a = mulMv(R0, ldv(jt == TSIM_J_TRANSLATIONAL ? e : ax + 3 * kk));
+          Xp = Xp + a * c.q[k0 + kk];
+          Wj[kk] = mk6<R>(zero3<R>(), a);
+          VJ = VJ + Wj[kk] * c.qd[k0 + kk]; AJ = AJ + Wj[kk] * c.qa[k0 + kk];
+        }
       }
     }
-    const S6<R> V = ld6(P + LK_W) + VJ;
-    const S6<R> A = ld6(P + LK_AW) + AJ + crm(V, VJ);
+    const S6<R> V = PV + VJ;
+    const S6<R> A = PA + AJ + crm(V, VJ);
     const V3<R> cw = mulMv(XR, ldv(lf + TSIM_LF_COM)) + Xp;
     // world rotational inertia  Ic = XR Il XR^T  (symmetric, 6 entries)
     const R* il = lf + TSIM_LF_INERTIA;
@@ -69,57 +86,42 @@ __device__ void phase1(const Ctx<R>& c, int lane) {
     Ic[4] = T.m[0] * XR.m[6] + T.m[1] * XR.m[7] + T.m[2] * XR.m[8];
     Ic[5] = T.m[3] * XR.m[6] + T.m[4] * XR.m[7] + T.m[5] * XR.m[8];
     const R mass = lf[TSIM_LF_MASS];
-    const S6<R> Fi = imul(mass, cw, Ic, A) + crf(V, imul(mass, cw, Ic, V));
+    const S6<R> h = imul(mass, cw, Ic, V), IA = imul(mass, cw, Ic, A);
     if (lane == 0) {
-      stm(X + LK_R, XR); stv(X + LK_P, Xp); st6(X + LK_W, V); st6(X + LK_AW, A); st6(X + LK_FN, Fi);
+      stm(X + LK_R, XR); stv(X + LK_P, Xp); st6(X + LK_W, V); st6(X + LK_AW, A); st6(X + LK_FN, IA + crf(V, h));
       stv(X + LK_C, cw);
 #pragma unroll
       for (int e = 0; e < 6; ++e) X[LK_IC + e] = Ic[e];
-      st6(X + LK_JW, VJ);
-    }
-    __syncthreads();
-  }
-}
-
-// ================================================================================================ phase 1t (tangents)
-// lanes = directions.  Seeds on dof k: q_k += eps*sq, qd_k += eps*sv, qdd_k += eps*sa.
-template <class R>
-__device__ void phase1t(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
-  const int k = lane, nd = c.nd;
-  if (k >= c.nr) return;
-  const S6<R> Wk = ld6(c.WP + k * 6);
-  for (int i = 1; i <= c.nl; ++i) {
-    const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
-    R* D = c.DT + (i * nd + k) * DT_SIZE;
-    if (!((li[TSIM_LI_ANCMASK] >> k) & 1)) {      // dof k does not move link i
 #pragma unroll
-      for (int e = 0; e < DT_SIZE; ++e) D[e] = R(0);
-      continue;
+      for (int kk = 0; kk < 3; ++kk) if (kk < ndj) st6(c.WP + (k0 + kk) * 6, Wj[kk]);
     }
-    const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
-    const int par = li[TSIM_LI_PARENT], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
-    const R* X = c.LP + i * LK_SIZE;
-    const R* Dp = c.DT + (par * nd + k) * DT_SIZE;
-    const S6<R> dxi = Wk * sq;                                  // displacement of link i
-    const S6<R> V = ld6(X + LK_W), A = ld6(X + LK_AW), VJ = ld6(X + LK_JW);
-    // joint part: dW_j = dxi x W_j ;  d(VJ) = sum dW_j qd_j + W_k sv ;  d(AJ) = sum dW_j qdd_j + W_k sa
-    S6<R> dVJ = zero6<R>(), dAJ = zero6<R>();
-    for (int j = k0; j < k0 + ndj; ++j) {
-      const S6<R> dW = crm(dxi, ld6(c.WP + j * 6));
-      dVJ = dVJ + dW * c.qd[j]; dAJ = dAJ + dW * c.qa[j];
+    S6<R> dV = zero6<R>(), dA = zero6<R>();
+    if (act) {
+      R* D = c.DT + (i * nd + k) * DT_SIZE;
+      S6<R> dF = zero6<R>();
+      if ((li[TSIM_LI_ANCMASK] >> k) & 1) {          // dof k moves link i
+        // W_k: this joint's column, or an ancestor's column saved in this lane's registers when its link was swept
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) if (k == k0 + kk && kk < ndj) Wk = Wj[kk];
+        const S6<R> dxi = Wk * sq;                                  // displacement of link i
+        // joint part: dW_j = dxi x W_j ;  d(VJ) = sum dW_j qd_j + W_k sv ;  d(AJ) = sum dW_j qdd_j + W_k sa
+        S6<R> dVJ = zero6<R>(), dAJ = zero6<R>();
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          if (kk < ndj) { const S6<R> dW = crm(dxi, Wj[kk]); dVJ = dVJ + dW * c.qd[k0 + kk]; dAJ = dAJ + dW * c.qa[k0 + kk]; }
+        }
+        if (k >= k0 && k < k0 + ndj) { dVJ = dVJ + Wk * sv; dAJ = dAJ + Wk * sa; }
+        dV = PdV + dVJ;
+        dA = PdA + dAJ + crm(dV, VJ) + crm(V, dVJ);
+        // inertial wrench  F = I A + V x* (I V);  d(I m) = dxi x* (I m) - I (dxi x m) + I dm
+        const S6<R> dh = crf(dxi, h) - imul(mass, cw, Ic, crm(dxi, V)) + imul(mass, cw, Ic, dV);
+        dF = crf(dxi, IA) - imul(mass, cw, Ic, crm(dxi, A)) + imul(mass, cw, Ic, dA) + crf(dV, h) + crf(V, dh);
+      }
+      st6(D + DT_VW, dV); st6(D + DT_AW, dA); st6(D + DT_FN, dF);
     }
-    if (k >= k0 && k < k0 + ndj) { dVJ = dVJ + Wk * sv; dAJ = dAJ + Wk * sa; }
-    const S6<R> dV = ld6(Dp + DT_VW) + dVJ;
-    const S6<R> dA = ld6(Dp + DT_AW) + dAJ + crm(dV, VJ) + crm(V, dVJ);
-    // inertial wrench  F = I A + V x* (I V)
-    const R mass = lf[TSIM_LF_MASS];
-    const V3<R> cw = ldv(X + LK_C);
-    const R* Ic = X + LK_IC;
-    const S6<R> h = imul(mass, cw, Ic, V), IA = imul(mass, cw, Ic, A);
-    const S6<R> dh = crf(dxi, h) - imul(mass, cw, Ic, crm(dxi, V)) + imul(mass, cw, Ic, dV);
-    const S6<R> dF = crf(dxi, IA) - imul(mass, cw, Ic, crm(dxi, A)) + imul(mass, cw, Ic, dA) + crf(dV, h) + crf(V, dh);
-    st6(D + DT_VW, dV); st6(D + DT_AW, dA); st6(D + DT_FN, dF);
+    pR = XR; pp = Xp; pV = V; pA = A; pdV = dV; pdA = dA;
   }
+  __syncthreads();
 }
 
 // ================================================================================================ staged pairs
@@ -386,10 +388,7 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   }
   __syncthreads();
   TS_STAMP(c);
-  phase1(c, lane);
-  TS_STAMP(c);
-  phase1t(c, lane, sq, sv, sa);
-  __syncthreads();
+  phase1<R, true>(c, lane, sq, sv, sa);
   TS_STAMP(c);
   phase2<R, NRM>(c, lane, sq);
   TS_STAMP(c);

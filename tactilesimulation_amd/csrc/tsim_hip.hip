@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
   if (lane < nr) { c.q[lane] = st[lane]; c.qd[lane] = st[nr + lane]; c.qa[lane] = R(0); }
   __syncthreads();
-  phase1(c, lane);
+  phase1<R, false>(c, lane, R(0), R(0), R(0));
   readout(c, lane, env, a.var_out, a.tac_out);
 }
 
@@ -355,9 +355,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
     if (lane < nu) c.u[lane] = r1[2 * nr + nr * nr + lane];
     for (int e = lane; e < nr * nr; e += TS_WAVE) H2[e] = r1[2 * nr + e];
     __syncthreads();
-    phase1(c, lane);
-    phase1t(c, lane, R(1), R(0), R(0));
-    __syncthreads();
+    phase1<R, true>(c, lane, R(1), R(0), R(0));
     // direct partials of the loss w.r.t. this sub-step's outputs
     const bool seeded = a.seed_mode == 1 || j == a.n - 1;
     if (seeded) {
@@ -590,7 +588,7 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
 int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream) {
   if (!b->record) return fail("backward_steps: reset(backward_flag=True) was not called");
   if (n <= 0 || n > b->t_cur) return fail("backward_steps: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
-  if (!df_du) return fail("backward_steps: df_du is null");
+  if (!df_du && b->nu > 0) return fail("backward_steps: df_du is null");
   if (seed_mode != 0 && seed_mode != 1) return fail("backward_steps: bad seed_mode");
   HIPCHK(hipSetDevice(b->device));
   int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, n, seed_mode, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)

@@ -157,8 +157,11 @@ def parse_xml(path):
             ce = be.find("collision")
             if ce is not None and ce.get("contacts"):
                 pts = _read_points(os.path.join(base, ce.get("contacts")))
-                Tc = Pose.from_pos_quat(_floats(ce.get("pos", "0 0 0"), 3), _floats(ce.get("quat", "1 0 0 0"), 4))
-                # stored in the JOINT frame
+                # <collision pos quat> places the point file's frame in the BODY frame (dclaw_position_control.xml:18-21:
+                # body frame o collision frame == joint frame, the files hold joint-frame coordinates); stored in the
+                # JOINT frame
+                Tc = Pose.from_pos_quat(Bd["pos"], Bd["quat"]) * \
+                    Pose.from_pos_quat(_floats(ce.get("pos", "0 0 0"), 3), _floats(ce.get("quat", "1 0 0 0"), 4))
                 Bd["contacts"] = Tc.apply(pts).tolist()
         else:
             raise NotImplementedError("body type %r" % btype)
@@ -436,7 +439,8 @@ def compile_spec(spec):
                     img.append((i, jx))
             rows, cols = R_, C_
         else:
-            Ts = Tj * Pose.from_pos_quat(s["pos"], s["quat"])
+            _, Tbody, _ = body_link_pose(s["body"])          # sensor pos/quat are relative to the body frame
+            Ts = Tbody * Pose.from_pos_quat(s["pos"], s["quat"])
             tl, img = [], []
             for t in s["taxels"]:
                 tl.append(np.concatenate([Ts.apply(t["pos"]), Ts.rotate(t["axis0"]), Ts.rotate(t["axis1"]),

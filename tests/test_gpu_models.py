@@ -1,0 +1,103 @@
+"""HIP path vs fp64 oracle on further models: the build's own small XMLs (prismatic joint + limits, planar, position
+motor, double pendulum without contacts, cylinder sampling) and the reference's DClaw model (10 revolute dofs, 10 links,
+432 contact points from files, 3 x 302 abstract taxels, cylinder primitive, position motors, joint limits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tactilesimulation_amd.model.blob as B
+from tactilesimulation_amd.model.compiler import load_model
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, tol=1e-13):
+    p = os.path.join(HERE, "models", name + ".xml")
+    m = load_model(p if os.path.exists(p) else os.path.join(HERE, "golden", "models", name + ".npz"))
+    m.F[B.TSIM_FH_TOL] = tol
+    return m
+
+
+CASES = {
+    # name: (q0, u sampler, T, S)
+    "point_fall": (np.zeros(3), lambda r: r.uniform(-1, 1, 3), 6, 3),
+    "box_rest": (np.zeros(3), lambda r: np.zeros(0), 6, 5),
+    "pendulum": (np.array([0.7, -0.4]), lambda r: r.uniform(-1, 1, 2), 8, 4),
+    "slider_push": (np.zeros(4), lambda r: np.array([r.uniform(0.2, 1.0)]), 16, 4),
+    "dclaw_position_control": (None, None, 10, 5),
+}
+
+
+def _inputs(name, m, B_, T):
+    rng = np.random.default_rng(7)
+    q0c, us, _, _ = CASES[name]
+    if name == "dclaw_position_control":
+        # a grasp of the cap: all three fingertips close on the cylinder and twist it (joint order per finger: base
+        # abduction, proximal, distal; limits and relative-target stepping as in envs/dclaw_rotate_env.py:23,86-96,201-207)
+        q0 = np.zeros((B_, 10)); q0[:, [0, 3, 6]] = 0.0; q0[:, [1, 4, 7]] = 0.1; q0[:, [2, 5, 8]] = 0.97
+        q0[:, :9] += 0.01 * rng.normal(size=(B_, 9))
+        goal = np.zeros(9); goal[[0, 3, 6]] = 0.04; goal[[1, 4, 7]] = 0.1; goal[[2, 5, 8]] = 1.1
+        u = np.zeros((B_, T, 9))
+        cur = q0[:, :9].copy()
+        for t in range(T):
+            cur = cur + np.clip(goal - cur, -0.02, 0.02) + 0.005 * rng.uniform(-1, 1, size=(B_, 9))
+            u[:, t] = cur
+        return q0, u
+    q0 = np.tile(q0c, (B_, 1)) + 1e-3 * rng.normal(size=(B_, q0c.size)) * (name != "box_rest")
+    u = np.stack([[us(rng) for _ in range(T)] for _ in range(B_)]).reshape(B_, T, m.ndof_u)
+    return q0, u
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("dtype,tq,tg", [(torch.float64, 1e-9, 1e-6), (torch.float32, 5e-4, 2e-2)])
+def test_model_forward_and_adjoint(name, dtype, tq, tg):
+    from tactilesimulation_amd.host.batch import BatchSim
+    from oracle.oracle import OracleSim
+    m = _load(name, 1e-13 if dtype == torch.float64 else 1e-8)
+    _, _, T, S = CASES[name]
+    B_ = 4
+    q0, u = _inputs(name, m, B_, T)
+    nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
+    rng = np.random.default_rng(11)
+    wq, wv, wt = rng.normal(size=(T, nr)), rng.normal(size=(T, nv)), rng.normal(size=(T, nt))
+    sim = BatchSim(m, B_, dtype=dtype, tape_capacity=T * S)
+    sim.reset(torch.tensor(q0), None, backward_flag=True)
+    outs = []
+    for t in range(T):
+        r = sim.step(torch.tensor(u[:, t]) if nu else torch.zeros(B_, 0), S, want_qd=True)
+        outs.append({k: v.double().cpu().numpy() for k, v in r.items()})
+    G = np.zeros((B_, T, max(nu, 1)))
+    for t in reversed(range(T)):
+        du = sim.backward_steps(S, torch.tensor(np.tile(wq[t], (B_, 1))), torch.tensor(np.tile(wv[t], (B_, 1))) if nv else None,
+                                torch.tensor(np.tile(wt[t], (B_, 1))) if nt else None)
+        if nu:
+            G[:, t] = du.double().cpu().numpy().sum(1)
+    lq, lv = (x.double().cpu().numpy() for x in sim.get_adjoint())
+    o = OracleSim(m)
+    for e in range(B_):
+        o.reset(q0[e], record=True)
+        for t in range(T):
+            assert o.forward(u[e, t], S) == 0
+            q, qd = o.state()
+            v, tc = o.outputs()
+            assert np.abs(outs[t]["q"][e] - q).max() <= tq * max(1.0, np.abs(q).max()), (name, e, t)
+            if nv:
+                assert np.abs(outs[t]["var"][e] - v).max() <= tq * 10
+            if nt:
+                assert np.abs(outs[t]["tactile"][e] - tc).max() <= max(tq * 1e3, 1e-12) * max(np.abs(tc).max(), 1e-3), (name, e, t)
+        Go = np.zeros((T, max(nu, 1)))
+        for t in reversed(range(T)):
+            dq = np.zeros((S, nr)); dq[-1] = wq[t]
+            dv = np.zeros((S, nv)); dv[-1] = wv[t] if nv else 0
+            dt = np.zeros((S, nt)); dt[-1] = wt[t] if nt else 0
+            du = o.backward_steps(S, dq, dv, dt)
+            if nu:
+                Go[t] = du.sum(0)
+        alq, alv = o.adjoint()
+        if nu:
+            assert np.abs(G[e] - Go).max() <= tg * max(np.abs(Go).max(), 1e-9), (name, e, np.abs(G[e] - Go).max() / np.abs(Go).max())
+        assert np.abs(lq[e] - alq).max() <= tg * max(np.abs(alq).max(), 1e-9), (name, "lam_q")
+        assert np.abs(lv[e] - alv).max() <= tg * max(np.abs(alv).max(), 1e-9), (name, "lam_v")
