@@ -152,6 +152,15 @@ def main():
         dom, dom_ms, dom_bytes = ("k_forward", fwd_ms, fb) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb)
         achieved = dom_bytes * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         value = B * world * args.steps / dt
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.dtype)
+        if os.path.exists(pmc_file) and B == 4096:       # separate rocprofv3 --pmc run of this same command (tools/gpu_pmc.sh)
+            try:
+                pk = [v for k, v in json.load(open(pmc_file))["per_kernel"].items() if dom in k][0]
+                traffic = (2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024.0      # gfx950: FETCH_SIZE counts 1/2 (MI355X_MICROARCH.md §HBM)
+                traffic_src = "profiles/" + os.path.basename(pmc_file) + " (2*FETCH_SIZE + WRITE_SIZE KiB, per launch)"
+            except Exception:
+                pass
         res = {
             "metric": "env-steps/sec (fwd+bwd) TactilePush batch=4096" if not args.forward_only else "env-steps/sec (fwd only) TactilePush",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +170,8 @@ def main():
                                    "batch %d envs/GPU, episodes of %d env-steps" % (S, B, T),
                        "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": dom_bytes * B,
                          "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb},
                          "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms},
                          "note": "state stays in LDS across sub-steps, so this path is latency/VALU-bound, not HBM-bound (SURVEY.md §0.6)"},
