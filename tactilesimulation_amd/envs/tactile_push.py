@@ -1,0 +1,85 @@
+"""BatchedTactilePushEnv — B TactilePush-v1 environments stepped as one batch on one GPU.
+
+Vectorised counterpart of the reference's envs/tactile_push_env.py (observation_type "tactile_flatten", use_torch):
+same action mapping (:175-193), observation (:72-131) and reward (:202-211), evaluated for all B environments in torch
+on the device; the simulator step is BatchedStepSimFunction (one HIP launch forward, one backward per env-step). The
+per-environment gym wrapper of the reference keeps working through compat/redmax_py.py; this class is what SURVEY.md
+§8(f).1 calls the batched counterpart.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from ..functions import BatchedStepSimFunction
+from ..host.batch import BatchSim
+from ..model.compiler import load_model
+
+
+class BatchedTactilePushEnv:
+    tactile_rows, tactile_cols = 13, 10           # envs/tactile_push_env.py:31-32
+    frame_skip = 5                                # :66
+    max_episode_steps = 100                       # envs/__init__.py:9-13
+
+    def __init__(self, model, batch_size, device="cuda:0", dtype=torch.float32, gradient=True, seed=0, tape_steps=None):
+        if isinstance(model, str):
+            model = load_model(model)
+        self.B, self.device, self.dtype, self.gradient = int(batch_size), torch.device(device), dtype, bool(gradient)
+        T = tape_steps if tape_steps is not None else self.max_episode_steps
+        self.sim = BatchSim(model, self.B, device=device, dtype=dtype, tape_capacity=T * self.frame_skip)
+        assert (self.sim.ndof_r, self.sim.ndof_u, self.sim.ndof_var, self.sim.ndof_tactile) == (7, 6, 6, 390)
+        self.rng = np.random.default_rng(seed)
+        self.obs_dim, self.act_dim = 3 + 390, 3
+        self.dt = self.sim.h * self.frame_skip
+        self.current_step = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _t(self, a):
+        return torch.as_tensor(np.asarray(a), device=self.device, dtype=self.dtype)
+
+    def _obs(self, q, tactile):
+        """goal pose in the gripper frame (3) + flattened tactile (390)   (tactile_push_env.py:84-114)"""
+        th = q[:, 0]
+        c, s = torch.cos(-th), torch.sin(-th)
+        gx, gy = self.goal[:, 0], self.goal[:, 1]
+        gl = torch.stack([c * gx - s * gy - q[:, 1], s * gx + c * gy - q[:, 2], self.goal[:, 2] - th], dim=1)
+        return torch.cat([gl, tactile], dim=1)
+
+    # ------------------------------------------------------------------ gym-like API, batched
+    def reset(self, q0=None, goal=None):
+        """Per-environment draws of tactile_push_env.py:133-172 (box y offset, goal xy, goal yaw), or explicit tables."""
+        B = self.B
+        if q0 is None:
+            q0 = np.zeros((B, 7))
+            q0[:, 1] = -0.001
+            q0[:, 4] = self.rng.uniform(-0.02, 0.02, size=B)
+        if goal is None:
+            goal = np.zeros((B, 3))
+            goal[:, 0:2] = self.rng.uniform([0.15, -0.2], [0.25, 0.2], size=(B, 2))
+            goal[:, 2] = self.rng.uniform(goal[:, 1] * math.pi - math.pi / 16.0, goal[:, 1] * math.pi + math.pi / 16.0)
+        self.q0, self.goal = self._t(q0), self._t(goal)
+        self.sim.reset(self.q0, None, backward_flag=self.gradient)
+        _, tac = self.sim.readout(want_var=False)
+        self.external_force = torch.zeros(B, 2, device=self.device, dtype=self.dtype)
+        self.current_step = 0
+        return self._obs(self.q0, tac)
+
+    def step(self, u, disturbance=None):
+        """u: policy output [B, 3] (pre-tanh). Returns obs [B, 393], reward [B], info dict of reward terms."""
+        action = torch.tanh(u)
+        if disturbance is not None:
+            self.external_force = disturbance.to(self.device, self.dtype)
+        elif self.current_step % 10 == 0:                                   # :185-190
+            on = self._t(self.rng.uniform(0.0, 1.0, size=self.B) < 0.5).unsqueeze(1)
+            self.external_force = on * self._t(self.rng.uniform(-1.0, 1.0, size=(self.B, 2)))
+        robot_action = torch.cat([action, self.external_force, torch.zeros(self.B, 1, device=self.device, dtype=self.dtype)], dim=1)
+        q, var, tactile = BatchedStepSimFunction.apply(robot_action, self.frame_skip, self.sim, self.gradient)
+        self.current_step += 1
+        obs = self._obs(q, tactile)
+        r_pos = -(((q[:, 3:5] - self.goal[:, 0:2]) / 0.01) ** 2).sum(1) * 0.01
+        r_rot = -(((q[:, 6] - self.goal[:, 2]) / (math.pi / 36.0)) ** 2) * 0.1
+        r_touch = -((var[:, 0:3] - var[:, 3:6]) ** 2).sum(1) / (0.02 ** 2)
+        r_act = -(u ** 2).sum(1) * 0.1
+        info = {"reward_pos": r_pos, "reward_rot": r_rot, "reward_touch": r_touch, "reward_action": r_act, "q": q}
+        return obs, r_pos + r_rot + r_touch + r_act, info

@@ -1,0 +1,81 @@
+"""Batched TactilePush env + batched GD step on the GPU: observation / reward formulas against a per-environment numpy
+re-statement of envs/tactile_push_env.py driven by the oracle, and dLoss/dtheta against central differences."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_obs_reward_match_per_env_formulas(pusher_model):
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from oracle.oracle import OracleSim
+    B, T = 5, 6
+    env = BatchedTactilePushEnv(pusher_model, B, dtype=torch.float64, gradient=False, seed=3)
+    obs = env.reset()
+    q0, goal = env.q0.cpu().numpy(), env.goal.cpu().numpy()
+    rng = np.random.default_rng(0)
+    U = rng.normal(size=(T, B, 3)) * 0.7
+    D = rng.uniform(-1, 1, size=(T, B, 2))
+    R, O = [], [obs.cpu().numpy()]
+    for t in range(T):
+        o, r, _ = env.step(torch.tensor(U[t], device="cuda"), torch.tensor(D[t]))
+        R.append(r.cpu().numpy()); O.append(o.cpu().numpy())
+    sim = OracleSim(pusher_model)
+    for e in range(B):
+        sim.reset(q0[e])
+        for t in range(T):
+            a = np.concatenate([np.tanh(U[t, e]), D[t, e], [0.0]])
+            sim.forward(a, 5)
+            q, _ = sim.state(); var, tac = sim.outputs()
+            c, s = math.cos(-q[0]), math.sin(-q[0])                                   # tactile_push_env.py:90-101
+            gl = np.array([c * goal[e, 0] - s * goal[e, 1] - q[1], s * goal[e, 0] + c * goal[e, 1] - q[2], goal[e, 2] - q[0]])
+            assert np.abs(O[t + 1][e, :3] - gl).max() < 1e-5
+            assert np.abs(O[t + 1][e, 3:] - tac).max() < 1e-4 * max(np.abs(tac).max(), 1e-3)
+            rew = (-np.sum(((q[3:5] - goal[e, :2]) / 0.01) ** 2) * 0.01 - ((q[6] - goal[e, 2]) / (math.pi / 36)) ** 2 * 0.1
+                   - np.sum((var[:3] - var[3:]) ** 2) / 0.02 ** 2 - np.sum(U[t, e] ** 2) * 0.1)        # :206-211
+            assert abs(R[t][e] - rew) < 1e-5 * max(abs(rew), 1.0)
+
+
+def test_policy_gradient_matches_finite_differences(pusher_model):
+    import copy
+    import tactilesimulation_amd.model.blob as Bl
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.algorithms.batched_gd import Actor, rollout_loss, train_epoch
+    m = copy.copy(pusher_model); m.F = pusher_model.F.copy(); m.F[Bl.TSIM_FH_TOL] = 1e-13
+    B, T = 4, 8
+    env = BatchedTactilePushEnv(m, B, dtype=torch.float64, gradient=True, seed=5, tape_steps=T)
+    torch.manual_seed(0)
+    actor = Actor(dtype=torch.float64).cuda()
+    assert sum(p.numel() for p in actor.parameters()) == 29574          # SURVEY.md §2.2 / §8e payload
+    env.reset()
+    q0, goal = env.q0.cpu().numpy(), env.goal.cpu().numpy()
+    D = torch.tensor(np.random.default_rng(1).uniform(-1, 1, size=(T, B, 2)))
+    kw = dict(q0=q0, goal=goal, disturbances=D)
+    loss = rollout_loss(env, actor, T, **kw)
+    loss.backward()
+    p = actor.mu_net[-1].bias
+    g = p.grad.clone()
+    w = actor.mu_net[0].weight
+    gw = w.grad[3, 1].item(), w.grad[10, 200].item()
+    eps = 1e-6
+    with torch.no_grad():
+        for i in range(3):
+            p[i] += eps; lp = rollout_loss(env, actor, T, **kw).item(); env.sim.reset(env.q0, None, True)
+            p[i] -= 2 * eps; lm = rollout_loss(env, actor, T, **kw).item(); env.sim.reset(env.q0, None, True)
+            p[i] += eps
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - g[i].item()) < 2e-5 * max(abs(fd), 1.0), (i, fd, g[i].item())
+        for (r, c_), ga in (((3, 1), gw[0]), ((10, 200), gw[1])):
+            w[r, c_] += eps; lp = rollout_loss(env, actor, T, **kw).item()
+            w[r, c_] -= 2 * eps; lm = rollout_loss(env, actor, T, **kw).item()
+            w[r, c_] += eps
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - ga) < 2e-5 * max(abs(fd), 1e-2), (r, c_, fd, ga)
+    opt = torch.optim.Adam(actor.parameters(), lr=1e-3)
+    l0 = train_epoch(env, actor, opt, T, B, **kw)
+    l1 = train_epoch(env, actor, opt, T, B, **kw)
+    assert np.isfinite(l0) and np.isfinite(l1)
