@@ -265,18 +265,22 @@ __device__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
   const S6<R> Ww = wrench_to_world(RP, pP, ld6(S + PP_WN));
   const R inB = ((anc_of(c.I, c.off_link, lb) >> k) & 1) ? R(1) : R(0);
   const S6<R> dWw = wrench_to_world(RP, pP, ld6(T + PT_WN)) + crf(ld6(c.WP + k * 6) * (sq * inB), Ww);
-  R* Da = c.DT + (la * nd + k) * DT_SIZE + DT_FN;
+  if (la > 0) {         // link 0 (world-fixed general bodies) takes no wrench
+    R* Da = c.DT + (la * nd + k) * DT_SIZE + DT_FN;
 #pragma unroll
-  for (int e = 0; e < 3; ++e) { Da[e] -= (&dWw.a.x)[e]; Da[3 + e] -= (&dWw.l.x)[e]; }
+    for (int e = 0; e < 3; ++e) { Da[e] -= (&dWw.a.x)[e]; Da[3 + e] -= (&dWw.l.x)[e]; }
+  }
   if (lb > 0) {
     R* Db = c.DT + (lb * nd + k) * DT_SIZE + DT_FN;
 #pragma unroll
     for (int e = 0; e < 3; ++e) { Db[e] += (&dWw.a.x)[e]; Db[3 + e] += (&dWw.l.x)[e]; }
   }
   if (k == 0) {
-    R* Fa = c.LP + la * LK_SIZE + LK_FN;
+    if (la > 0) {
+      R* Fa = c.LP + la * LK_SIZE + LK_FN;
 #pragma unroll
-    for (int e = 0; e < 3; ++e) { Fa[e] -= (&Ww.a.x)[e]; Fa[3 + e] -= (&Ww.l.x)[e]; }
+      for (int e = 0; e < 3; ++e) { Fa[e] -= (&Ww.a.x)[e]; Fa[3 + e] -= (&Ww.l.x)[e]; }
+    }
     if (lb > 0) {
       R* Fb = c.LP + lb * LK_SIZE + LK_FN;
 #pragma unroll

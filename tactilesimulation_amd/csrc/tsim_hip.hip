@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
       const int* mi = c.I + c.off_motor + lane * TSIM_MI_SIZE;
       const R* mf = c.F + c.foff_motor + lane * TSIM_MF_SIZE;
       R dtu;
-      if (mi[TSIM_MI_CTRL] == 0) dtu = (c.u[lane] > R(-1) && c.u[lane] < R(1)) ? R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]) : R(0);
+      if (mi[TSIM_MI_CTRL] == 0) dtu = (c.u[lane] >= R(-1) && c.u[lane] <= R(1)) ? R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]) : R(0);
       else dtu = mf[TSIM_MF_P];
       a.df_du[((size_t)env * a.n + j) * nu + lane] = c.h * c.h * c.z[mi[TSIM_MI_DOF]] * dtu;
     }

@@ -344,13 +344,29 @@ def compile_spec(spec):
         plink = link_of_joint[par] if par >= 0 else 0
         T_pl = (T_link_joint[par] if par >= 0 else Pose()) * E_pj0   # joint-0 frame in the parent LINK frame
         nd = B.JOINT_NDOF[J["type"]]
+        jdesc = {"damping": J["damping"], "lim": J["lim"], "lim_stiffness": J["lim_stiffness"]}
         if nd == 0:
             link_of_joint[j] = plink
             T_link_joint[j] = T_pl
+        elif J["type"] == "free3d-euler":
+            # [CHOICE] free3d-euler = translation (parent frame) followed by intrinsic X-Y-Z Euler rotations, realised as
+            # a translational joint and three revolute joints with massless intermediate links: q = (x, y, z, a, b, c),
+            # R = Rx(a) Ry(b) Rz(c). No new kernel joint type is needed; for the yaw-only motions the reference's
+            # insertion env commands (tactile_insertion_env.py:181-196) Euler and rotation-vector coordinates coincide.
+            chain = [("translational", [], 3, T_pl), ("revolute", [[1.0, 0, 0]], 1, Pose()),
+                     ("revolute", [[0, 1.0, 0]], 1, Pose()), ("revolute", [[0, 0, 1.0]], 1, Pose())]
+            for jt_, axes_, n_, E_ in chain:
+                links.append(dict(jdesc, parent=plink, joint=j, E_pj0=E_, dof0=dof0, ndof=n_, mp=MassProps(),
+                                  jtype=jt_, axes=axes_))
+                plink = len(links) - 1
+                dof0 += n_
+            link_of_joint[j] = plink
+            T_link_joint[j] = Pose()
         else:
             link_of_joint[j] = len(links)
             T_link_joint[j] = Pose()
-            links.append({"parent": plink, "joint": j, "E_pj0": T_pl, "dof0": dof0, "ndof": nd, "mp": MassProps()})
+            links.append(dict(jdesc, parent=plink, joint=j, E_pj0=T_pl, dof0=dof0, ndof=nd, mp=MassProps(),
+                              jtype=J["type"], axes=J["axes"]))
             dof0 += nd
         L = links[link_of_joint[j]]
         L["mp"] = L["mp"] + _body_props(J["body"]).transformed(T_link_joint[j])
@@ -464,10 +480,12 @@ def compile_spec(spec):
         j = jidx_by_name[m["joint"]]
         if B.JOINT_NDOF[joints[j]["type"]] == 0:
             raise ValueError("motor on fixed joint %r" % m["joint"])
-        L = links[link_of_joint[j]]
-        for k in range(L["ndof"]):
-            motors.append({"dof": L["dof0"] + k, "ctrl": 0 if m["ctrl"] == "force" else 1,
-                           "f": [m["ctrl_range"][0], m["ctrl_range"][1], m["P"], m["D"]]})
+        for L in links[1:]:
+            if L["joint"] != j:
+                continue
+            for k in range(L["ndof"]):
+                motors.append({"dof": L["dof0"] + k, "ctrl": 0 if m["ctrl"] == "force" else 1,
+                               "f": [m["ctrl_range"][0], m["ctrl_range"][1], m["P"], m["D"]]})
     nu = len(motors)
 
     # ---- variables
@@ -499,10 +517,9 @@ def compile_spec(spec):
     lrec_i, lrec_f = [], []
     for i in range(1, nl + 1):
         L = links[i]
-        J = joints[L["joint"]]
-        lrec_i.append([L["parent"], B.JOINT_TYPES[J["type"]], L["dof0"], L["ndof"], L["ancmask"]])
+        lrec_i.append([L["parent"], B.JOINT_TYPES[L["jtype"]], L["dof0"], L["ndof"], L["ancmask"]])
         axes = np.zeros((3, 3))
-        for k, a in enumerate(J["axes"]):
+        for k, a in enumerate(L["axes"]):
             a = np.asarray(a, dtype=np.float64)
             axes[k] = a / np.linalg.norm(a)
         mp = L["mp"]
@@ -514,13 +531,12 @@ def compile_spec(spec):
     drec_i, drec_f = [], []
     for i in range(1, nl + 1):
         L = links[i]
-        J = joints[L["joint"]]
         for k in range(L["ndof"]):
             drec_i.append([i])
-            if J["lim"] is not None and J["lim_stiffness"] > 0:
-                drec_f.append([J["damping"], J["lim"][0], J["lim"][1], J["lim_stiffness"]])
+            if L["lim"] is not None and L["lim_stiffness"] > 0:
+                drec_f.append([L["damping"], L["lim"][0], L["lim"][1], L["lim_stiffness"]])
             else:
-                drec_f.append([J["damping"], 0.0, 0.0, 0.0])
+                drec_f.append([L["damping"], 0.0, 0.0, 0.0])
     Ih[B.TSIM_IH_OFF_DOF], Ih[B.TSIM_IH_FOFF_DOF] = section(drec_i, drec_f, B.TSIM_DI_SIZE, B.TSIM_DF_SIZE)
     Ih[B.TSIM_IH_OFF_MOTOR], Ih[B.TSIM_IH_FOFF_MOTOR] = section(
         [[m["dof"], m["ctrl"]] for m in motors], [m["f"] for m in motors], B.TSIM_MI_SIZE, B.TSIM_MF_SIZE)
@@ -560,7 +576,7 @@ def compile_spec(spec):
     meta = {
         "joint_names": [J["name"] for J in joints],
         "link_of_joint": link_of_joint,
-        "dof_of_joint": {J["name"]: (links[link_of_joint[j]]["dof0"], links[link_of_joint[j]]["ndof"])
+        "dof_of_joint": {J["name"]: (min(L["dof0"] for L in links[1:] if L["joint"] == j), B.JOINT_NDOF[J["type"]])
                          for j, J in enumerate(joints) if B.JOINT_NDOF[J["type"]] > 0},
         "pair_keys": [p["key"] for p in pairs],
         "sensor_names": [s["name"] for s in sensors],

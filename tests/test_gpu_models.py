@@ -28,6 +28,9 @@ CASES = {
     "pendulum": (np.array([0.7, -0.4]), lambda r: r.uniform(-1, 1, 2), 8, 4),
     "slider_push": (np.zeros(4), lambda r: np.array([r.uniform(0.2, 1.0)]), 16, 4),
     "dclaw_position_control": (None, None, 10, 5),
+    # 2 pads x 13x10 taxels, prismatic fingers with limits, free3d-euler box (3 translations + 3 revolutes after the
+    # compiler's decomposition), 11 contact pairs incl. world-fixed general bodies (tactile_insertion.xml)
+    "tactile_insertion": (None, None, 14, 5),
 }
 
 
@@ -45,6 +48,18 @@ def _inputs(name, m, B_, T):
         for t in range(T):
             cur = cur + np.clip(goal - cur, -0.02, 0.02) + 0.005 * rng.uniform(-1, 1, size=(B_, 9))
             u[:, t] = cur
+        return q0, u
+    if name == "tactile_insertion":
+        # grasp as in envs/tactile_insertion_env.py:126-170 (height 0.2, fingers open at -0.03, closing force ramp),
+        # then drag the gripped box sideways into the hole walls
+        q0 = np.zeros((B_, 12)); q0[:, 2] = 0.2; q0[:, 4] = -0.03; q0[:, 5] = -0.03
+        q0[:, 6:8] += 5e-4 * rng.normal(size=(B_, 2))
+        u = np.zeros((B_, T, 6))
+        for t in range(T):
+            a = min(1.0, (t + 1) / 5.0)
+            drift = 0.004 * max(0.0, (t - 5) / 8.0)
+            u[:, t] = np.array([drift, 0.6 * drift, 0.2, 0.05 * max(0.0, (t - 7) / 6.0), a, a]) + \
+                np.concatenate([1e-4 * rng.normal(size=(B_, 3)), np.zeros((B_, 3))], axis=1)
         return q0, u
     q0 = np.tile(q0c, (B_, 1)) + 1e-3 * rng.normal(size=(B_, q0c.size)) * (name != "box_rest")
     u = np.stack([[us(rng) for _ in range(T)] for _ in range(B_)]).reshape(B_, T, m.ndof_u)
