@@ -46,6 +46,14 @@ int tsim_tape_len(const tsim_batch* b);          /* recorded sub-steps since the
  * offsets) must be unchanged. */
 int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* stream);
 
+/* Batched counterpart of the update_* randomisers (envs/tactile_insertion_env.py:238-281 draws new contact / tactile
+ * parameters per episode; with B environments each one gets its own): `tables` is a DEVICE array [B][tsim_table_size]
+ * of the batch's real type whose rows are copies of the leading `tsim_table_size` reals of the blob's F[] (all numeric
+ * tables: links, dofs, motors, variables, pairs, sensors) with the randomised entries overwritten. NULL reverts to the
+ * shared model. Point arrays (contact points, taxels) are always shared. */
+int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream);
+int tsim_table_size(const tsim_batch* b);
+
 /* sim.set_state_init(q, qdot) + sim.reset(backward_flag)      envs/redmax_torch_functions.py:39-41,
  * envs/tactile_push_env.py:138,154.  q0 / qd0: [B][ndof_r].  Restarts the tape and zeroes the carried
  * adjoint. */

@@ -179,14 +179,15 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int ni, int 
   return n + 8;
 }
 
-template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds) {
+template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, const R* Fenv = nullptr) {
   // Stage the model's FLOAT tables in LDS (link / dof / motor / pair / sensor records): later reads are ds_read
   // broadcasts instead of ~500-cycle global loads.  The INT tables stay in global memory on purpose: they are
   // wave-uniform, so they travel through the scalar cache and all indexing / control flow stays on the SALU.
   {
     const int nfrec = I[TSIM_IH_FOFF_CPT];
     R* mf = lds;
-    for (int i = threadIdx.x; i < nfrec; i += TS_WAVE) mf[i] = F[i];
+    const R* src = Fenv ? Fenv : F;          // per-environment float tables (domain randomisation) or the shared ones
+    for (int i = threadIdx.x; i < nfrec; i += TS_WAVE) mf[i] = src[i];
     __syncthreads();
     c.Fg = F; c.F = mf; c.I = I;
     lds += nfrec + 2;

@@ -76,7 +76,7 @@ __device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_o
 
 // ================================================================================================ forward kernel
 template <class R> struct FwdArgs {
-  const int* I; const R* F;
+  const int* I; const R* F; const R* Fenv; int fstride;
   int B, nsub, record, t0;
   R* tape; const R* u;
   R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
   init_world(c, lane);
   {
@@ -164,14 +164,14 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
 }
 
 // ================================================================================================ read-out kernel
-template <class R> struct ReadArgs { const int* I; const R* F; int B, t0; const R* tape; R *var_out, *tac_out; };
+template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R *var_out, *tac_out; };
 
 template <class R>
 __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
   const int nr = c.nr, REC = ts_rec(nr, c.nu);
   init_world(c, lane);
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
@@ -182,14 +182,14 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
 }
 
 // ================================================================================================ debug evaluation
-template <class R> struct DbgArgs { const int* I; const R* F; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; };
+template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; };
 
 template <class R>
 __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu;
   init_world(c, lane);
   if (lane < nr) {
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
 
 // ================================================================================================ backward kernel
 template <class R> struct BwdArgs {
-  const int* I; const R* F;
+  const int* I; const R* F; const R* Fenv; int fstride;
   int B, n, t_end, seed_mode;
   const R* tape;
   const R *df_dq, *df_dvar, *df_dtac;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
   R* H2 = c.H2;    // taped Newton matrix of the sub-step
@@ -400,6 +400,7 @@ struct tsim_batch {
   std::vector<int32_t> I; std::vector<double> F;
   int nl, nr, nu, nvar, ntax, rec;
   int* dI; void* dF;             // model on device (dF in the batch's real type)
+  void* dFenv; int nfrec;        // optional per-environment float tables [B][nfrec] (domain randomisation)
   void* tape;                    // [(cap+1)][B][rec]
   void *lamq, *lamv;             // carried adjoint [B][nr]
   int* evals;                    // residual evaluations of the last forward launch, per env (diagnostics)
@@ -440,7 +441,7 @@ template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, i
 template <class R>
 static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
   FwdArgs<R> a;
-  a.I = b->dI; a.F = (const R*)b->dF; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur;
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals;
   if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
@@ -452,7 +453,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, v
 template <class R>
 static int launch_backward(tsim_batch* b, int n, int seed_mode, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, hipStream_t st) {
   BwdArgs<R> a;
-  a.I = b->dI; a.F = (const R*)b->dF; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_mode = seed_mode;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_mode = seed_mode;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du;
   if (b->nr <= 8) hipLaunchKernelGGL((k_backward<R, 8>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
@@ -491,7 +492,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
   if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   b->t_cur = 0; b->record = 0;
-  b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr;
+  b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT]; b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, b->I.size() * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
@@ -510,7 +511,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
-  (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals);
   delete b;
 }
 
@@ -533,8 +534,19 @@ int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* st
   for (int i = 0; i < TSIM_IH_SIZE; ++i) if (I[i] != b->I[i]) return fail("update_model: topology changed");
   HIPCHK(hipSetDevice(b->device));
   b->I.assign(I, I + I[TSIM_IH_NI]); b->F.assign(F, F + I[TSIM_IH_NF]);
+  if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; }     // per-environment tables refer to the old model
   return upload_model(b, (hipStream_t)stream);
 }
+
+int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream) {
+  HIPCHK(hipSetDevice(b->device));
+  if (!tables) { if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; } return 0; }
+  size_t bytes = (size_t)b->B * b->nfrec * b->esz;
+  if (!b->dFenv) HIPCHK(hipMalloc(&b->dFenv, bytes));
+  HIPCHK(hipMemcpyAsync(b->dFenv, tables, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+int tsim_table_size(const tsim_batch* b) { return b->nfrec; }
 
 int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag, void* stream) {
   if (!q0) return fail("reset: q0 is null");
@@ -575,10 +587,10 @@ int tsim_get_state(tsim_batch* b, void* q_out, void* qd_out, void* stream) {
 int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   HIPCHK(hipSetDevice(b->device));
   if (b->dtype == TSIM_F32) {
-    ReadArgs<float> a{b->dI, (const float*)b->dF, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out};
+    ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out};
     hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   } else {
-    ReadArgs<double> a{b->dI, (const double*)b->dF, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out};
+    ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out};
     hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());
@@ -638,10 +650,10 @@ int tsim_cache_clear(tsim_batch* b) {
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u, void* g_out, void* H_out, long long* cycles, void* stream) {
   HIPCHK(hipSetDevice(b->device));
   if (b->dtype == TSIM_F32) {
-    DbgArgs<float> a{b->dI, (const float*)b->dF, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles};
+    DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles};
     hipLaunchKernelGGL(k_debug_eval<float>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   } else {
-    DbgArgs<double> a{b->dI, (const double*)b->dF, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles};
+    DbgArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles};
     hipLaunchKernelGGL(k_debug_eval<double>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());

@@ -78,6 +78,19 @@ class BatchSim:
         capi.check(capi.lib().tsim_update_model(self._h, self._I.ctypes.data_as(capi._ip),
                                                 self._F.ctypes.data_as(C.POINTER(C.c_double)), self._stream()))
 
+    # ------------------------------------------------------------------ per-environment parameters
+    def base_tables(self):
+        """[B, table_size] copy of the model's numeric tables, one row per environment, ready to be edited."""
+        n = capi.lib().tsim_table_size(self._h)
+        row = torch.tensor(self.model.F[:n], device=self.device, dtype=self.dtype)
+        return row.unsqueeze(0).repeat(self.B, 1)
+
+    def set_env_tables(self, tables):
+        """Per-environment numeric tables (domain randomisation); None reverts to the shared model."""
+        if tables is not None:
+            tables = self._chk(tables, capi.lib().tsim_table_size(self._h), "tables")
+        capi.check(capi.lib().tsim_set_env_tables(self._h, _ptr(tables), self._stream()))
+
     def reset(self, q0, qd0=None, backward_flag=False):
         q0 = self._chk(q0, self.ndof_r, "q0")
         qd0 = self._chk(qd0, self.ndof_r, "qd0")

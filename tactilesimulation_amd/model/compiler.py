@@ -255,6 +255,25 @@ class CompiledModel:
     def __init__(self, spec, I, F, meta):
         self.spec, self.I, self.F, self.meta = spec, I, F, meta
 
+    def table_offset(self, kind, key, field):
+        """Index into F[] of one numeric parameter, for per-environment tables (BatchSim.set_env_tables).
+        kind 'pair': key = (general_body | 'ground', primitive_body | body), field in kn kt mu damping shape0..3;
+        kind 'sensor': key = sensor name, field in kn kt mu damping; kind 'dof': key = (joint name, k), field damping."""
+        I = self.I
+        if kind == "pair":
+            idx = [tuple(k) for k in self.meta["pair_keys"]].index(tuple(key))
+            f = {"kn": B.TSIM_PF_KN, "kt": B.TSIM_PF_KT, "mu": B.TSIM_PF_MU, "damping": B.TSIM_PF_KD}
+            f.update({"shape%d" % i: B.TSIM_PF_SHAPE + i for i in range(4)})
+            return int(I[B.TSIM_IH_FOFF_PAIR]) + idx * B.TSIM_PF_SIZE + f[field]
+        if kind == "sensor":
+            idx = self.meta["sensor_names"].index(key)
+            f = {"kn": B.TSIM_SF_KN, "kt": B.TSIM_SF_KT, "mu": B.TSIM_SF_MU, "damping": B.TSIM_SF_KD}
+            return int(I[B.TSIM_IH_FOFF_SENSOR]) + idx * B.TSIM_SF_SIZE + f[field]
+        if kind == "dof":
+            d0, nd = self.meta["dof_of_joint"][key[0]]
+            return int(I[B.TSIM_IH_FOFF_DOF]) + (d0 + key[1]) * B.TSIM_DF_SIZE + {"damping": B.TSIM_DF_DAMPING}[field]
+        raise KeyError(kind)
+
     ndof_r = property(lambda s: int(s.I[B.TSIM_IH_NR]))
     ndof_u = property(lambda s: int(s.I[B.TSIM_IH_NU]))
     ndof_var = property(lambda s: 3 * int(s.I[B.TSIM_IH_NVAR]))

@@ -116,3 +116,41 @@ def test_model_forward_and_adjoint(name, dtype, tq, tg):
             assert np.abs(G[e] - Go).max() <= tg * max(np.abs(Go).max(), 1e-9), (name, e, np.abs(G[e] - Go).max() / np.abs(Go).max())
         assert np.abs(lq[e] - alq).max() <= tg * max(np.abs(alq).max(), 1e-9), (name, "lam_q")
         assert np.abs(lv[e] - alv).max() <= tg * max(np.abs(alv).max(), 1e-9), (name, "lam_v")
+
+
+def test_per_environment_tables_domain_randomisation(pusher_model):
+    """Each environment gets its own contact / tactile parameters (batched form of update_contact_parameters /
+    update_tactile_parameters, envs/tactile_insertion_env.py:238-281); every row must equal an oracle run on a model
+    compiled with those parameters."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.model import compiler as mc
+    from oracle.oracle import OracleSim
+    from tests.workloads import push_workload
+    m = _load("pusher")
+    B_, T = 4, 8
+    q0, u, _ = push_workload(B_, T, seed=31)
+    rng = np.random.default_rng(2)
+    kn, mu, tkn = rng.uniform(50, 400, B_), rng.uniform(0.3, 2.0, B_), rng.uniform(50, 200, B_)
+    sim = BatchSim(m, B_, dtype=torch.float64, tape_capacity=4)
+    tab = sim.base_tables()
+    tab[:, m.table_offset("pair", ("tactile_pad_left", "box"), "kn")] = torch.tensor(kn, device="cuda")
+    tab[:, m.table_offset("pair", ("tactile_pad_left", "box"), "mu")] = torch.tensor(mu, device="cuda")
+    tab[:, m.table_offset("sensor", "tactile_pad_left", "kn")] = torch.tensor(tkn, device="cuda")
+    sim.set_env_tables(tab)
+    sim.reset(torch.tensor(q0), None, False)
+    for t in range(T):
+        out = sim.step(torch.tensor(u[:, t]), 5)
+    for e in range(B_):
+        spec = mc.compile_spec(m.spec).spec
+        spec["options"]["tol"] = 1e-13
+        mc.edit_spec(spec, "contact_parameters", ("tactile_pad_left", "box"), kn=kn[e], mu=mu[e])
+        mc.edit_spec(spec, "tactile_parameters", "tactile_pad_left", kn=tkn[e])
+        o = OracleSim(mc.compile_spec(spec)); o.reset(q0[e])
+        for t in range(T):
+            o.forward(u[e, t], 5)
+        tac = o.outputs()[1]
+        assert np.abs(out["q"][e].cpu().numpy() - o.state()[0]).max() < 1e-9
+        assert np.abs(out["tactile"][e].cpu().numpy() - tac).max() < 1e-7 * max(np.abs(tac).max(), 1e-4)
+    sim.set_env_tables(None)        # back to the shared model
+    sim.reset(torch.tensor(q0), None, False)
+    sim.step(torch.tensor(u[:, 0]), 5)
