@@ -80,14 +80,17 @@ template <class R> struct FwdArgs {
   int B, nsub, record, t0;
   R* tape; const R* u;
   R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
+  const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
 };
 
 template <class R, int NRM>
 __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
-  const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
+  // Stragglers set the kernel time (all environments wait for the one with the most Newton work), so environments that
+  // were expensive in the previous env-step are dispatched first: block b runs environment order[b].
+  const int env = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
   init_world(c, lane);
   {
@@ -161,6 +164,21 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
   if (a.evals && lane == 0) a.evals[env] = (int)evals;
   // link poses / velocities in LDS are those of the accepted state (last evaluation)
   readout(c, lane, env, a.var_out, a.tac_out);
+}
+
+// ================================================================================================ LPT ordering
+// One block: counting sort of the environments by their residual-evaluation count of the last launch, descending
+// (64 bins; order inside a bin is irrelevant).  Runs on the same stream right after k_forward.
+__global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* order, int B) {
+  __shared__ int hist[64], base[64];
+  const int t = threadIdx.x;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (int e = t; e < B; e += 1024) atomicAdd(&hist[min(evals[e], 63)], 1);
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 63; k >= 0; --k) { base[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (int e = t; e < B; e += 1024) order[atomicAdd(&base[min(evals[e], 63)], 1)] = e;
 }
 
 // ================================================================================================ read-out kernel
@@ -403,7 +421,8 @@ struct tsim_batch {
   void* dFenv; int nfrec;        // optional per-environment float tables [B][nfrec] (domain randomisation)
   void* tape;                    // [(cap+1)][B][rec]
   void *lamq, *lamv;             // carried adjoint [B][nr]
-  int* evals;                    // residual evaluations of the last forward launch, per env (diagnostics)
+  int* evals;                    // residual evaluations of the last forward launch, per env
+  int* order; int order_valid;   // block -> env map for the next forward launch (LPT scheduling)
   int t_cur, record;
   size_t lds_bytes, esz;
   std::vector<CacheEntry> cache;
@@ -443,10 +462,15 @@ static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, v
   FwdArgs<R> a;
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur;
   a.tape = (R*)b->tape; a.u = (const R*)u;
-  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals;
+  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256) ? b->order : nullptr;
   if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   else hipLaunchKernelGGL((k_forward<R, 16>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   HIPCHK(hipGetLastError());
+  if (b->B >= 256) {
+    hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B);
+    HIPCHK(hipGetLastError());
+    b->order_valid = 1;
+  }
   return 0;
 }
 
@@ -492,11 +516,11 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
   if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   b->t_cur = 0; b->record = 0;
-  b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT]; b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr;
+  b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT]; b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, b->I.size() * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess) {
+      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
   }
@@ -511,7 +535,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->order);
   delete b;
 }
 
@@ -558,7 +582,7 @@ int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(b->lamq, 0, (size_t)b->B * b->nr * b->esz, st));
   HIPCHK(hipMemsetAsync(b->lamv, 0, (size_t)b->B * b->nr * b->esz, st));
-  b->t_cur = 0; b->record = backward_flag ? 1 : 0;
+  b->t_cur = 0; b->record = backward_flag ? 1 : 0; b->order_valid = 0;
   return 0;
 }
 
