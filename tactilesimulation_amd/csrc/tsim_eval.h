@@ -321,12 +321,17 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   const bool act = lane < nr;
   const R h2 = c.h * c.h;
   const S6<R> Wk = act ? ld6(c.WP + k * 6) : zero6<R>();
+  // A child's subtree wrench is handed to its parent in registers when the parent is the next link of the sweep
+  // (chains); only branching parents go through LDS (+ one barrier).
+  S6<R> cF = zero6<R>(), cdF = zero6<R>();
+  int carry_to = -1;
   for (int i = c.nl; i >= 1; --i) {
     const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
     const int par = li[TSIM_LI_PARENT], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
+    S6<R> F = ld6(c.LP + i * LK_SIZE + LK_FN);
+    S6<R> dF = act ? ld6(c.DT + (i * nd + k) * DT_SIZE + DT_FN) : zero6<R>();
+    if (carry_to == i) { F = F + cF; dF = dF + cdF; }
     if (act) {
-      const S6<R> F = ld6(c.LP + i * LK_SIZE + LK_FN);
-      const S6<R> dF = ld6(c.DT + (i * nd + k) * DT_SIZE + DT_FN);
       const bool moves = (li[TSIM_LI_ANCMASK] >> k) & 1;
       for (int j = k0; j < k0 + ndj; ++j) {
         const S6<R> Wj = ld6(c.WP + j * 6);
@@ -335,10 +340,17 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
         c.H[j * nr + k] = dtau;
         if (lane == 0) c.g[j] = dot6(Wj, F);
       }
-      if (par > 0) {
-        R* pt = c.DT + (par * nd + k) * DT_SIZE + DT_FN;
+    }
+    bool via_lds = false;
+    if (par > 0) {
+      if (par == i - 1) { cF = F; cdF = dF; carry_to = par; }
+      else {
+        via_lds = true;
+        if (act) {
+          R* pt = c.DT + (par * nd + k) * DT_SIZE + DT_FN;
 #pragma unroll
-        for (int e = 0; e < 3; ++e) { pt[e] += (&dF.a.x)[e]; pt[3 + e] += (&dF.l.x)[e]; }
+          for (int e = 0; e < 3; ++e) { pt[e] += (&dF.a.x)[e]; pt[3 + e] += (&dF.l.x)[e]; }
+        }
         if (lane == 0) {
           R* pp = c.LP + par * LK_SIZE + LK_FN;
 #pragma unroll
@@ -346,8 +358,9 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
         }
       }
     }
-    __syncthreads();
+    if (via_lds) __syncthreads();
   }
+  __syncthreads();
   // joint-space forces: damping, limits (lanes = dofs), then motors
   if (act) {
     const int j = lane;
@@ -401,37 +414,39 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
 }
 
 // ================================================================================================ dense solve
-// Gauss-Jordan with partial pivoting, one matrix row per lane held in registers (fp64 regardless of R).
+// Gauss-Jordan with partial pivoting, one matrix row per lane held in registers, in precision S: fp64 for the
+// adjoint solves (their error goes straight into the gradient), the kernel's own precision for Newton steps (a Newton
+// direction with 1e-4 relative error still converges; the residual decides the answer).
 // Pivot search: 4 DPP steps inside the first 16-lane row; pivot row broadcast: v_readlane. No LDS traffic.
 // Solves A x = b (or A^T x = b), n <= NRM <= 16.
-template <class R, int NRM>
+template <class R, int NRM, class S = double>
 __device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane) {
-  double a[NRM], rb = 0.0;
+  S a[NRM], rb = S(0);
 #pragma unroll
   for (int j = 0; j < NRM; ++j) {
-    double v = (j == lane) ? 1.0 : 0.0;
-    if (lane < n && j < n) v = (double)(transpose ? A[j * n + lane] : A[lane * n + j]);
+    S v = (j == lane) ? S(1) : S(0);
+    if (lane < n && j < n) v = (S)(transpose ? A[j * n + lane] : A[lane * n + j]);
     a[j] = v;
   }
-  if (lane < n) rb = (double)b[lane];
-  bool done = false; int mycol = -1; double mypiv = 1.0;
+  if (lane < n) rb = (S)b[lane];
+  bool done = false; int mycol = -1; S mypiv = S(1);
 #pragma unroll
   for (int col = 0; col < NRM; ++col) {
     if (col < n) {
-      float mag = (!done && lane < n) ? (float)fabs(a[col]) : -1.0f;
+      float mag = (!done && lane < n) ? fabsf((float)a[col]) : -1.0f;
       int idx = lane;
 #define TS_ARGMAX_STEP(CTRL) { float om = dpp_r<CTRL, 0xf>(mag); int oi = dpp_i<CTRL, 0xf>(idx); \
         if (om > mag || (om == mag && oi < idx)) { mag = om; idx = oi; } }
       TS_ARGMAX_STEP(0xB1) TS_ARGMAX_STEP(0x4E) TS_ARGMAX_STEP(0x141) TS_ARGMAX_STEP(0x140)
 #undef TS_ARGMAX_STEP
       const int p = __builtin_amdgcn_readfirstlane(idx);
-      const double piv = lane_bcast(a[col], p);
-      const double f = (lane != p) ? a[col] / piv : 0.0;
+      const S piv = lane_bcast(a[col], p);
+      const S f = (lane != p) ? a[col] / piv : S(0);
 #pragma unroll
       for (int j = 0; j < NRM; ++j) {
-        if (j >= col) { const double pj = lane_bcast(a[j], p); a[j] -= f * pj; }
+        if (j >= col) { const S pj = lane_bcast(a[j], p); a[j] -= f * pj; }
       }
-      const double pb = lane_bcast(rb, p); rb -= f * pb;
+      const S pb = lane_bcast(rb, p); rb -= f * pb;
       if (lane == p) { done = true; mycol = col; mypiv = piv; }
     }
   }

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
       if (iter >= c.max_iter) break;
       if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
       __syncthreads();
-      solve_lanes<R, NRM>(c.H, c.rhs, c.dq, nr, false, lane);
+      solve_lanes<R, NRM, double>(c.H, c.rhs, c.dq, nr, false, lane);
       alpha = R(1); ls = 0;
       if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
       __syncthreads();
