@@ -41,7 +41,8 @@ enum { TSIM_FH_H = 0, TSIM_FH_GX, TSIM_FH_GY, TSIM_FH_GZ, TSIM_FH_TOL, TSIM_FH_S
 
 /* joint types */
 enum { TSIM_J_REVOLUTE = 1, TSIM_J_PRISMATIC = 2, TSIM_J_PLANAR = 3, TSIM_J_TRANSLATIONAL = 4,
-       TSIM_J_FREE3D_EULER = 5, TSIM_J_FREE3D_EXP = 6 };
+       TSIM_J_FREE3D_EULER = 5, TSIM_J_FREE3D_EXP = 6,   /* 5, 6: never emitted — the compiler decomposes them */
+       TSIM_J_SPHERICAL_EXP = 7 };                         /* 3 dofs: rotation vector theta, R = exp([theta]) */
 
 /* link record: ints */
 enum { TSIM_LI_PARENT = 0, TSIM_LI_JTYPE, TSIM_LI_DOF0, TSIM_LI_NDOF, TSIM_LI_ANCMASK, TSIM_LI_SIZE = 8 };

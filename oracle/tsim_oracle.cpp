@@ -55,6 +55,18 @@ static inline Dual cos(const Dual& a) { Dual r; r.v = std::cos(a.v); double s = 
 static inline double val(double x) { return x; }
 static inline double val(const Dual& x) { return x.v; }
 
+// one-direction dual over an arbitrary scalar (used only for d/ds J_l(theta + s thetadot) inside the exponential joint)
+template <class T> struct D1 { T v, d; D1() {} D1(double x) : v(x), d(0.0) {} D1(const T& a, const T& b) : v(a), d(b) {} };
+template <class T> static inline D1<T> operator+(const D1<T>& a, const D1<T>& b) { return D1<T>(a.v + b.v, a.d + b.d); }
+template <class T> static inline D1<T> operator-(const D1<T>& a, const D1<T>& b) { return D1<T>(a.v - b.v, a.d - b.d); }
+template <class T> static inline D1<T> operator*(const D1<T>& a, const D1<T>& b) { return D1<T>(a.v * b.v, a.d * b.v + a.v * b.d); }
+template <class T> static inline D1<T> operator/(const D1<T>& a, const D1<T>& b) { T q = a.v / b.v; return D1<T>(q, (a.d - q * b.d) / b.v); }
+template <class T> static inline D1<T> sqrt(const D1<T>& a) { T s = sqrt(a.v); return D1<T>(s, a.d / (s + s)); }
+template <class T> static inline D1<T> sin(const D1<T>& a) { return D1<T>(sin(a.v), a.d * cos(a.v)); }
+template <class T> static inline D1<T> cos(const D1<T>& a) { return D1<T>(cos(a.v), T(0.0) - a.d * sin(a.v)); }
+template <class T> static inline double val(const D1<T>& x) { return val(x.v); }
+using std::sqrt; using std::sin; using std::cos;
+
 // ------------------------------------------------------------------------------------------ small linear algebra
 template <class T> struct V3 { T x, y, z; };
 template <class T> static inline V3<T> mk(T x, T y, T z) { V3<T> r; r.x = x; r.y = y; r.z = z; return r; }
@@ -76,6 +88,25 @@ template <class T> static inline M3<T> rot_axis(const double* a, const T& th) {
   R.m[3] = t * T(a[0] * a[1]) + s * T(a[2]); R.m[4] = t * T(a[1] * a[1]) + c;          R.m[5] = t * T(a[1] * a[2]) - s * T(a[0]);
   R.m[6] = t * T(a[0] * a[2]) - s * T(a[1]); R.m[7] = t * T(a[1] * a[2]) + s * T(a[0]); R.m[8] = t * T(a[2] * a[2]) + c;
   return R;
+}
+
+// exp([th]) and the left Jacobian J_l(th) of SO(3):  omega_spatial = J_l(th) thdot.   U is any scalar with + - * / sqrt sin cos.
+template <class U> static inline void so3_coeffs(const U& x, const U& y, const U& z, U& s1, U& s2, U& c2) {
+  U p2 = x * x + y * y + z * z;
+  if (val(p2) < 1e-8) {   // series in phi^2 (differentiable through the duals)
+    s1 = U(1.0) - p2 * U(1.0 / 6) + p2 * p2 * U(1.0 / 120);
+    s2 = U(0.5) - p2 * U(1.0 / 24) + p2 * p2 * U(1.0 / 720);
+    c2 = U(1.0 / 6) - p2 * U(1.0 / 120) + p2 * p2 * U(1.0 / 5040);
+  } else {
+    U p = sqrt(p2);
+    s1 = sin(p) / p; s2 = (U(1.0) - cos(p)) / p2; c2 = (p - sin(p)) / (p2 * p);
+  }
+}
+template <class U> static inline void so3_mat(const U& x, const U& y, const U& z, const U& a, const U& b, U* M) {
+  // M = I + a [th]x + b [th]x^2
+  M[0] = U(1.0) - b * (y * y + z * z); M[1] = b * x * y - a * z;          M[2] = b * x * z + a * y;
+  M[3] = b * x * y + a * z;          M[4] = U(1.0) - b * (x * x + z * z); M[5] = b * y * z - a * x;
+  M[6] = b * x * z - a * y;          M[7] = b * y * z + a * x;          M[8] = U(1.0) - b * (x * x + y * y);
 }
 
 // ------------------------------------------------------------------------------------------ model view
@@ -174,6 +205,7 @@ static void kinematics(const Model& m, const T* q, const T* qd, const T* qdd, Li
     M3<T> R0 = mul(P.R, cmat<T>(lf + TSIM_LF_R));           // joint-0 frame in the world
     V3<T> p0 = mul(P.R, cvec<T>(lf + TSIM_LF_P)) + P.p;
     const double* ax = lf + TSIM_LF_AXES;
+    V3<T> extra_b = mk<T>(T(0.0), T(0.0), T(0.0)); bool has_b = false;
     // joint motion + world-frame twist columns  W_k = Ad(E_0i) S_k
     if (jt == TSIM_J_REVOLUTE) {
       X.R = mul(R0, rot_axis<T>(ax, q[k0])); X.p = p0;
@@ -187,6 +219,26 @@ static void kinematics(const Model& m, const T* q, const T* qd, const T* qdd, Li
         X.p = X.p + a * q[k0 + k];
         Ww[k0 + k] = mk<T>(T(0.0), T(0.0), T(0.0)); Wv[k0 + k] = a;
       }
+    } else if (jt == TSIM_J_SPHERICAL_EXP) {
+      // R = R0 exp([th]);  world angular columns a_m = R0 J_l(th) e_m;  extra acceleration term b = R0 (d/dt J_l) thdot
+      T s1, s2, c2, E[9], Jl[9];
+      so3_coeffs<T>(q[k0], q[k0 + 1], q[k0 + 2], s1, s2, c2);
+      so3_mat<T>(q[k0], q[k0 + 1], q[k0 + 2], s1, s2, E);
+      so3_mat<T>(q[k0], q[k0 + 1], q[k0 + 2], s2, c2, Jl);
+      M3<T> Em; for (int e = 0; e < 9; ++e) Em.m[e] = E[e];
+      X.R = mul(R0, Em); X.p = p0;
+      for (int mcol = 0; mcol < 3; ++mcol) {
+        V3<T> a = mul(R0, mk<T>(Jl[mcol], Jl[3 + mcol], Jl[6 + mcol]));
+        Ww[k0 + mcol] = a; Wv[k0 + mcol] = cross(X.p, a);
+      }
+      typedef D1<T> U;
+      U t0(q[k0], qd[k0]), t1(q[k0 + 1], qd[k0 + 1]), t2(q[k0 + 2], qd[k0 + 2]), u1, u2, uc, JU[9];
+      so3_coeffs<U>(t0, t1, t2, u1, u2, uc);
+      so3_mat<U>(t0, t1, t2, u2, uc, JU);
+      V3<T> jd = mk<T>(JU[0].d * qd[k0] + JU[1].d * qd[k0 + 1] + JU[2].d * qd[k0 + 2],
+                       JU[3].d * qd[k0] + JU[4].d * qd[k0 + 1] + JU[5].d * qd[k0 + 2],
+                       JU[6].d * qd[k0] + JU[7].d * qd[k0 + 1] + JU[8].d * qd[k0 + 2]);
+      extra_b = mul(R0, jd); has_b = true;
     } else {
       fprintf(stderr, "oracle: joint type %d not implemented\n", jt); abort();
     }
@@ -196,6 +248,7 @@ static void kinematics(const Model& m, const T* q, const T* qd, const T* qdd, Li
     X.w = P.w + jw; X.v = P.v + jv;
     X.aw = P.aw + bw + cross(X.w, jw);
     X.av = P.av + bv + cross(X.w, jv) + cross(X.v, jw);
+    if (has_b) { X.aw = X.aw + extra_b; X.av = X.av + cross(X.p, extra_b); }
     if (!dyn) continue;
     // inertial wrench about the world origin
     T mass = T(lf[TSIM_LF_MASS]);
@@ -334,58 +387,85 @@ static bool solve_dense(int n, const double* A, const double* b, double* x, bool
 }
 
 // ------------------------------------------------------------------------------------------ simulation object
-struct Rec { std::vector<double> q0, qd0, q1, qd1, u; };
+struct Rec { std::vector<double> q0, qd0, q1, qd1, u; bool bdf2 = false; };
 struct Sim {
   Model m;
-  std::vector<double> q, qd, u, lam_q, lam_v;
+  std::vector<double> q, qd, u, lam_q, lam_v, qm1, qdm1;   // qm1 / qdm1: state before the last sub-step (BDF2)
+  bool has_prev = false;
   std::vector<Rec> tape;
   std::vector<std::vector<Rec>> cache;
   bool record = false;
   long newton_iters = 0, substeps = 0, nonconv = 0;
 };
 
-// g = h^2 r for BDF1 at trial q1 (plain doubles)
-static void eval_g(const Model& m, const double* q1, const double* q0, const double* qd0, const double* u, double* g) {
-  double qd[MAXR], qa[MAXR]; Link<double> L[MAXL];
+// One implicit step in predictor form (covers BDF1 and BDF2):
+//   qd1 = qdpred + cv (q1 - qpred),  qdd1 = ca (q1 - qpred),  g = r(q1, qd1, qdd1, u) / ca
+//   BDF1: qpred = q0 + h qd0, qdpred = qd0, cv = 1/h, ca = 1/h^2            (g = h^2 r, RedMax BDF1)
+//   BDF2: qpred = 4/3 q0 - 1/3 q_1 + 8/9 h qd0 - 2/9 h qd_1, qdpred = (3 qpred - 4 q0 + q_1)/(2h),
+//         cv = 3/(2h), ca = 9/(4h^2)                                        (RedMax BDF2; first step after reset: BDF1)
+struct StepCoef { double qpred[MAXR], qdpred[MAXR], cv, ca; };
+static void make_coef(const Model& m, const double* q0, const double* qd0, const double* qm1, const double* qdm1, StepCoef& c) {
   double h = m.h;
-  for (int k = 0; k < m.nr; ++k) { qd[k] = (q1[k] - q0[k]) / h; qa[k] = (q1[k] - q0[k] - h * qd0[k]) / (h * h); }
-  residual<double>(m, q1, qd, qa, u, g, L);
-  for (int k = 0; k < m.nr; ++k) g[k] *= h * h;
+  if (qm1) {
+    c.cv = 1.5 / h; c.ca = 2.25 / (h * h);
+    for (int k = 0; k < m.nr; ++k) {
+      c.qpred[k] = 4.0 / 3 * q0[k] - 1.0 / 3 * qm1[k] + 8.0 / 9 * h * qd0[k] - 2.0 / 9 * h * qdm1[k];
+      c.qdpred[k] = (3 * c.qpred[k] - 4 * q0[k] + qm1[k]) / (2 * h);
+    }
+  } else {
+    c.cv = 1.0 / h; c.ca = 1.0 / (h * h);
+    for (int k = 0; k < m.nr; ++k) { c.qpred[k] = q0[k] + h * qd0[k]; c.qdpred[k] = qd0[k]; }
+  }
 }
-// g and Jacobians with seed scales (sq, sv, sa) on direction k of the chosen argument; J[row*ncol+col]
-// which: 0 = d/dq1 (total), 1 = d/dq0 (total), 2 = d/dqd0, 3 = d/du
-static void eval_g_jac(const Model& m, const double* q1, const double* q0, const double* qd0, const double* u, int which, double* g, double* J) {
+static void eval_g_c(const Model& m, const double* q1, const StepCoef& c, const double* u, double* g) {
+  double qd[MAXR], qa[MAXR]; Link<double> L[MAXL];
+  for (int k = 0; k < m.nr; ++k) { double d = q1[k] - c.qpred[k]; qd[k] = c.qdpred[k] + c.cv * d; qa[k] = c.ca * d; }
+  residual<double>(m, q1, qd, qa, u, g, L);
+  for (int k = 0; k < m.nr; ++k) g[k] /= c.ca;
+}
+// which: 0 = d/dq1 (total), 1 = d/dq0 (total, BDF1 only), 2 = d/dqd0 (BDF1 only), 3 = d/du ;  J[row*ncol+col]
+static void eval_g_jac_c(const Model& m, const double* q1, const StepCoef& c, const double* u, int which, double* g, double* J) {
   int nr = m.nr, ncol = which == 3 ? m.nu : nr;
   double h = m.h;
   for (int c0 = 0; c0 < ncol; c0 += NDMAX) {
     int nd = std::min(NDMAX, ncol - c0);
     g_nd = nd;
     Dual q[MAXR], qd[MAXR], qa[MAXR], uu[MAXR], r[MAXR]; Link<Dual> L[MAXL];
-    for (int k = 0; k < nr; ++k) { q[k] = Dual(q1[k]); qd[k] = Dual((q1[k] - q0[k]) / h); qa[k] = Dual((q1[k] - q0[k] - h * qd0[k]) / (h * h)); }
+    for (int k = 0; k < nr; ++k) { double d = q1[k] - c.qpred[k]; q[k] = Dual(q1[k]); qd[k] = Dual(c.qdpred[k] + c.cv * d); qa[k] = Dual(c.ca * d); }
     for (int j = 0; j < m.nu; ++j) uu[j] = Dual(u[j]);
     for (int d = 0; d < nd; ++d) {
       int k = c0 + d;
-      if (which == 0) { q[k].d[d] = 1.0; qd[k].d[d] = 1.0 / h; qa[k].d[d] = 1.0 / (h * h); }
-      else if (which == 1) { qd[k].d[d] = -1.0 / h; qa[k].d[d] = -1.0 / (h * h); }
-      else if (which == 2) { qa[k].d[d] = -1.0 / h; }
+      if (which == 0) { q[k].d[d] = 1.0; qd[k].d[d] = c.cv; qa[k].d[d] = c.ca; }
+      else if (which == 1) { qd[k].d[d] = -c.cv; qa[k].d[d] = -c.ca; }                  // qpred = q0 + h qd0, qdpred = qd0
+      else if (which == 2) { qd[k].d[d] = 1.0 - c.cv * h; qa[k].d[d] = -c.ca * h; }
       else uu[k].d[d] = 1.0;
     }
     residual<Dual>(m, q, qd, qa, uu, r, L);
-    for (int i = 0; i < nr; ++i) { g[i] = r[i].v * h * h; for (int d = 0; d < nd; ++d) J[i * ncol + c0 + d] = r[i].d[d] * h * h; }
+    for (int i = 0; i < nr; ++i) { g[i] = r[i].v / c.ca; for (int d = 0; d < nd; ++d) J[i * ncol + c0 + d] = r[i].d[d] / c.ca; }
     g_nd = 0;
   }
+}
+// BDF1 wrappers in terms of (q0, qd0) (adjoint, diagnostics)
+static void eval_g(const Model& m, const double* q1, const double* q0, const double* qd0, const double* u, double* g) {
+  StepCoef c; make_coef(m, q0, qd0, nullptr, nullptr, c); eval_g_c(m, q1, c, u, g);
+}
+static void eval_g_jac(const Model& m, const double* q1, const double* q0, const double* qd0, const double* u, int which, double* g, double* J) {
+  StepCoef c; make_coef(m, q0, qd0, nullptr, nullptr, c); eval_g_jac_c(m, q1, c, u, which, g, J);
 }
 
 static double norm2(int n, const double* x) { double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return std::sqrt(s); }
 
-// one implicit BDF1 sub-step; returns Newton iterations used, negative if not converged
-static int substep_bdf1(Sim& S, const double* u) {
+// one implicit sub-step (BDF1, or BDF2 once a previous state exists); returns Newton iterations used, negative if not converged
+static int substep(Sim& S, const double* u) {
   const Model& m = S.m; int nr = m.nr; double h = m.h;
   double q0[MAXR], qd0[MAXR], q1[MAXR], g[MAXR], H[MAXR * MAXR], dq[MAXR], qn[MAXR], gn[MAXR];
-  for (int k = 0; k < nr; ++k) { q0[k] = S.q[k]; qd0[k] = S.qd[k]; q1[k] = q0[k] + h * qd0[k]; }
+  for (int k = 0; k < nr; ++k) { q0[k] = S.q[k]; qd0[k] = S.qd[k]; }
+  const bool bdf2 = m.integrator == 2 && S.has_prev;
+  StepCoef c; make_coef(m, q0, qd0, bdf2 ? S.qm1.data() : nullptr, bdf2 ? S.qdm1.data() : nullptr, c);
+  for (int k = 0; k < nr; ++k) q1[k] = c.qpred[k];
   int it = 0; bool ok = false;
   for (; it <= m.max_iter; ++it) {
-    eval_g_jac(m, q1, q0, qd0, u, 0, g, H);
+    eval_g_jac_c(m, q1, c, u, 0, g, H);
     double gnorm = norm2(nr, g);
     if (gnorm < m.tol) { ok = true; break; }
     if (it == m.max_iter) break;
@@ -394,18 +474,22 @@ static int substep_bdf1(Sim& S, const double* u) {
     double alpha = 1.0;
     for (int ls = 0; ls <= m.max_ls; ++ls) {
       for (int k = 0; k < nr; ++k) qn[k] = q1[k] + alpha * dq[k];
-      eval_g(m, qn, q0, qd0, u, gn);
+      eval_g_c(m, qn, c, u, gn);
       if (norm2(nr, gn) < gnorm || ls == m.max_ls) break;
       alpha *= 0.5;
     }
     for (int k = 0; k < nr; ++k) q1[k] = qn[k];
   }
+  double qd1[MAXR];
+  for (int k = 0; k < nr; ++k) qd1[k] = c.qdpred[k] + c.cv * (q1[k] - c.qpred[k]);
   if (S.record) {
     Rec r; r.q0.assign(q0, q0 + nr); r.qd0.assign(qd0, qd0 + nr); r.q1.assign(q1, q1 + nr); r.u.assign(u, u + m.nu);
-    r.qd1.resize(nr); for (int k = 0; k < nr; ++k) r.qd1[k] = (q1[k] - q0[k]) / h;
+    r.qd1.assign(qd1, qd1 + nr); r.bdf2 = bdf2;
     S.tape.push_back(r);
   }
-  for (int k = 0; k < nr; ++k) { S.q[k] = q1[k]; S.qd[k] = (q1[k] - q0[k]) / h; }
+  S.qm1.assign(q0, q0 + nr); S.qdm1.assign(qd0, qd0 + nr); S.has_prev = true;
+  for (int k = 0; k < nr; ++k) { S.q[k] = q1[k]; S.qd[k] = qd1[k]; }
+  (void)h;
   S.newton_iters += it; S.substeps += 1; if (!ok) S.nonconv += 1;
   return ok ? it : -it - 1;
 }
@@ -456,14 +540,13 @@ void orc_destroy(void* h) { delete (Sim*)h; }
 void orc_reset(void* h, const double* q, const double* qd, int record) {
   Sim& S = *(Sim*)h;
   for (int k = 0; k < S.m.nr; ++k) { S.q[k] = q[k]; S.qd[k] = qd[k]; }
-  S.tape.clear(); S.record = record != 0;
+  S.tape.clear(); S.record = record != 0; S.has_prev = false;
   std::fill(S.lam_q.begin(), S.lam_q.end(), 0.0); std::fill(S.lam_v.begin(), S.lam_v.end(), 0.0);
 }
 // nsub implicit sub-steps with u held; returns number of non-converged sub-steps
 int orc_forward(void* h, const double* u, int nsub) {
   Sim& S = *(Sim*)h; int bad = 0;
-  if (S.m.integrator != 1) { fprintf(stderr, "oracle: only BDF1 implemented\n"); return -1; }
-  for (int s = 0; s < nsub; ++s) if (substep_bdf1(S, u) < 0) ++bad;
+  for (int s = 0; s < nsub; ++s) if (substep(S, u) < 0) ++bad;
   return bad;
 }
 void orc_get_state(void* h, double* q, double* qd) { Sim& S = *(Sim*)h; for (int k = 0; k < S.m.nr; ++k) { q[k] = S.q[k]; qd[k] = S.qd[k]; } }
@@ -487,6 +570,7 @@ int orc_backward_steps(void* h, int n, const double* df_dq, const double* df_dva
   std::vector<double> g(nr), H(nr * nr), Jq0(nr * nr), Jv0(nr * nr), Ju(nr * std::max(nu, 1)), rhs(nr), z(nr);
   for (int j = n - 1; j >= 0; --j) {
     Rec& r = S.tape.back();
+    if (r.bdf2) return -3;      // adjoint of BDF2 steps is not implemented (the reference's BDF2 model is forward-only)
     for (int k = 0; k < nr; ++k) S.lam_q[k] += df_dq ? df_dq[j * nr + k] : 0.0;
     output_vjp(m, r.q1.data(), r.qd1.data(), df_dvar ? df_dvar + (size_t)j * 3 * m.nvar : nullptr,
                df_dtac ? df_dtac + (size_t)j * 3 * m.ntax : nullptr, S.lam_q.data(), S.lam_v.data());

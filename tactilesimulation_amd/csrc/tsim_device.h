@@ -112,6 +112,72 @@ template <class T> __device__ __forceinline__ S6<T> wrench_to_world(const M3<T>&
   return mk6<T>(mulMv(R, w.a) + cross3(p, f), f);
 }
 
+// ------------------------------------------------------------------------------------------------ SO(3) exponential joint
+// Small forward-mode jets, used ONLY inside the rotation-vector joint to differentiate the 3x3 left Jacobian J_l(theta)
+// (first derivatives w.r.t. theta, and their directional derivative along thetadot). Everything else in the kernels
+// propagates tangents analytically.
+template <class T, int N> struct Jet { T v; T d[N]; };
+__device__ __forceinline__ float t_sin(float x) { return sinf(x); }
+__device__ __forceinline__ double t_sin(double x) { return sin(x); }
+__device__ __forceinline__ float t_cos(float x) { return cosf(x); }
+__device__ __forceinline__ double t_cos(double x) { return cos(x); }
+__device__ __forceinline__ float jval(float x) { return x; }
+__device__ __forceinline__ double jval(double x) { return x; }
+template <class T, int N> __device__ __forceinline__ auto jval(const Jet<T, N>& a) { return jval(a.v); }
+template <class T> struct JetC { static __device__ __forceinline__ T c(double x) { return T(x); } };
+template <class T, int N> struct JetC<Jet<T, N>> {
+  static __device__ __forceinline__ Jet<T, N> c(double x) { Jet<T, N> r; r.v = JetC<T>::c(x);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = JetC<T>::c(0.0);
+    return r; }
+};
+template <class T, int N> __device__ __forceinline__ Jet<T, N> operator+(const Jet<T, N>& a, const Jet<T, N>& b) { Jet<T, N> r; r.v = a.v + b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i];
+  return r; }
+template <class T, int N> __device__ __forceinline__ Jet<T, N> operator-(const Jet<T, N>& a, const Jet<T, N>& b) { Jet<T, N> r; r.v = a.v - b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i];
+  return r; }
+template <class T, int N> __device__ __forceinline__ Jet<T, N> operator*(const Jet<T, N>& a, const Jet<T, N>& b) { Jet<T, N> r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  return r; }
+template <class T, int N> __device__ __forceinline__ Jet<T, N> operator/(const Jet<T, N>& a, const Jet<T, N>& b) { Jet<T, N> r; r.v = a.v / b.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+  return r; }
+template <class T, int N> __device__ __forceinline__ Jet<T, N> t_sqrt(const Jet<T, N>& a) { Jet<T, N> r; r.v = t_sqrt(a.v); const T k = JetC<T>::c(0.5) / r.v;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * k;
+  return r; }
+template <class T, int N> __device__ __forceinline__ Jet<T, N> t_sin(const Jet<T, N>& a) { Jet<T, N> r; r.v = t_sin(a.v); const T c = t_cos(a.v);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c;
+  return r; }
+template <class T, int N> __device__ __forceinline__ Jet<T, N> t_cos(const Jet<T, N>& a) { Jet<T, N> r; r.v = t_cos(a.v); const T s = JetC<T>::c(0.0) - t_sin(a.v);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s;
+  return r; }
+// exp([th]) = I + s1 [th]x + s2 [th]x^2 ;  J_l(th) = I + s2 [th]x + c2 [th]x^2   (omega_spatial = J_l thdot)
+template <class U> __device__ __forceinline__ void so3_coeffs(const U& x, const U& y, const U& z, U& s1, U& s2, U& c2) {
+  const U p2 = x * x + y * y + z * z;
+  if (jval(p2) < 1e-8) {          // series in phi^2, differentiable through the jets
+    s1 = JetC<U>::c(1.0) - p2 * JetC<U>::c(1.0 / 6) + p2 * p2 * JetC<U>::c(1.0 / 120);
+    s2 = JetC<U>::c(0.5) - p2 * JetC<U>::c(1.0 / 24) + p2 * p2 * JetC<U>::c(1.0 / 720);
+    c2 = JetC<U>::c(1.0 / 6) - p2 * JetC<U>::c(1.0 / 120) + p2 * p2 * JetC<U>::c(1.0 / 5040);
+  } else {
+    const U p = t_sqrt(p2);
+    s1 = t_sin(p) / p; s2 = (JetC<U>::c(1.0) - t_cos(p)) / p2; c2 = (p - t_sin(p)) / (p2 * p);
+  }
+}
+template <class U> __device__ __forceinline__ void so3_mat(const U& x, const U& y, const U& z, const U& a, const U& b, U* M) {
+  const U one = JetC<U>::c(1.0);
+  M[0] = one - b * (y * y + z * z); M[1] = b * x * y - a * z;        M[2] = b * x * z + a * y;
+  M[3] = b * x * y + a * z;        M[4] = one - b * (x * x + z * z); M[5] = b * y * z - a * x;
+  M[6] = b * x * z - a * y;        M[7] = b * y * z + a * x;        M[8] = one - b * (x * x + y * y);
+}
+
 // ------------------------------------------------------------------------------------------------ wave reductions
 // Cross-lane traffic stays in the VALU: DPP row operations (quad_perm / row_mirror / row_bcast) instead of
 // ds_bpermute round trips through the LDS crossbar, and v_readlane for broadcasts of a wave-uniform lane.
@@ -153,9 +219,12 @@ template <class R> struct Ctx {
   int off_link, off_dof, off_motor, off_var, off_pair, off_sensor, off_sprim;
   int foff_link, foff_dof, foff_motor, foff_var, foff_pair, foff_sensor, foff_cpt, foff_tax;
   R h, gx, gy, gz, tol;
+  R cv, ca;                               // qd = qdp + cv*dl, qdd = ca*dl (BDF1: 1/h, 1/h^2; BDF2: 3/(2h), 9/(4h^2)); g = r/ca
   int max_iter, max_ls;
   // LDS
   R *q, *q0, *qd0, *u, *qd, *qa, *g, *dq, *dl, *H, *H2, *lamq, *lamv, *z, *rhs;
+  R *qp, *qdp, *qm1, *qdm1;               // predictor of the implicit step; state before the previous sub-step (BDF2)
+  R *expw;                                // rotation-vector joint: d W_m / d theta_k, 9 x 6 reals
   R *LP, *WP, *DT, *PP, *PT, *scr;
   long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
   mutable int nstamp;
@@ -167,7 +236,7 @@ template <class R> struct Ctx {
 __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int ni, int nfrec, int esz) {
   int nd = nr;
   int n = nfrec + 2; (void)ni; (void)esz;
-  n += 11 * nr + nu;                       // q q0 qd0 qd qa g dq(2) dl(2) spare ; u
+  n += 15 * nr + nu;                       // q q0 qd0 qd qa g dq(2) dl(2) qp qdp qm1 qdm1 spare ; u
   n += 2 * nr * nr;                        // H, H2 (taped Newton matrix in the adjoint kernel)
   n += 4 * nr;                             // lamq lamv z rhs
   n += (nl + 1) * LK_SIZE;                 // LP
@@ -175,7 +244,7 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int ni, int 
   n += (nl + 1) * nd * DT_SIZE;            // DT
   n += TS_PAIR_GROUP * PP_SIZE;            // PP
   n += TS_PAIR_GROUP * nd * PT_SIZE;       // PT
-  n += 16;                                 // scratch
+  n += 16 + 54;                            // scratch, expw
   return n + 8;
 }
 
@@ -205,10 +274,12 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
   c.foff_cpt = I[TSIM_IH_FOFF_CPT]; c.foff_tax = I[TSIM_IH_FOFF_TAXEL];
   c.h = F[TSIM_FH_H]; c.gx = F[TSIM_FH_GX]; c.gy = F[TSIM_FH_GY]; c.gz = F[TSIM_FH_GZ]; c.tol = F[TSIM_FH_TOL];
   c.max_iter = I[TSIM_IH_MAX_ITER]; c.max_ls = I[TSIM_IH_MAX_LS];
+  c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
   int nr = c.nr, nl = c.nl, nd = c.nd;
   R* p = lds;
   c.q = p; p += nr; c.q0 = p; p += nr; c.qd0 = p; p += nr; c.qd = p; p += nr; c.qa = p; p += nr;
-  c.g = p; p += nr; c.dq = p; p += 2 * nr; c.dl = p; p += 2 * nr; c.u = p; p += c.nu;
+  c.g = p; p += nr; c.dq = p; p += 2 * nr; c.dl = p; p += 2 * nr;
+  c.qp = p; p += nr; c.qdp = p; p += nr; c.qm1 = p; p += nr; c.qdm1 = p; p += nr; c.u = p; p += c.nu;
   c.H = p; p += nr * nr; c.H2 = p; p += nr * nr;
   c.lamq = p; p += nr; c.lamv = p; p += nr; c.z = p; p += nr; c.rhs = p; p += nr;
   c.LP = p; p += (nl + 1) * LK_SIZE;
@@ -216,6 +287,7 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
   c.DT = p; p += (nl + 1) * nd * DT_SIZE;
   c.PP = p; p += TS_PAIR_GROUP * PP_SIZE;
   c.PT = p; p += TS_PAIR_GROUP * nd * PT_SIZE;
+  c.expw = p; p += 54;
   c.scr = p;
 }
 

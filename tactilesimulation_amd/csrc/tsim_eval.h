@@ -42,7 +42,66 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
     const R* ax = lf + TSIM_LF_AXES;
     S6<R> VJ = zero6<R>(), AJ = zero6<R>();
     S6<R> Wj[3];                                     // twist columns of this joint (<= 3 dofs on the HIP path)
-    if (jt == TSIM_J_REVOLUTE) {
+    // rotation-vector joint only: Bvec = (b; p x b), b = R0 (d/dt J_l) thdot, and what lane k needs for its tangents
+    const bool is_exp = jt == TSIM_J_SPHERICAL_EXP;
+    S6<R> Bvec = zero6<R>(), dWexp[3], dBexp = zero6<R>();
+    dWexp[0] = dWexp[1] = dWexp[2] = zero6<R>();
+    if (is_exp) {
+      typedef Jet<R, 1> J1;
+      typedef Jet<J1, 3> J3;
+      J3 t[3], s1, s2, c2, JL[9];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        t[m].v.v = c.q[k0 + m]; t[m].v.d[0] = c.qd[k0 + m];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) { t[m].d[n].v = (m == n) ? R(1) : R(0); t[m].d[n].d[0] = R(0); }
+      }
+      so3_coeffs<J3>(t[0], t[1], t[2], s1, s2, c2);
+      so3_mat<J3>(t[0], t[1], t[2], s2, c2, JL);             // J_l with d/dtheta_n (outer) and d/ds along thdot (inner)
+      R E[9];
+      so3_mat<R>(c.q[k0], c.q[k0 + 1], c.q[k0 + 2], s1.v.v, s2.v.v, E);
+      M3<R> Em;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Em.m[e] = E[e];
+      XR = mulMM(R0, Em);
+      const V3<R> thd = mk3<R>(c.qd[k0], c.qd[k0 + 1], c.qd[k0 + 2]);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const V3<R> a = mulMv(R0, mk3<R>(JL[m].v.v, JL[3 + m].v.v, JL[6 + m].v.v));
+        Wj[m] = mk6<R>(a, cross3(Xp, a));
+        VJ = VJ + Wj[m] * c.qd[k0 + m]; AJ = AJ + Wj[m] * c.qa[k0 + m];
+      }
+      {
+        const V3<R> b0 = mk3<R>(JL[0].v.d[0] * thd.x + JL[1].v.d[0] * thd.y + JL[2].v.d[0] * thd.z,
+                                JL[3].v.d[0] * thd.x + JL[4].v.d[0] * thd.y + JL[5].v.d[0] * thd.z,
+                                JL[6].v.d[0] * thd.x + JL[7].v.d[0] * thd.y + JL[8].v.d[0] * thd.z);
+        const V3<R> b = mulMv(R0, b0);
+        Bvec = mk6<R>(b, cross3(Xp, b));
+      }
+      // d W_m / d theta_kk for all (m, kk): stored for phase 3 by lane 0, kept in registers by the lane that owns kk
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        S6<R> dWm[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const V3<R> bm = mulMv(R0, mk3<R>(JL[m].d[kk].v, JL[3 + m].d[kk].v, JL[6 + m].d[kk].v));
+          dWm[m] = mk6<R>(bm, cross3(Xp, bm));
+          if (lane == 0) st6(c.expw + (m * 3 + kk) * 6, dWm[m]);
+        }
+        if (k == k0 + kk) {
+          dWexp[0] = dWm[0]; dWexp[1] = dWm[1]; dWexp[2] = dWm[2];
+          // d b0 / d theta_kk (thdot fixed) and d b0 / d thdot_kk
+          const V3<R> Cq = mk3<R>(JL[0].d[kk].d[0] * thd.x + JL[1].d[kk].d[0] * thd.y + JL[2].d[kk].d[0] * thd.z,
+                                  JL[3].d[kk].d[0] * thd.x + JL[4].d[kk].d[0] * thd.y + JL[5].d[kk].d[0] * thd.z,
+                                  JL[6].d[kk].d[0] * thd.x + JL[7].d[kk].d[0] * thd.y + JL[8].d[kk].d[0] * thd.z);
+          const V3<R> Cv = mk3<R>(JL[0].d[kk].v * thd.x + JL[1].d[kk].v * thd.y + JL[2].d[kk].v * thd.z + JL[kk].v.d[0],
+                                  JL[3].d[kk].v * thd.x + JL[4].d[kk].v * thd.y + JL[5].d[kk].v * thd.z + JL[3 + kk].v.d[0],
+                                  JL[6].d[kk].v * thd.x + JL[7].d[kk].v * thd.y + JL[8].d[kk].v * thd.z + JL[6 + kk].v.d[0]);
+          const V3<R> db = mulMv(R0, Cq * sq + Cv * sv);
+          dBexp = mk6<R>(db, cross3(Xp, db));
+        }
+      }
+    } else if (jt == TSIM_J_REVOLUTE) {
       R s, co; t_sincos(c.q[k0], s, co);
       const R t = R(1) - co;
       M3<R> Q;
@@ -67,7 +126,7 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
       }
     }
     const S6<R> V = PV + VJ;
-    const S6<R> A = PA + AJ + crm(V, VJ);
+    const S6<R> A = PA + AJ + crm(V, VJ) + Bvec;
     const V3<R> cw = mulMv(XR, ldv(lf + TSIM_LF_COM)) + Xp;
     // world rotational inertia  Ic = XR Il XR^T  (symmetric, 6 entries)
     const R* il = lf + TSIM_LF_INERTIA;
@@ -106,13 +165,18 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
         const S6<R> dxi = Wk * sq;                                  // displacement of link i
         // joint part: dW_j = dxi x W_j ;  d(VJ) = sum dW_j qd_j + W_k sv ;  d(AJ) = sum dW_j qdd_j + W_k sa
         S6<R> dVJ = zero6<R>(), dAJ = zero6<R>();
+        const bool own = k >= k0 && k < k0 + ndj;
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
-          if (kk < ndj) { const S6<R> dW = crm(dxi, Wj[kk]); dVJ = dVJ + dW * c.qd[k0 + kk]; dAJ = dAJ + dW * c.qa[k0 + kk]; }
+          if (kk < ndj) {
+            const S6<R> dW = (is_exp && own) ? dWexp[kk] * sq : crm(dxi, Wj[kk]);
+            dVJ = dVJ + dW * c.qd[k0 + kk]; dAJ = dAJ + dW * c.qa[k0 + kk];
+          }
         }
-        if (k >= k0 && k < k0 + ndj) { dVJ = dVJ + Wk * sv; dAJ = dAJ + Wk * sa; }
+        if (own) { dVJ = dVJ + Wk * sv; dAJ = dAJ + Wk * sa; }
         dV = PdV + dVJ;
         dA = PdA + dAJ + crm(dV, VJ) + crm(V, dVJ);
+        if (is_exp) dA = dA + (own ? dBexp : crm(dxi, Bvec));
         // inertial wrench  F = I A + V x* (I V);  d(I m) = dxi x* (I m) - I (dxi x m) + I dm
         const S6<R> dh = crf(dxi, h) - imul(mass, cw, Ic, crm(dxi, V)) + imul(mass, cw, Ic, dV);
         dF = crf(dxi, IA) - imul(mass, cw, Ic, crm(dxi, A)) + imul(mass, cw, Ic, dA) + crf(dV, h) + crf(V, dh);
@@ -319,7 +383,7 @@ template <class R>
 __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   const int nd = c.nd, k = lane, nr = c.nr;
   const bool act = lane < nr;
-  const R h2 = c.h * c.h;
+  const R h2 = R(1) / c.ca;      // g = r / ca  (BDF1: h^2 r)
   const S6<R> Wk = act ? ld6(c.WP + k * 6) : zero6<R>();
   // A child's subtree wrench is handed to its parent in registers when the parent is the next link of the sweep
   // (chains); only branching parents go through LDS (+ one barrier).
@@ -336,7 +400,11 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
       for (int j = k0; j < k0 + ndj; ++j) {
         const S6<R> Wj = ld6(c.WP + j * 6);
         R dtau = dot6(Wj, dF);
-        if (moves) dtau += sq * dot6(crm(Wk, Wj), F);
+        if (moves) {
+          const bool same_exp = li[TSIM_LI_JTYPE] == TSIM_J_SPHERICAL_EXP && k >= k0 && k < k0 + ndj;
+          const S6<R> dW = same_exp ? ld6(c.expw + ((j - k0) * 3 + (k - k0)) * 6) : crm(Wk, Wj);
+          dtau += sq * dot6(dW, F);
+        }
         c.H[j * nr + k] = dtau;
         if (lane == 0) c.g[j] = dot6(Wj, F);
       }
@@ -392,16 +460,17 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
 }
 
 // full evaluation at the trial increment held in c.dl (with c.q0, c.qd0, c.u): fills c.q, c.qd, c.qa, link state, g, H.
-// The Newton unknown is the increment  dl = q1 - q0 - h qd0  (O(h^2 * acceleration)), not q1 itself, so that the
-// discrete acceleration dl/h^2 and velocity qd0 + dl/h keep full relative precision in fp32 (no q1 - q0 cancellation).
-// forward seeds: (1, 1/h, 1/h^2) -> H = dg/dq1 ;  adjoint seeds: (1, 0, 0) -> H = h^2 dr/dq.
+// The Newton unknown is the increment  dl = q1 - qp  over the force-free predictor qp (BDF1: q0 + h qd0; BDF2:
+// 4/3 q0 - 1/3 q_1 + 8/9 h qd0 - 2/9 h qd_1), not q1 itself: qd1 = qdp + cv dl, qdd1 = ca dl keep full relative
+// precision in fp32 (no q1 - q0 cancellation).  forward seeds: (1, cv, ca) -> H = dg/dq1 ;  adjoint seeds (1, 0, 0)
+// -> H = (1/ca) dr/dq  (BDF1: h^2 dr/dq).
 template <class R, int NRM>
 __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   if (lane < c.nr) {
     const R d = c.dl[lane];
-    c.qd[lane] = c.qd0[lane] + d / c.h;
-    c.qa[lane] = d / (c.h * c.h);
-    c.q[lane] = c.q0[lane] + (c.h * c.qd0[lane] + d);
+    c.qd[lane] = c.qdp[lane] + c.cv * d;
+    c.qa[lane] = c.ca * d;
+    c.q[lane] = c.qp[lane] + d;
   }
   __syncthreads();
   TS_STAMP(c);

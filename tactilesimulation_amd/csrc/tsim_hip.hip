@@ -81,6 +81,7 @@ template <class R> struct FwdArgs {
   R* tape; const R* u;
   R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
   const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
+  R* prev; int has_prev;  // state before the previous sub-step [B][2 nr] (BDF2 history across launches)
 };
 
 template <class R, int NRM>
@@ -99,12 +100,30 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
   }
   __syncthreads();
-  const R sq = R(1), sv = R(1) / c.h, sa = R(1) / (c.h * c.h);
   R* dlbase = c.dq + nr;
   int bad = 0; bool nonfinite = false;
   long long evals = 0;
+  const bool bdf2_model = c.I[TSIM_IH_INTEGRATOR] == 2;
+  bool has_prev = a.has_prev != 0;
+  if (bdf2_model && has_prev && lane < nr) {
+    c.qm1[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qdm1[lane] = a.prev[(size_t)env * 2 * nr + nr + lane];
+  }
+  __syncthreads();
   for (int s = 0; s < a.nsub; ++s) {
-    if (lane < nr) c.dl[lane] = R(0);          // initial guess q1 = q0 + h qd0
+    // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment
+    if (bdf2_model && has_prev) {
+      c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h);
+      if (lane < nr) {
+        const R qp = R(4.0 / 3) * c.q0[lane] - R(1.0 / 3) * c.qm1[lane] + c.h * (R(8.0 / 9) * c.qd0[lane] - R(2.0 / 9) * c.qdm1[lane]);
+        c.qp[lane] = qp;
+        c.qdp[lane] = (R(3) * qp - R(4) * c.q0[lane] + c.qm1[lane]) / (R(2) * c.h);
+      }
+    } else {
+      c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
+      if (lane < nr) { c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane]; }
+    }
+    const R sq = R(1), sv = c.cv, sa = c.ca;
+    if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
     __syncthreads();
     // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
     // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).
@@ -149,9 +168,11 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
       if (lane < nu) rec[2 * nr + nr * nr + lane] = c.u[lane];
     }
     __syncthreads();
-    if (lane < nr) { c.q0[lane] = c.q[lane]; c.qd0[lane] = c.qd[lane]; }
+    if (lane < nr) { c.qm1[lane] = c.q0[lane]; c.qdm1[lane] = c.qd0[lane]; c.q0[lane] = c.q[lane]; c.qd0[lane] = c.qd[lane]; }
+    has_prev = true;
     __syncthreads();
   }
+  if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = c.qdm1[lane]; }
   if (!a.record) {
     R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
     if (lane < nr) { st[lane] = c.q0[lane]; st[nr + lane] = c.qd0[lane]; }
@@ -212,7 +233,8 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   init_world(c, lane);
   if (lane < nr) {
     c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane];
-    c.dl[lane] = a.q1[(size_t)env * nr + lane] - c.q0[lane] - c.h * c.qd0[lane];
+    c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane];
+    c.dl[lane] = a.q1[(size_t)env * nr + lane] - c.qp[lane];
   }
   if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
   __syncthreads();
@@ -423,6 +445,7 @@ struct tsim_batch {
   void *lamq, *lamv;             // carried adjoint [B][nr]
   int* evals;                    // residual evaluations of the last forward launch, per env
   int* order; int order_valid;   // block -> env map for the next forward launch (LPT scheduling)
+  void* prev; int has_prev;      // BDF2: state before the previous sub-step [B][2 nr]
   int t_cur, record;
   size_t lds_bytes, esz;
   std::vector<CacheEntry> cache;
@@ -463,6 +486,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, v
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur;
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256) ? b->order : nullptr;
+  a.prev = (R*)b->prev; a.has_prev = b->has_prev;
   if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   else hipLaunchKernelGGL((k_forward<R, 16>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   HIPCHK(hipGetLastError());
@@ -495,13 +519,15 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   if (I[TSIM_IH_MAGIC] != TSIM_MAGIC || I[TSIM_IH_VERSION] != TSIM_VERSION) return fail("model blob: bad magic/version");
   if (B <= 0 || tape_capacity < 0) return fail("bad batch size / tape capacity");
   if (dtype != TSIM_F32 && dtype != TSIM_F64) return fail("bad dtype");
-  if (I[TSIM_IH_INTEGRATOR] != 1) return fail("integrator not supported by the HIP path yet (BDF1 only)");
+  if (I[TSIM_IH_INTEGRATOR] != 1 && I[TSIM_IH_INTEGRATOR] != 2) return fail("unknown integrator");
   const int nl = I[TSIM_IH_NL], nr = I[TSIM_IH_NR], nu = I[TSIM_IH_NU];
+  int n_exp = 0;
   if (nr > 16 || nr < 1 || nu > TS_WAVE) return fail("ndof_r must be in 1..16");
   for (int i = 1; i <= nl; ++i) {
     int jt = I[I[TSIM_IH_OFF_LINK] + (i - 1) * TSIM_LI_SIZE + TSIM_LI_JTYPE];
-    if (jt != TSIM_J_REVOLUTE && jt != TSIM_J_PRISMATIC && jt != TSIM_J_PLANAR && jt != TSIM_J_TRANSLATIONAL)
-      return fail("joint type not supported by the HIP path yet");
+    if (jt != TSIM_J_REVOLUTE && jt != TSIM_J_PRISMATIC && jt != TSIM_J_PLANAR && jt != TSIM_J_TRANSLATIONAL && jt != TSIM_J_SPHERICAL_EXP)
+      return fail("joint type not supported by the HIP path");
+    if (jt == TSIM_J_SPHERICAL_EXP && ++n_exp > 1) return fail("at most one rotation-vector joint per model on the HIP path");
   }
   for (int s = 0; s < I[TSIM_IH_NSENSOR]; ++s)
     if (I[I[TSIM_IH_OFF_SENSOR] + s * TSIM_SI_SIZE + TSIM_SI_NSPRIM] > 16) return fail("too many primitives per sensor");
@@ -516,11 +542,11 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
   if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   b->t_cur = 0; b->record = 0;
-  b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT]; b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0;
+  b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT]; b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, b->I.size() * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess) {
+      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * b->esz) != hipSuccess) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
   }
@@ -535,7 +561,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->order);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->order); (void)hipFree(b->prev);
   delete b;
 }
 
@@ -582,7 +608,7 @@ int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(b->lamq, 0, (size_t)b->B * b->nr * b->esz, st));
   HIPCHK(hipMemsetAsync(b->lamv, 0, (size_t)b->B * b->nr * b->esz, st));
-  b->t_cur = 0; b->record = backward_flag ? 1 : 0; b->order_valid = 0;
+  b->t_cur = 0; b->record = backward_flag ? 1 : 0; b->order_valid = 0; b->has_prev = 0;
   return 0;
 }
 
@@ -595,6 +621,7 @@ int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd
                                 : launch_forward<double>(b, u, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
   if (rc) return rc;
   if (b->record) b->t_cur += num_steps;
+  b->has_prev = 1;
   return 0;
 }
 
@@ -623,6 +650,7 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
 
 int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream) {
   if (!b->record) return fail("backward_steps: reset(backward_flag=True) was not called");
+  if (b->I[TSIM_IH_INTEGRATOR] != 1) return fail("backward_steps: the adjoint is implemented for BDF1 models only (the reference's BDF2 model, tactile_pad.xml, is forward-only)");
   if (n <= 0 || n > b->t_cur) return fail("backward_steps: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
   if (!df_du && b->nu > 0) return fail("backward_steps: df_du is null");
   if (seed_mode != 0 && seed_mode != 1) return fail("backward_steps: bad seed_mode");
@@ -659,7 +687,7 @@ int tsim_cache_pop(tsim_batch* b, void* stream) {
   HIPCHK(hipMemcpyAsync(b->tape, e.buf, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   HIPCHK(hipFree(e.buf));
-  b->t_cur = e.len; b->record = e.record;
+  b->t_cur = e.len; b->record = e.record; b->has_prev = 0;
   HIPCHK(hipMemsetAsync(b->lamq, 0, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream));
   HIPCHK(hipMemsetAsync(b->lamv, 0, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream));
   return 0;

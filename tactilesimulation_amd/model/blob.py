@@ -37,7 +37,7 @@ globals().update(C)
 JOINT_TYPES = {
     "revolute": C["TSIM_J_REVOLUTE"], "prismatic": C["TSIM_J_PRISMATIC"], "planar": C["TSIM_J_PLANAR"],
     "translational": C["TSIM_J_TRANSLATIONAL"], "free3d-euler": C["TSIM_J_FREE3D_EULER"],
-    "free3d-exp": C["TSIM_J_FREE3D_EXP"],
+    "free3d-exp": C["TSIM_J_FREE3D_EXP"], "spherical-exp": C["TSIM_J_SPHERICAL_EXP"],
 }
 JOINT_NDOF = {"fixed": 0, "revolute": 1, "prismatic": 1, "planar": 2, "translational": 3,
               "free3d-euler": 6, "free3d-exp": 6}

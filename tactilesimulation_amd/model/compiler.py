@@ -381,6 +381,16 @@ def compile_spec(spec):
                 dof0 += n_
             link_of_joint[j] = plink
             T_link_joint[j] = Pose()
+        elif J["type"] == "free3d-exp":
+            # translation (parent frame) followed by a rotation-vector (exponential-coordinate) spherical joint,
+            # q = (x, y, z, theta) as examples/RollingBallExp/test_sim_speed.py:54 describes; massless link in between
+            for jt_, n_, E_ in (("translational", 3, T_pl), ("spherical-exp", 3, Pose())):
+                links.append(dict(jdesc, parent=plink, joint=j, E_pj0=E_, dof0=dof0, ndof=n_, mp=MassProps(),
+                                  jtype=jt_, axes=[]))
+                plink = len(links) - 1
+                dof0 += n_
+            link_of_joint[j] = plink
+            T_link_joint[j] = Pose()
         else:
             link_of_joint[j] = len(links)
             T_link_joint[j] = Pose()

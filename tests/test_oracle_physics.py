@@ -181,3 +181,47 @@ def test_pusher_static_sag_and_contact(pusher_model):
     o.forward(np.zeros(6), 400)
     q, _ = o.state()
     assert abs(q[5] + 0.075 * 9.8 / 4e3) < 1e-7
+
+
+def _rolling_ball_actions():
+    """examples/RollingBallExp/test_sim_speed.py:43-48"""
+    acts = [[0, 0, .2]] * 100 + [[.1, 0, .2]] * 50 + [[-.2, 0, .2]] * 50 + [[0, .1, .2]] * 50 + [[0, -.2, .2]] * 100
+    return np.asarray(acts, dtype=np.float64)
+
+
+def test_rolling_ball_kinematic_known_answer():
+    """RollingBall (tactile_pad.xml: BDF2, free3d-exp sphere between ground and pad): a ball rolling without slipping
+    between a fixed plane and a moving plate travels HALF the plate's displacement and turns by x / r."""
+    m = load_model(os.path.join(HERE, "golden", "models", "tactile_pad.npz"))
+    assert (m.ndof_r, m.ndof_u, m.ndof_tactile) == (9, 3, 120000)         # test_sim_speed.py:53-54, 200 x 200 taxels
+    o = OracleSim(m)
+    o.reset(np.zeros(9))
+    A = _rolling_ball_actions()
+    for i in range(150):
+        assert o.forward(A[i], 1) == 0
+    q, _ = o.state()
+    assert abs(q[3] - 0.5 * q[0]) < 0.03 * abs(q[0]) and abs(q[7] - q[3] / 0.02) < 0.02 * abs(q[7])
+    _, tac = o.outputs()
+    nz = np.count_nonzero(tac) // 3
+    assert 1000 < nz < 4000 and tac[2::3].min() < -5e-4 and tac[2::3].max() <= 0.0      # normal negative under compression
+
+
+def test_exponential_joint_newton_matrix_is_exact():
+    m = load_model(os.path.join(HERE, "golden", "models", "tactile_pad.npz"))
+    o = OracleSim(m)
+    o.reset(np.zeros(9))
+    A = _rolling_ball_actions()
+    for i in range(230):
+        o.forward(A[i], 1)
+    q, qd = o.state()
+    assert np.linalg.norm(q[6:9]) > 0.5            # a genuinely 3-D rotation vector
+    q1 = q + m.h * qd
+    g, H = o.residual(q1, q, qd, A[230], which=0)
+    Hfd = np.zeros_like(H)
+    for k in range(9):
+        d = np.zeros(9); d[k] = 1e-7
+        Hfd[:, k] = (o.residual(q1 + d, q, qd, A[230]) - o.residual(q1 - d, q, qd, A[230])) / 2e-7
+    # ~1900 pad points are in stick/slip contact with the ball: a central difference straddles friction kinks in the
+    # translational columns, so those are compared loosely; the rotation-vector columns (the new joint) must be exact
+    assert np.abs(H[:, 6:9] - Hfd[:, 6:9]).max() < 1e-6 * np.abs(H).max()
+    assert np.abs(H - Hfd).max() < 2e-2 * np.abs(H).max()
