@@ -16,7 +16,7 @@
 // lanes k < nr, the tangents w.r.t. dof k (seeds: q_k += eps*sq, qd_k += eps*sv, qdd_k += eps*sa).
 // The parent's state is carried in registers when the parent is the previous link of the sweep (chains) or the world,
 // so the common case has no LDS round trip and no barrier inside the sweep.
-template <class R, bool TANGENT>
+template <class R, bool TANGENT, bool EXPJ>
 __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   const int k = lane, nd = c.nd;
   const bool act = TANGENT && lane < c.nr;
@@ -43,7 +43,7 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
     S6<R> VJ = zero6<R>(), AJ = zero6<R>();
     S6<R> Wj[3];                                     // twist columns of this joint (<= 3 dofs on the HIP path)
     // rotation-vector joint only: Bvec = (b; p x b), b = R0 (d/dt J_l) thdot, and what lane k needs for its tangents
-    const bool is_exp = jt == TSIM_J_SPHERICAL_EXP;
+    const bool is_exp = EXPJ && jt == TSIM_J_SPHERICAL_EXP;      // EXPJ = false compiles the whole branch away
     S6<R> Bvec = zero6<R>(), dWexp[3], dBexp = zero6<R>();
     dWexp[0] = dWexp[1] = dWexp[2] = zero6<R>();
     if (is_exp) {
@@ -379,7 +379,7 @@ __device__ void phase2(const Ctx<R>& c, int lane, R sq) {
 // lanes = directions.  Leaf -> root: tau_j = W_j . F_subtree(link(j)); fold each link's wrench into its
 // parent; then the joint-space forces.  Result: g (value, LDS) and H[j][k] = d g_j / d dir_k (lane k owns
 // column k).  Both are scaled by h^2.
-template <class R>
+template <class R, bool EXPJ>
 __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   const int nd = c.nd, k = lane, nr = c.nr;
   const bool act = lane < nr;
@@ -401,7 +401,7 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
         const S6<R> Wj = ld6(c.WP + j * 6);
         R dtau = dot6(Wj, dF);
         if (moves) {
-          const bool same_exp = li[TSIM_LI_JTYPE] == TSIM_J_SPHERICAL_EXP && k >= k0 && k < k0 + ndj;
+          const bool same_exp = EXPJ && li[TSIM_LI_JTYPE] == TSIM_J_SPHERICAL_EXP && k >= k0 && k < k0 + ndj;
           const S6<R> dW = same_exp ? ld6(c.expw + ((j - k0) * 3 + (k - k0)) * 6) : crm(Wk, Wj);
           dtau += sq * dot6(dW, F);
         }
@@ -464,7 +464,7 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
 // 4/3 q0 - 1/3 q_1 + 8/9 h qd0 - 2/9 h qd_1), not q1 itself: qd1 = qdp + cv dl, qdd1 = ca dl keep full relative
 // precision in fp32 (no q1 - q0 cancellation).  forward seeds: (1, cv, ca) -> H = dg/dq1 ;  adjoint seeds (1, 0, 0)
 // -> H = (1/ca) dr/dq  (BDF1: h^2 dr/dq).
-template <class R, int NRM>
+template <class R, int NRM, bool EXPJ>
 __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   if (lane < c.nr) {
     const R d = c.dl[lane];
@@ -474,11 +474,11 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   }
   __syncthreads();
   TS_STAMP(c);
-  phase1<R, true>(c, lane, sq, sv, sa);
+  phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
   TS_STAMP(c);
   phase2<R, NRM>(c, lane, sq);
   TS_STAMP(c);
-  phase3(c, lane, sq, sv);
+  phase3<R, EXPJ>(c, lane, sq, sv);
   TS_STAMP(c);
 }
 

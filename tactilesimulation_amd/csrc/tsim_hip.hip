@@ -84,7 +84,7 @@ template <class R> struct FwdArgs {
   R* prev; int has_prev;  // state before the previous sub-step [B][2 nr] (BDF2 history across launches)
 };
 
-template <class R, int NRM>
+template <class R, int NRM, bool EXPJ>
 __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     int iter = 0, ls = -1;                     // ls < 0: the evaluation is the first one of the sub-step
     bool conv = false;
     while (true) {
-      evaluate<R, NRM>(c, lane, sq, sv, sa); ++evals;
+      evaluate<R, NRM, EXPJ>(c, lane, sq, sv, sa); ++evals;
       const R gnew = block_norm2(c.g, nr, lane);
       if (ls >= 0) {                           // this was a line-search trial
         if (!(gnew < gn)) {
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
   if (lane < nr) { c.q[lane] = st[lane]; c.qd[lane] = st[nr + lane]; c.qa[lane] = R(0); }
   __syncthreads();
-  phase1<R, false>(c, lane, R(0), R(0), R(0));
+  phase1<R, false, true>(c, lane, R(0), R(0), R(0));
   readout(c, lane, env, a.var_out, a.tac_out);
 }
 
@@ -240,14 +240,14 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   __syncthreads();
   if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve
     c.stamps = a.cyc + (size_t)env * 32;
-    evaluate<R, 8>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    evaluate<R, 8, false>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
     if (lane < nr) c.rhs[lane] = -c.g[lane];
     __syncthreads();
     solve_lanes<R, 8>(c.H, c.rhs, c.dq, nr, false, lane);
     TS_STAMP(c);
     if (lane == 0) for (int i = c.nstamp; i < 32; ++i) c.stamps[i] = 0;
   } else {
-    evaluate<R, 16>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    evaluate<R, 16, true>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
   }
   if (lane < nr) a.g[(size_t)env * nr + lane] = c.g[lane];
   for (int e = lane; e < nr * nr; e += TS_WAVE) a.H[(size_t)env * nr * nr + e] = c.H[e];
@@ -371,7 +371,7 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
   __syncthreads();
 }
 
-template <class R, int NRM>
+template <class R, int NRM, bool EXPJ>
 __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
     if (lane < nu) c.u[lane] = r1[2 * nr + nr * nr + lane];
     for (int e = lane; e < nr * nr; e += TS_WAVE) H2[e] = r1[2 * nr + e];
     __syncthreads();
-    phase1<R, true>(c, lane, R(1), R(0), R(0));
+    phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
     // direct partials of the loss w.r.t. this sub-step's outputs
     const bool seeded = a.seed_mode == 1 || j == a.n - 1;
     if (seeded) {
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
     __syncthreads();
     solve_lanes<R, NRM>(H2, c.rhs, c.z, nr, true, lane);
     phase2<R, NRM>(c, lane, R(1));
-    phase3(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
+    phase3<R, EXPJ>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
     if (lane < nr) {
       R yq = R(0);
       for (int i = 0; i < nr; ++i) yq += c.z[i] * c.H[i * nr + lane];
@@ -446,6 +446,7 @@ struct tsim_batch {
   int* evals;                    // residual evaluations of the last forward launch, per env
   int* order; int order_valid;   // block -> env map for the next forward launch (LPT scheduling)
   void* prev; int has_prev;      // BDF2: state before the previous sub-step [B][2 nr]
+  int has_exp;                   // model contains a rotation-vector joint
   int t_cur, record;
   size_t lds_bytes, esz;
   std::vector<CacheEntry> cache;
@@ -487,8 +488,11 @@ static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, v
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256) ? b->order : nullptr;
   a.prev = (R*)b->prev; a.has_prev = b->has_prev;
-  if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
-  else hipLaunchKernelGGL((k_forward<R, 16>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
+  // compiled out otherwise: it costs registers in every evaluation)
+  if (b->has_exp) hipLaunchKernelGGL((k_forward<R, 16, true>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  else if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  else hipLaunchKernelGGL((k_forward<R, 16, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   HIPCHK(hipGetLastError());
   if (b->B >= 256) {
     hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B);
@@ -504,8 +508,9 @@ static int launch_backward(tsim_batch* b, int n, int seed_mode, const void* df_d
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_mode = seed_mode;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du;
-  if (b->nr <= 8) hipLaunchKernelGGL((k_backward<R, 8>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
-  else hipLaunchKernelGGL((k_backward<R, 16>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  if (b->has_exp) hipLaunchKernelGGL((k_backward<R, 16, true>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  else if (b->nr <= 8) hipLaunchKernelGGL((k_backward<R, 8, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  else hipLaunchKernelGGL((k_backward<R, 16, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -541,7 +546,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   int reals = ts_lds_reals(nl, nr, nu, I[TSIM_IH_NI], I[TSIM_IH_FOFF_CPT], (int)b->esz);
   b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
   if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
-  b->t_cur = 0; b->record = 0;
+  b->t_cur = 0; b->record = 0; b->has_exp = n_exp > 0;
   b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT]; b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, b->I.size() * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
