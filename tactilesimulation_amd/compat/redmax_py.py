@@ -124,13 +124,16 @@ class Simulation:
     def forward(self, num_steps, verbose=False, test_derivatives=False, save_last_frame_var_only=False):
         if test_derivatives:
             raise NotImplementedError("test_derivatives: use tests/test_gpu_parity.py (adjoint vs oracle / finite differences)")
-        out = self._sim.step(self._t(self._u, self.ndof_u, "u"), int(num_steps), want_qd=True)
+        # high-resolution sensors (RollingBall: 120 000 values) are read out on demand by the sliced read-out kernel
+        # instead of after every step (test_sim_speed.py:79 asks for them every 5th step only)
+        lazy = self.ndof_tactile > 4096
+        out = self._sim.step(self._t(self._u, self.ndof_u, "u"), int(num_steps), want_qd=True, want_tactile=not lazy)
         st = int(out["status"].item())
         if st & (1 << 30):
             raise RuntimeError("simulation produced non-finite values")
         self._q, self._qdot = self._np(out["q"]), self._np(out["qd"])
         self._var = self._np(out["var"]) if "var" in out else np.zeros(0)
-        self._tac = self._np(out["tactile"]) if "tactile" in out else np.zeros(0)
+        self._tac = self._np(out["tactile"]) if "tactile" in out else (None if lazy else np.zeros(0))
         self._dirty_outputs = False
         self.last_nonconverged_substeps = st
 
@@ -148,6 +151,9 @@ class Simulation:
 
     def get_tactile_force_vector(self):
         self._refresh()
+        if self._tac is None:
+            _, tac = self._sim.readout(want_var=False)
+            self._tac = self._np(tac)
         return self._tac
 
     def get_tactile_image_pos(self, name):

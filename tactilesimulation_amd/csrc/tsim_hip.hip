@@ -28,7 +28,7 @@ __host__ __device__ inline int ts_rec(int nr, int nu) { return 2 * nr + nr * nr 
 // variables: lanes = end-effector points; tactile: lanes = taxels (coalesced SoA loads of position / frame,
 // 12 B per lane contiguous stores).  Each taxel is evaluated in the frame of the primitive it is tested against.
 template <class R>
-__device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_out) {
+__device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
   if (var_out) {
     for (int e = lane; e < c.nvar; e += TS_WAVE) {
       const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
@@ -47,9 +47,11 @@ __device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_o
       __syncthreads();
       for (int j = j0; j < je; ++j) pair_stage_value(c, c.I[c.off_sprim + sp0 + j], j - j0, lane);
       __syncthreads();
-      for (int base = 0; base < nt; base += TS_WAVE) {
+      // this block's slice [tb, te) of the global taxel range, intersected with the sensor
+      const int lo = max(tb, t0) - t0, hi = min(te, t0 + nt) - t0;
+      for (int base = lo; base < hi; base += TS_WAVE) {
         const int t = t0 + base + lane;
-        if (base + lane >= nt) continue;
+        if (base + lane >= hi) continue;
         const R* tp = c.Fg + c.foff_tax + t;
         const V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
         V3<R> Fl = zero3<R>();                          // force on the taxel, sensor-link frame
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* 
 }
 
 // ================================================================================================ read-out kernel
-template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R *var_out, *tac_out; };
+template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R *var_out, *tac_out; int slice; };
 
 template <class R>
 __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
@@ -217,7 +219,9 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   if (lane < nr) { c.q[lane] = st[lane]; c.qd[lane] = st[nr + lane]; c.qa[lane] = R(0); }
   __syncthreads();
   phase1<R, false, true>(c, lane, R(0), R(0), R(0));
-  readout(c, lane, env, a.var_out, a.tac_out);
+  // high-resolution sensors (RollingBall: 40 000 taxels): blockIdx.y selects a slice of the taxels, so one
+  // environment's read-out spreads over many CUs; 12 B/lane contiguous stores, SoA coalesced loads
+  readout(c, lane, env, blockIdx.y == 0 ? a.var_out : nullptr, a.tac_out, (int)blockIdx.y * a.slice, ((int)blockIdx.y + 1) * a.slice);
 }
 
 // ================================================================================================ debug evaluation
@@ -642,12 +646,15 @@ int tsim_get_state(tsim_batch* b, void* q_out, void* qd_out, void* stream) {
 
 int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   HIPCHK(hipSetDevice(b->device));
+  const int slice = 1024;                                   // taxels per block
+  const int ny = tac_out ? (b->ntax + slice - 1) / slice : 1;
+  dim3 grid(b->B, ny > 0 ? ny : 1);
   if (b->dtype == TSIM_F32) {
-    ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out};
-    hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
+    ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out, slice};
+    hipLaunchKernelGGL(k_readout<float>, grid, dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   } else {
-    ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out};
-    hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
+    ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out, slice};
+    hipLaunchKernelGGL(k_readout<double>, grid, dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());
   return 0;
