@@ -98,6 +98,10 @@ template <class T> __device__ __forceinline__ S6<T> crm(S6<T> v, S6<T> m) { retu
 template <class T> __device__ __forceinline__ S6<T> crf(S6<T> v, S6<T> f) { return mk6<T>(cross3(v.a, f.a) + cross3(v.l, f.l), cross3(v.a, f.l)); }   // v x* f
 template <class T> __device__ __forceinline__ S6<T> ld6(const T* p) { return mk6<T>(ldv(p), ldv(p + 3)); }
 template <class T> __device__ __forceinline__ void st6(T* p, S6<T> v) { stv(p, v.a); stv(p + 3, v.l); }
+// p[0..6) += s * v   (read-modify-write of a 6-vector in LDS)
+template <class T> __device__ __forceinline__ void acc6(T* p, S6<T> v, T s) {
+  p[0] += s * v.a.x; p[1] += s * v.a.y; p[2] += s * v.a.z; p[3] += s * v.l.x; p[4] += s * v.l.y; p[5] += s * v.l.z;
+}
 // spatial inertia (mass, world COM c, world rotational inertia about the COM) times a motion vector
 template <class T> __device__ __forceinline__ S6<T> imul(T mass, V3<T> c, const T* Ic, S6<T> m) {
   V3<T> f = (m.l + cross3(m.a, c)) * mass;

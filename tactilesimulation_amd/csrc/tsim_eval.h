@@ -330,26 +330,12 @@ __device__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
   const R inB = ((anc_of(c.I, c.off_link, lb) >> k) & 1) ? R(1) : R(0);
   const S6<R> dWw = wrench_to_world(RP, pP, ld6(T + PT_WN)) + crf(ld6(c.WP + k * 6) * (sq * inB), Ww);
   if (la > 0) {         // link 0 (world-fixed general bodies) takes no wrench
-    R* Da = c.DT + (la * nd + k) * DT_SIZE + DT_FN;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) { Da[e] -= (&dWw.a.x)[e]; Da[3 + e] -= (&dWw.l.x)[e]; }
+    acc6(c.DT + (la * nd + k) * DT_SIZE + DT_FN, dWw, R(-1));
   }
-  if (lb > 0) {
-    R* Db = c.DT + (lb * nd + k) * DT_SIZE + DT_FN;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) { Db[e] += (&dWw.a.x)[e]; Db[3 + e] += (&dWw.l.x)[e]; }
-  }
+  if (lb > 0) acc6(c.DT + (lb * nd + k) * DT_SIZE + DT_FN, dWw, R(1));
   if (k == 0) {
-    if (la > 0) {
-      R* Fa = c.LP + la * LK_SIZE + LK_FN;
-#pragma unroll
-      for (int e = 0; e < 3; ++e) { Fa[e] -= (&Ww.a.x)[e]; Fa[3 + e] -= (&Ww.l.x)[e]; }
-    }
-    if (lb > 0) {
-      R* Fb = c.LP + lb * LK_SIZE + LK_FN;
-#pragma unroll
-      for (int e = 0; e < 3; ++e) { Fb[e] += (&Ww.a.x)[e]; Fb[3 + e] += (&Ww.l.x)[e]; }
-    }
+    if (la > 0) acc6(c.LP + la * LK_SIZE + LK_FN, Ww, R(-1));
+    if (lb > 0) acc6(c.LP + lb * LK_SIZE + LK_FN, Ww, R(1));
   }
 }
 
@@ -414,16 +400,8 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
       if (par == i - 1) { cF = F; cdF = dF; carry_to = par; }
       else {
         via_lds = true;
-        if (act) {
-          R* pt = c.DT + (par * nd + k) * DT_SIZE + DT_FN;
-#pragma unroll
-          for (int e = 0; e < 3; ++e) { pt[e] += (&dF.a.x)[e]; pt[3 + e] += (&dF.l.x)[e]; }
-        }
-        if (lane == 0) {
-          R* pp = c.LP + par * LK_SIZE + LK_FN;
-#pragma unroll
-          for (int e = 0; e < 3; ++e) { pp[e] += (&F.a.x)[e]; pp[3 + e] += (&F.l.x)[e]; }
-        }
+        if (act) acc6(c.DT + (par * nd + k) * DT_SIZE + DT_FN, dF, R(1));
+        if (lane == 0) acc6(c.LP + par * LK_SIZE + LK_FN, F, R(1));
       }
     }
     if (via_lds) __syncthreads();

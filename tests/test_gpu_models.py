@@ -31,6 +31,8 @@ CASES = {
     # 2 pads x 13x10 taxels, prismatic fingers with limits, free3d-euler box (3 translations + 3 revolutes after the
     # compiler's decomposition), 11 contact pairs incl. world-fixed general bodies (tactile_insertion.xml)
     "tactile_insertion": (None, None, 14, 5),
+    # rotation-vector joint under BDF1, forward AND adjoint (the reference's only free3d-exp model is forward-only)
+    "ball_push": (np.array([0, 0, 0, 0, 0, 0, 0.3, -0.2, 0.5]), None, 12, 3),
 }
 
 
@@ -48,6 +50,10 @@ def _inputs(name, m, B_, T):
         for t in range(T):
             cur = cur + np.clip(goal - cur, -0.02, 0.02) + 0.005 * rng.uniform(-1, 1, size=(B_, 9))
             u[:, t] = cur
+        return q0, u
+    if name == "ball_push":
+        q0 = np.tile(q0c, (B_, 1)) + 0.02 * rng.normal(size=(B_, 9)) * np.array([0, 0, 0, 0.05, 0.05, 0, 1, 1, 1])
+        u = np.stack([[[0.3 * np.sin(t + e), 0.25 * np.cos(t - e), -0.4 + 0.05 * rng.uniform(-1, 1)] for t in range(T)] for e in range(B_)])
         return q0, u
     if name == "tactile_insertion":
         # grasp as in envs/tactile_insertion_env.py:126-170 (height 0.2, fingers open at -0.03, closing force ramp),
