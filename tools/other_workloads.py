@@ -1,0 +1,41 @@
+"""Forward-only throughput of the non-headline BASELINE.json configs on ONE GPU (per-GPU share of the 8-GPU batch):
+DClaw (configs[3]: 16 384 envs / 8 = 2 048 per GPU, frame_skip 5) and TactileInsertion (configs[4]: 32 768 / 8 = 4 096 per
+GPU, 45 single sub-steps per episode). Synthetic inputs as in tests/test_gpu_models.py. Not the bench.py headline."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from tactilesimulation_amd.model.compiler import load_model  # noqa: E402
+from tactilesimulation_amd.host.batch import BatchSim  # noqa: E402
+from tests.test_gpu_models import _inputs  # noqa: E402
+
+
+def run(name, B, T, S, dtype=torch.float32, reps=3):
+    m = load_model(os.path.join(ROOT, "tests", "golden", "models", name + ".npz"))
+    q0, u = _inputs(name, m, 64, T)
+    q0 = np.tile(q0, (B // 64, 1)); u = np.tile(u, (B // 64, 1, 1))
+    sim = BatchSim(m, B, dtype=dtype, tape_capacity=0)
+    q0d = torch.tensor(q0, device="cuda", dtype=dtype); ud = torch.tensor(u, device="cuda", dtype=dtype).transpose(0, 1).contiguous()
+    out = {}
+    best = None
+    for r in range(reps):
+        sim.reset(q0d, None, False)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for t in range(T):
+            sim.step(ud[t], S, out=out)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"model": name, "B": B, "env_steps": T, "substeps_per_env_step": S, "dtype": str(dtype),
+            "env_steps_per_s": B * T / best, "substeps_per_s": B * T * S / best, "nonconverged_last": int((out["status"] != 0).sum())}
+
+
+if __name__ == "__main__":
+    res = [run("dclaw_position_control", 2048, 10, 5), run("tactile_insertion", 4096, 14, 5),
+           run("dclaw_position_control", 2048, 10, 5, torch.float64), run("tactile_insertion", 4096, 14, 5, torch.float64)]
+    print(json.dumps(res))
