@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--episode", type=int, default=100, help="env-steps per episode (tape length / frame_skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] style run (not the headline)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI, the real multi-GPU path) or gloo (plumbing test: with TSIM_BENCH_SHARE_GPU=1 "
+                         "all ranks share cuda:0 and the collectives go through host copies)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -56,8 +59,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("TSIM_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
@@ -113,7 +121,10 @@ def main():
                 grad_buf[:6] = du[0].sum(0).float()[:6] if nu >= 6 else 0.0
             if world > 1:
                 import torch.distributed as dist
-                dist.all_reduce(grad_buf)           # GD outer loop: policy-gradient all-reduce over xGMI (RCCL)
+                if args.backend == "nccl":
+                    dist.all_reduce(grad_buf)       # GD outer loop: policy-gradient all-reduce over xGMI (RCCL)
+                else:
+                    g = grad_buf.cpu(); dist.all_reduce(g); grad_buf.copy_(g)
             done += n
         return bad
 
@@ -132,7 +143,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -162,7 +173,7 @@ def main():
             except Exception:
                 pass
         res = {
-            "metric": "env-steps/sec (fwd+bwd) TactilePush batch=4096" if not args.forward_only else "env-steps/sec (fwd only) TactilePush",
+            "metric": ("env-steps/sec (fwd+bwd) TactilePush batch=%d" % B) if not args.forward_only else ("env-steps/sec (fwd only) TactilePush batch=%d" % B),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
