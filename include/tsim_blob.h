@@ -36,6 +36,13 @@ enum {
   TSIM_IH_SIZE = 40
 };
 
+/* Newton globalisation constants shared by the kernels and the oracle: backtracking halves the step at
+ * most min(max_ls, TSIM_LS_SHORT) times; if no trial reduces ||g||, the full Newton step is taken anyway (non-monotone
+ * step across a contact / friction kink), at most TSIM_KICK_MAX times per sub-step; a sub-step that needs more is restarted
+ * from the predictor with monotone backtracking down to 2^-max_ls. */
+#define TSIM_LS_SHORT 4
+#define TSIM_KICK_MAX 6
+
 /* ---- float header (F[0..TSIM_FH_SIZE)) ---- */
 enum { TSIM_FH_H = 0, TSIM_FH_GX, TSIM_FH_GY, TSIM_FH_GZ, TSIM_FH_TOL, TSIM_FH_SIZE = 8 };
 

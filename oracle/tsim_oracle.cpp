@@ -463,21 +463,36 @@ static int substep(Sim& S, const double* u) {
   const bool bdf2 = m.integrator == 2 && S.has_prev;
   StepCoef c; make_coef(m, q0, qd0, bdf2 ? S.qm1.data() : nullptr, bdf2 ? S.qdm1.data() : nullptr, c);
   for (int k = 0; k < nr; ++k) q1[k] = c.qpred[k];
-  int it = 0; bool ok = false;
+  int it = 0, kicks = 0; bool ok = false, deep = false;
+  static const bool trace = getenv("TSIM_ORACLE_TRACE") != nullptr;
   for (; it <= m.max_iter; ++it) {
     eval_g_jac_c(m, q1, c, u, 0, g, H);
     double gnorm = norm2(nr, g);
+    if (trace) fprintf(stderr, "  it %d gn %.3e kicks %d deep %d\n", it, gnorm, kicks, (int)deep);
     if (gnorm < m.tol) { ok = true; break; }
     if (it == m.max_iter) break;
     for (int k = 0; k < nr; ++k) g[k] = -g[k];
     if (!solve_dense(nr, H, g, dq, false)) break;
-    double alpha = 1.0;
-    for (int ls = 0; ls <= m.max_ls; ++ls) {
+    // Globalisation: backtracking on ||g||. ||g|| has non-smooth local minima next to contact / friction
+    // kinks where no short step along the Newton direction reduces it; there the full Newton step is taken anyway (it
+    // lands across the kink, from where the iteration normally converges in two or three steps).  A sub-step that needs
+    // more than TSIM_KICK_MAX such steps (a cycle) is restarted from the predictor with plain monotone backtracking
+    // down to 2^-max_ls, which stops at the last accepted iterate when even that finds no decrease.
+    double alpha = 1.0; bool accepted = false, kick = false, restart = false;
+    for (int ls = 0;; ++ls) {
       for (int k = 0; k < nr; ++k) qn[k] = q1[k] + alpha * dq[k];
       eval_g_c(m, qn, c, u, gn);
-      if (norm2(nr, gn) < gnorm || ls == m.max_ls) break;
+      if (norm2(nr, gn) < gnorm) { accepted = true; if (trace) fprintf(stderr, "    accept alpha %.3g\n", alpha); break; }
+      if (!deep && ls >= std::min(m.max_ls, TSIM_LS_SHORT)) {
+        if (kicks < TSIM_KICK_MAX) { ++kicks; kick = true; } else { deep = true; restart = true; }
+        break;
+      }
+      if (ls >= m.max_ls) break;
       alpha *= 0.5;
     }
+    if (restart) { for (int k = 0; k < nr; ++k) q1[k] = c.qpred[k]; it = -1; continue; }
+    if (kick) { for (int k = 0; k < nr; ++k) qn[k] = q1[k] + dq[k]; }
+    else if (!accepted) { ok = gnorm < 100.0 * m.tol; break; }   // stays at the last accepted iterate
     for (int k = 0; k < nr; ++k) q1[k] = qn[k];
   }
   double qd1[MAXR];

@@ -129,27 +129,42 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     __syncthreads();
     // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
     // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).
+    // Globalisation: backtracking on ||g||.  ||g|| has non-smooth local minima next to contact /
+    // friction kinks where no short step along the Newton direction reduces it; there the full Newton step is taken
+    // anyway (it lands across the kink, from where the iteration normally converges in two or three steps).  A
+    // sub-step that needs more than TSIM_KICK_MAX such steps (a cycle) is restarted from the predictor with plain
+    // monotone backtracking down to 2^-max_ls, which returns to the last accepted iterate when even that finds no
+    // decrease.
     R gn = R(0), alpha = R(1);
-    int iter = 0, ls = -1;                     // ls < 0: the evaluation is the first one of the sub-step
-    bool conv = false;
+    int iter = 0, ls = -1, kicks = 0;          // ls < 0: the evaluation just done is not a line-search trial
+    bool conv = false, forced = false, giving_up = false, deep = false;
     while (true) {
       evaluate<R, NRM, EXPJ>(c, lane, sq, sv, sa); ++evals;
       const R gnew = block_norm2(c.g, nr, lane);
-      if (ls >= 0) {                           // this was a line-search trial
+      if (giving_up) { gn = gnew; conv = gn < R(100) * c.tol; break; }       // back at the last accepted iterate
+      if (ls >= 0 && !forced) {                // this was a line-search trial
         if (!(gnew < gn)) {
-          if (ls == c.max_ls) {
-            // No step length down to 2^-max_ls reduces ||g||: the iterate sits on the round-off floor of the residual
-            // (or on a kink). Repeating the same failed search max_iter times cannot move it by more than
-            // 2^-max_ls |dq| per pass, so stop; it counts as converged when it is within two decades of tol.
-            conv = gnew < R(100) * c.tol; break;
+          if (!deep && ls >= min(c.max_ls, TSIM_LS_SHORT)) {
+            if (kicks < TSIM_KICK_MAX) {
+              ++kicks; forced = true;
+              if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+            } else {                           // restart the sub-step, monotone from here on
+              deep = true; iter = 0; ls = -1;
+              if (lane < nr) c.dl[lane] = R(0);
+            }
+          } else if (ls >= c.max_ls) {
+            giving_up = true;
+            if (lane < nr) c.dl[lane] = dlbase[lane];
+          } else {
+            alpha *= R(0.5); ++ls;
+            if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
           }
-          alpha *= R(0.5); ++ls;
-          if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
           __syncthreads();
           continue;
         }
-        ++iter;
       }
+      if (ls >= 0) ++iter;
+      forced = false;
       gn = gnew;
       if (!(gn == gn)) { nonfinite = true; break; }
       if (gn < c.tol) { conv = true; break; }
