@@ -5,7 +5,11 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N > 1: l
 A "step" = one env-step (5 implicit BDF1 sub-steps, tactile read-out) forward AND its adjoint for one batch of
 B = 4096 TactilePush environments per GPU (BASELINE.json configs[2]: gd_tactile fwd+adjoint, batch 4096).  The K steps
 are run as episodes of <= 100 env-steps (forward all, then backward all — the order autograd imposes in
-algorithms/gd.py:239-259).  Inputs are resident in HBM before the timed region.  Environments shard across ranks with
+algorithms/gd.py:239-259).  Default launch granularity: one launch per episode each way (tsim_rollout /
+tsim_backward_episode — the open-loop episode of EpisodicSimFunction, envs/redmax_torch_functions.py:46-57,77-92, with the
+synthetic actions resident in HBM); `--launch step` times one launch per env-step (StepSimFunction granularity) and
+its rate is reported in the same JSON line either way (`launch.other_mode_value`).  Every frame's q / variables /
+tactile outputs are written in both modes.  Inputs are resident in HBM before the timed region.  Environments shard across ranks with
 no data-path exchange (weak scaling); the only collective is the GD outer loop's policy-gradient all-reduce
 (29 574 fp32 = 118 296 B), issued once per episode.
 
@@ -47,6 +51,12 @@ def main():
     ap.add_argument("--episode", type=int, default=100, help="env-steps per episode (tape length / frame_skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] style run (not the headline)")
+    ap.add_argument("--launch", default="episode", choices=["episode", "step"],
+                    help="episode: tsim_rollout + tsim_backward_episode, one launch each way per episode (the open-loop "
+                         "episode of EpisodicSimFunction); step: one tsim_step / tsim_backward_steps launch per env-step "
+                         "(StepSimFunction granularity, what a closed-loop policy needs)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="skip the legs after the timed region (other launch mode, evaluation statistics): profiler runs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the real multi-GPU path) or gloo (plumbing test: with TSIM_BENCH_SHARE_GPU=1 "
                          "all ranks share cuda:0 and the collectives go through host copies)")
@@ -89,36 +99,54 @@ def main():
     wq = torch.ones(B, nr, device=dev, dtype=tdt)
     wv = torch.ones(B, nvar, device=dev, dtype=tdt)
     wt = torch.ones(B, ntac, device=dev, dtype=tdt) * 100.0
+    wqT, wvT, wtT = (w.unsqueeze(0).expand(T, -1, -1).contiguous() for w in (wq, wv, wt))    # per-frame seeds [T, B, dim]
     grad_buf = torch.zeros(POLICY_GRAD_FLOATS, device=dev, dtype=torch.float32)
     out = {}
     ev = {"fwd": [], "bwd": []}
 
-    def run_steps(k_total, timed):
+    def run_steps(k_total, timed, launch):
         """k_total env-steps as episodes of <= T: forward all, backward all."""
         done = 0
         bad = 0
+        Ev = lambda: torch.cuda.Event(enable_timing=True)
         while done < k_total:
             n = min(T, k_total - done)
             sim.reset(q0, None, backward_flag=not args.forward_only)
-            for t in range(n):
+            if launch == "episode":
+                e0, e1, e2 = Ev(), Ev(), Ev()
+                e0.record()
+                ro = sim.rollout(u[:n], S)
+                e1.record()
+                status = ro["status"]
+                if not args.forward_only:
+                    du = sim.backward_episode(n, S, wqT[:n], wvT[:n], wtT[:n])
+                    e2.record()
+                    grad_buf[:6] = du.sum((0, 1)).float()[:6] if nu >= 6 else 0.0
                 if timed:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                sim.step(u[t], S, out=out)
-                if timed:
-                    e1.record()
-                    ev["fwd"].append((e0, e1))
-            bad += int((out["status"] != 0).sum().item()) if not timed else 0
-            if not args.forward_only:
-                for t in reversed(range(n)):
+                    ev["fwd"].append((e0, e1, n))
+                    if not args.forward_only:
+                        ev["bwd"].append((e1, e2, n))
+            else:
+                for t in range(n):
                     if timed:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0, e1 = Ev(), Ev()
                         e0.record()
-                    du = sim.backward_steps(S, wq, wv, wt)
+                    sim.step(u[t], S, out=out)
                     if timed:
                         e1.record()
-                        ev["bwd"].append((e0, e1))
-                grad_buf[:6] = du[0].sum(0).float()[:6] if nu >= 6 else 0.0
+                        ev["fwd"].append((e0, e1, 1))
+                status = out["status"]
+                if not args.forward_only:
+                    for t in reversed(range(n)):
+                        if timed:
+                            e0, e1 = Ev(), Ev()
+                            e0.record()
+                        du = sim.backward_steps(S, wq, wv, wt)
+                        if timed:
+                            e1.record()
+                            ev["bwd"].append((e0, e1, 1))
+                    grad_buf[:6] = du[0].sum(0).float()[:6] if nu >= 6 else 0.0
+            bad += int((status != 0).sum().item()) if not timed else 0
             if world > 1:
                 import torch.distributed as dist
                 if args.backend == "nccl":
@@ -135,10 +163,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    bad_warm = run_steps(args.warmup, False) if args.warmup > 0 else 0
+    bad_warm = run_steps(args.warmup, False, args.launch) if args.warmup > 0 else 0
     sync_all()
     t0 = time.perf_counter()
-    run_steps(args.steps, True)
+    run_steps(args.steps, True, args.launch)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -147,29 +175,57 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # kernel durations of the timed region (HIP events on the launching stream), per launch and per env-step
+    def ev_stats(lst):
+        if not lst:
+            return 0.0, 0.0, 0
+        ms = [a.elapsed_time(b) for a, b, _ in lst]
+        fr = [n for _, _, n in lst]
+        return float(np.mean(ms)), float(sum(ms) / sum(fr)), int(round(np.mean(fr)))
+    fwd_ms, fwd_ms_step, fwd_frames = ev_stats(ev["fwd"])
+    bwd_ms, bwd_ms_step, bwd_frames = ev_stats(ev["bwd"])
+
+    # second leg, reported next to the headline: the other launch granularity on the same workload (short, after the
+    # timed region)
+    other = "step" if args.launch == "episode" else "episode"
+    ev_main, ev = ev, {"fwd": [], "bwd": []}
+    k_other = min(args.steps, 40)
+    other_value = None
+    if not args.timed_only:
+        run_steps(min(k_other, 5), False, other)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(k_other, False, other)
+        torch.cuda.synchronize()
+        other_value = B * k_other / (time.perf_counter() - t1)
+    ev = ev_main
+
     # untimed: Newton work statistics (residual evaluations per env-step) of the same workload
     sim.reset(q0, None, backward_flag=False)
     evs = []
-    for t in range(min(T, 30)):
+    for t in range(min(T, 30) if not args.timed_only else 0):
         sim.step(u[t], S, out=out)
         evs.append(sim.last_evals())
-    evs = np.array(evs)
-    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]])) if ev["fwd"] else 0.0
-    bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]])) if ev["bwd"] else 0.0
+    evs = np.array(evs) if evs else np.zeros((1, 1))
+    if args.timed_only:
+        out["status"] = torch.zeros(1, dtype=torch.int32)
     status_bad = int((out["status"] != 0).sum().item())
 
     if rank == 0:
         fb, bb = algorithmic_bytes(nr, nu, nvar, ntac, S, esz)
-        dom, dom_ms, dom_bytes = ("k_forward", fwd_ms, fb) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb)
-        achieved = dom_bytes * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        dom, dom_ms, dom_bytes, dom_frames = ("k_forward", fwd_ms, fb, fwd_frames) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb, bwd_frames)
+        achieved = dom_bytes * B * dom_frames / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         value = B * world * args.steps / dt
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.dtype)
         if os.path.exists(pmc_file) and B == 4096:       # separate rocprofv3 --pmc run of this same command (tools/gpu_pmc.sh)
             try:
-                pk = [v for k, v in json.load(open(pmc_file))["per_kernel"].items() if dom in k][0]
-                traffic = (2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024.0      # gfx950: FETCH_SIZE counts 1/2 (MI355X_MICROARCH.md §HBM)
-                traffic_src = "profiles/" + os.path.basename(pmc_file) + " (2*FETCH_SIZE + WRITE_SIZE KiB, per launch)"
+                pj = json.load(open(pmc_file))
+                pk = [v for k, v in pj["per_kernel"].items() if dom in k][0]
+                # gfx950: FETCH_SIZE counts 1/2 (MI355X_MICROARCH.md §HBM); scaled from the profiled launch (pmc frames) to this one
+                traffic = (2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024.0 * dom_frames / pj.get("frames_per_launch", 1)
+                traffic_src = ("profiles/" + os.path.basename(pmc_file) + " (2*FETCH_SIZE + WRITE_SIZE KiB per launch of %d env-steps, "
+                               "scaled to %d)" % (pj.get("frames_per_launch", 1), dom_frames))
             except Exception:
                 pass
         res = {
@@ -182,10 +238,15 @@ def main():
                        "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes * B,
+                         "algorithmic_bytes_per_launch": dom_bytes * B * dom_frames, "env_steps_per_launch": dom_frames,
                          "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb},
                          "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms},
+                         "kernel_ms_per_env_step": {"k_forward": fwd_ms_step, "k_backward": bwd_ms_step},
                          "note": "state stays in LDS across sub-steps, so this path is latency/VALU-bound, not HBM-bound (SURVEY.md §0.6)"},
+            "launch": {"mode": args.launch,
+                       "episode": "tsim_rollout + tsim_backward_episode: one launch each way per episode (EpisodicSimFunction's open-loop episode)",
+                       "step": "tsim_step + tsim_backward_steps: one launch per env-step each way (StepSimFunction granularity)",
+                       "other_mode": other, "other_mode_value": other_value, "other_mode_env_steps": k_other},
             "nonconverged_envs_last_step": status_bad, "nonconverged_warmup": bad_warm,
             "lds_bytes_per_env": sim.launch_info()["lds_bytes"],
             "residual_evals_per_env_step": {"mean": float(evs.mean()), "p99": float(np.percentile(evs, 99)),

@@ -86,6 +86,24 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream);
 int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, const void* df_dvar,
                         const void* df_dtac, void* df_du, void* stream);
 
+/* The open-loop episode of EpisodicSimFunction.forward             envs/redmax_torch_functions.py:46-57
+ *   for t in range(T): sim.set_u(actions[t]); sim.forward(n); q, variables, tactile = getters
+ * as ONE launch: frame f applies u[f] for num_steps sub-steps and writes its outputs to slot f.
+ *   u [num_frames][B][ndof_u];  q_out, qd_out [num_frames][B][ndof_r], var_out [num_frames][B][ndof_var],
+ *   tac_out [num_frames][B][ndof_tactile] (any may be NULL);  status [B]: non-converged sub-steps of the whole call.
+ * Results are bit-identical to num_frames calls of tsim_step; no environment waits for the slowest one of the batch
+ * between env-steps, which is where the per-step launches lose their time. */
+int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, void* q_out, void* qd_out,
+                 void* var_out, void* tac_out, int32_t* status, void* stream);
+
+/* sim.backward() of EpisodicSimFunction.backward                  envs/redmax_torch_functions.py:77-92
+ * Adjoint of the newest num_frames * num_steps sub-steps in one launch.  Seeds are the partials w.r.t. the outputs of
+ * each frame (time-major like tsim_rollout's outputs): df_dq [num_frames][B][ndof_r], df_dvar [num_frames][B][ndof_var],
+ * df_dtac [num_frames][B][ndof_tactile], any may be NULL.  df_du [num_frames][B][ndof_u] = gradient w.r.t. u[f]
+ * (summed over the frame's sub-steps).  Continues / leaves the carried adjoint like tsim_backward_steps. */
+int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const void* df_dq, const void* df_dvar,
+                          const void* df_dtac, void* df_du, void* stream);
+
 /* sim.backward() results df_dq0 / df_dqdot0                    envs/redmax_torch_functions.py:92-100
  * = the carried adjoint once the whole tape has been popped. [B][ndof_r] each. */
 int tsim_get_adjoint(tsim_batch* b, void* df_dq0, void* df_dqd0, void* stream);

@@ -80,6 +80,7 @@ __device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_o
 template <class R> struct FwdArgs {
   const int* I; const R* F; const R* Fenv; int fstride;
   int B, nsub, record, t0;
+  int nframes;            // env-steps in this launch; frame f reads u[f][B][nu] and writes *_out[f][B][...] (tsim_rollout)
   R* tape; const R* u;
   R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
   const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
@@ -99,7 +100,6 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
   {
     const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
     if (lane < nr) { c.q0[lane] = st[lane]; c.qd0[lane] = st[nr + lane]; }
-    if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
   }
   __syncthreads();
   R* dlbase = c.dq + nr;
@@ -110,6 +110,11 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
   if (bdf2_model && has_prev && lane < nr) {
     c.qm1[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qdm1[lane] = a.prev[(size_t)env * 2 * nr + nr + lane];
   }
+  __syncthreads();
+  // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
+  // environment of the batch between env-steps: Newton stragglers average out over the episode.
+  for (int f = 0; f < a.nframes; ++f) {
+  if (lane < nu) c.u[lane] = a.u[((size_t)f * a.B + env) * nu + lane];
   __syncthreads();
   for (int s = 0; s < a.nsub; ++s) {
     // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     if (!conv) ++bad;
     // commit the sub-step: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
     if (a.record) {
-      R* rec = a.tape + ((size_t)(a.t0 + s + 1) * a.B + env) * REC;
+      R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
       if (lane < nr) { rec[lane] = c.q[lane]; rec[nr + lane] = c.qd[lane]; }
       for (int e = lane; e < nr * nr; e += TS_WAVE) rec[2 * nr + e] = c.H[e];
       if (lane < nu) rec[2 * nr + nr * nr + lane] = c.u[lane];
@@ -189,19 +194,23 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     has_prev = true;
     __syncthreads();
   }
+  if (lane < nr) {
+    const size_t o = ((size_t)f * a.B + env) * nr + lane;
+    if (a.q_out) a.q_out[o] = c.q0[lane];
+    if (a.qd_out) a.qd_out[o] = c.qd0[lane];
+  }
+  // link poses / velocities in LDS are those of the accepted state (last evaluation)
+  readout(c, lane, env, a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
+          a.tac_out ? a.tac_out + (size_t)f * a.B * 3 * c.ntax : nullptr);
+  __syncthreads();
+  }
   if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = c.qdm1[lane]; }
   if (!a.record) {
     R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
     if (lane < nr) { st[lane] = c.q0[lane]; st[nr + lane] = c.qd0[lane]; }
   }
-  if (lane < nr) {
-    if (a.q_out) a.q_out[(size_t)env * nr + lane] = c.q0[lane];
-    if (a.qd_out) a.qd_out[(size_t)env * nr + lane] = c.qd0[lane];
-  }
   if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
   if (a.evals && lane == 0) a.evals[env] = (int)evals;
-  // link poses / velocities in LDS are those of the accepted state (last evaluation)
-  readout(c, lane, env, a.var_out, a.tac_out);
 }
 
 // ================================================================================================ LPT ordering
@@ -275,7 +284,10 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
 // ================================================================================================ backward kernel
 template <class R> struct BwdArgs {
   const int* I; const R* F; const R* Fenv; int fstride;
-  int B, n, t_end, seed_mode;
+  int B, n, t_end;
+  int seed_stride;        // sub-step j (0 = oldest of the n) carries direct loss partials iff (j + 1) % seed_stride == 0
+  int frames;             // 0: seeds [B][n / seed_stride][.], df_du [B][n][nu] per sub-step (tsim_backward_steps)
+                          // 1: seeds [n / seed_stride][B][.], df_du [n / seed_stride][B][nu] summed per env-step (tsim_backward_episode)
   const R* tape;
   const R *df_dq, *df_dvar, *df_dtac;
   R *lamq, *lamv, *df_du;
@@ -402,6 +414,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
   init_world(c, lane);
   if (lane < nr) { c.lamq[lane] = a.lamq[(size_t)env * nr + lane]; c.lamv[lane] = a.lamv[(size_t)env * nr + lane]; }
   __syncthreads();
+  R du_frame = R(0);
   for (int j = a.n - 1; j >= 0; --j) {
     const int t = a.t_end - (a.n - 1 - j);
     const R* r1 = a.tape + ((size_t)t * a.B + env) * REC;
@@ -416,9 +429,10 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
     __syncthreads();
     phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
     // direct partials of the loss w.r.t. this sub-step's outputs
-    const bool seeded = a.seed_mode == 1 || j == a.n - 1;
+    const bool seeded = (j + 1) % a.seed_stride == 0;
     if (seeded) {
-      const size_t so = a.seed_mode == 1 ? (size_t)env * a.n + j : (size_t)env;
+      const int fr = j / a.seed_stride;
+      const size_t so = a.frames ? (size_t)fr * a.B + env : (size_t)env * (a.n / a.seed_stride) + fr;
       if (a.df_dq && lane < nr) c.lamq[lane] += a.df_dq[so * nr + lane];
       __syncthreads();
       output_vjp(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, (a.df_dtac && ntac3) ? a.df_dtac + so * ntac3 : nullptr);
@@ -441,7 +455,12 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
       R dtu;
       if (mi[TSIM_MI_CTRL] == 0) dtu = (c.u[lane] >= R(-1) && c.u[lane] <= R(1)) ? R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]) : R(0);
       else dtu = mf[TSIM_MF_P];
-      a.df_du[((size_t)env * a.n + j) * nu + lane] = c.h * c.h * c.z[mi[TSIM_MI_DOF]] * dtu;
+      const R du = c.h * c.h * c.z[mi[TSIM_MI_DOF]] * dtu;
+      if (!a.frames) a.df_du[((size_t)env * a.n + j) * nu + lane] = du;
+      else {
+        du_frame += du;
+        if (j % a.seed_stride == 0) { a.df_du[((size_t)(j / a.seed_stride) * a.B + env) * nu + lane] = du_frame; du_frame = R(0); }
+      }
     }
     __syncthreads();
   }
@@ -501,11 +520,11 @@ template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, i
 }
 
 template <class R>
-static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
+static int launch_forward(tsim_batch* b, const void* u, int nframes, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
   FwdArgs<R> a;
-  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes;
   a.tape = (R*)b->tape; a.u = (const R*)u;
-  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256) ? b->order : nullptr;
+  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
   a.prev = (R*)b->prev; a.has_prev = b->has_prev;
   // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
   // compiled out otherwise: it costs registers in every evaluation)
@@ -513,7 +532,8 @@ static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, v
   else if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   else hipLaunchKernelGGL((k_forward<R, 16, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
   HIPCHK(hipGetLastError());
-  if (b->B >= 256) {
+  if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
+  else if (b->B >= 256) {
     hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B);
     HIPCHK(hipGetLastError());
     b->order_valid = 1;
@@ -522,9 +542,9 @@ static int launch_forward(tsim_batch* b, const void* u, int nsub, void* q_out, v
 }
 
 template <class R>
-static int launch_backward(tsim_batch* b, int n, int seed_mode, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, hipStream_t st) {
+static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, hipStream_t st) {
   BwdArgs<R> a;
-  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_mode = seed_mode;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du;
   if (b->has_exp) hipLaunchKernelGGL((k_backward<R, 16, true>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
@@ -641,8 +661,8 @@ int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd
   if (!u && b->nu > 0) return fail("step: u is null");
   if (b->record && b->t_cur + num_steps > b->cap) return fail("step: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
   HIPCHK(hipSetDevice(b->device));
-  int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
-                                : launch_forward<double>(b, u, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
+  int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, 1, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
+                                : launch_forward<double>(b, u, 1, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
   if (rc) return rc;
   if (b->record) b->t_cur += num_steps;
   b->has_prev = 1;
@@ -682,10 +702,39 @@ int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, 
   if (!df_du && b->nu > 0) return fail("backward_steps: df_du is null");
   if (seed_mode != 0 && seed_mode != 1) return fail("backward_steps: bad seed_mode");
   HIPCHK(hipSetDevice(b->device));
-  int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, n, seed_mode, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
-                                : launch_backward<double>(b, n, seed_mode, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
+  const int stride = seed_mode == 1 ? 1 : n;
+  int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, n, stride, 0, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
+                                : launch_backward<double>(b, n, stride, 0, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
   if (rc) return rc;
   b->t_cur -= n;
+  return 0;
+}
+
+int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, void* stream) {
+  if (num_frames <= 0 || num_steps <= 0) return fail("rollout: num_frames and num_steps must be positive");
+  if (!u && b->nu > 0) return fail("rollout: u is null");
+  if (b->record && b->t_cur + (long long)num_frames * num_steps > b->cap) return fail("rollout: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
+  HIPCHK(hipSetDevice(b->device));
+  int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, num_frames, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
+                                : launch_forward<double>(b, u, num_frames, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
+  if (rc) return rc;
+  if (b->record) b->t_cur += num_frames * num_steps;
+  b->has_prev = 1;
+  return 0;
+}
+
+int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream) {
+  if (!b->record) return fail("backward_episode: reset(backward_flag=True) was not called");
+  if (b->I[TSIM_IH_INTEGRATOR] != 1) return fail("backward_episode: the adjoint is implemented for BDF1 models only (the reference's BDF2 model, tactile_pad.xml, is forward-only)");
+  if (num_frames <= 0 || num_steps <= 0) return fail("backward_episode: num_frames and num_steps must be positive");
+  const long long n = (long long)num_frames * num_steps;
+  if (n > b->t_cur) return fail("backward_episode: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
+  if (!df_du && b->nu > 0) return fail("backward_episode: df_du is null");
+  HIPCHK(hipSetDevice(b->device));
+  int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, (int)n, num_steps, 1, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
+                                : launch_backward<double>(b, (int)n, num_steps, 1, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
+  if (rc) return rc;
+  b->t_cur -= (int)n;
   return 0;
 }
 

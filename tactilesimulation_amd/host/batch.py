@@ -114,6 +114,42 @@ class BatchSim:
                                         _ptr(o.get("tactile")), _ptr(o["status"]), self._stream()))
         return o
 
+    def rollout(self, u, num_steps=1, want_qd=False, want_var=True, want_tactile=True):
+        """Open-loop episode in one launch (include/tsim.h tsim_rollout): u [T, B, ndof_u] -> dict of [T, B, dim] outputs
+        (+ status [B]); the same results as T calls of step()."""
+        if u.dim() != 3 or u.shape[1] != self.B or u.shape[2] != self.ndof_u:
+            raise ValueError("rollout: u must be [T, %d, %d], got %s" % (self.B, self.ndof_u, tuple(u.shape)))
+        T = int(u.shape[0])
+        u = u.to(device=self.device, dtype=self.dtype).contiguous()
+        new = lambda d: torch.empty((T, self.B, d), device=self.device, dtype=self.dtype)
+        o = {"q": new(self.ndof_r), "status": torch.empty(self.B, device=self.device, dtype=torch.int32)}
+        if want_qd:
+            o["qd"] = new(self.ndof_r)
+        if want_var and self.ndof_var:
+            o["var"] = new(self.ndof_var)
+        if want_tactile and self.ndof_tactile:
+            o["tactile"] = new(self.ndof_tactile)
+        capi.check(capi.lib().tsim_rollout(self._h, _ptr(u), T, int(num_steps), _ptr(o["q"]), _ptr(o.get("qd")), _ptr(o.get("var")),
+                                           _ptr(o.get("tactile")), _ptr(o["status"]), self._stream()))
+        return o
+
+    def backward_episode(self, num_frames, num_steps, df_dq=None, df_dvar=None, df_dtactile=None):
+        """Adjoint of the newest num_frames env-steps (num_steps sub-steps each) in one launch. Seeds [T, B, dim] or None;
+        returns df_du [T, B, ndof_u] (gradient w.r.t. the action of each frame)."""
+        T = int(num_frames)
+
+        def chk(t, dim, name):
+            if t is None or dim == 0:
+                return None
+            t = t.to(device=self.device, dtype=self.dtype).contiguous()
+            if tuple(t.shape) != (T, self.B, dim):
+                raise ValueError("%s: expected [%d, %d, %d], got %s" % (name, T, self.B, dim, tuple(t.shape)))
+            return t
+        a, b, c = chk(df_dq, self.ndof_r, "df_dq"), chk(df_dvar, self.ndof_var, "df_dvar"), chk(df_dtactile, self.ndof_tactile, "df_dtactile")
+        du = torch.empty((T, self.B, self.ndof_u), device=self.device, dtype=self.dtype)
+        capi.check(capi.lib().tsim_backward_episode(self._h, T, int(num_steps), _ptr(a), _ptr(b), _ptr(c), _ptr(du), self._stream()))
+        return du
+
     def get_state(self):
         q, qd = self.empty(self.ndof_r), self.empty(self.ndof_r)
         capi.check(capi.lib().tsim_get_state(self._h, _ptr(q), _ptr(qd), self._stream()))

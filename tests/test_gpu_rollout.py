@@ -1,0 +1,78 @@
+"""tsim_rollout / tsim_backward_episode (the open-loop episode of EpisodicSimFunction, envs/redmax_torch_functions.py:
+46-57, 77-92, as one launch each): bit-identical to the per-step entry points, and checked against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from workloads import push_workload
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_rollout_equals_steps_and_episode_adjoint_equals_step_adjoints(pusher_model, dtype):
+    from tactilesimulation_amd.host.batch import BatchSim
+    B, T, S = 16, 12, 5
+    q0_np, u_np, _ = push_workload(B, T, seed=5)
+    dev = "cuda:0"
+    q0 = torch.tensor(q0_np, device=dev, dtype=dtype)
+    u = torch.tensor(u_np, device=dev, dtype=dtype).transpose(0, 1).contiguous()        # [T, B, nu]
+    a = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+    b = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+    nr, nu, nv, nt = a.ndof_r, a.ndof_u, a.ndof_var, a.ndof_tactile
+    g = torch.Generator(device="cpu").manual_seed(1)
+    wq = torch.randn(T, B, nr, generator=g).to(dev, dtype)
+    wv = torch.randn(T, B, nv, generator=g).to(dev, dtype)
+    wt = (torch.randn(T, B, nt, generator=g) * 10).to(dev, dtype)
+
+    a.reset(q0, None, backward_flag=True)
+    ro = a.rollout(u, S, want_qd=True)
+    b.reset(q0, None, backward_flag=True)
+    for t in range(T):
+        so = b.step(u[t], S, want_qd=True)
+        for k in ("q", "qd", "var", "tactile"):
+            assert torch.equal(ro[k][t], so[k]), (k, t)
+    assert int(ro["status"].sum()) == 0
+
+    du_ep = a.backward_episode(T, S, wq, wv, wt)                                          # [T, B, nu]
+    du_st = torch.zeros_like(du_ep)
+    for t in reversed(range(T)):
+        du_st[t] = b.backward_steps(S, wq[t], wv[t], wt[t]).sum(1)
+    la, lb = a.get_adjoint(), b.get_adjoint()
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    sc = float(du_st.abs().max())
+    assert float((du_ep - du_st).abs().max()) <= tol * sc
+    for x, y in zip(la, lb):
+        assert float((x - y).abs().max()) <= tol * max(float(y.abs().max()), 1.0)
+    assert a.tape_len() == 0
+
+
+def test_episode_adjoint_matches_oracle(pusher_model):
+    from tactilesimulation_amd.host.batch import BatchSim
+    from oracle.oracle import OracleSim
+    B, T, S = 3, 6, 5
+    q0_np, u_np, _ = push_workload(B, T, seed=9)
+    m = pusher_model
+    dev = "cuda:0"
+    sim = BatchSim(m, B, dtype=torch.float64, tape_capacity=T * S)
+    sim.reset(torch.tensor(q0_np, device=dev), None, backward_flag=True)
+    u = torch.tensor(u_np, device=dev).transpose(0, 1).contiguous()
+    out = sim.rollout(u, S)
+    rng = np.random.default_rng(2)
+    nr, nu, nv, nt = sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile
+    wq, wv, wt = rng.normal(size=(T, nr)), rng.normal(size=(T, nv)), rng.normal(size=(T, nt))
+    tile = lambda w: torch.tensor(np.broadcast_to(w[:, None, :], (T, B, w.shape[1])).copy(), device=dev)
+    du = sim.backward_episode(T, S, tile(wq), tile(wv), tile(wt)).cpu().numpy()
+    o = OracleSim(m)
+    for e in range(B):
+        o.reset(q0_np[e], record=True)
+        for t in range(T):
+            o.forward(u_np[e, t], S)
+            q, _ = o.state(); var, tac = o.outputs()
+            assert np.abs(out["q"][t, e].cpu().numpy() - q).max() < 1e-6
+            assert np.abs(out["tactile"][t, e].cpu().numpy() - tac).max() < 1e-5 * max(np.abs(tac).max(), 1e-3)
+        n = T * S
+        sq, sv, st = np.zeros((n, nr)), np.zeros((n, nv)), np.zeros((n, nt))
+        sq[S - 1::S], sv[S - 1::S], st[S - 1::S] = wq, wv, wt
+        g = o.backward_steps(n, sq, sv, st).reshape(T, S, nu).sum(1)
+        assert np.abs(du[:, e] - g).max() < 1e-4 * max(np.abs(g).max(), 1e-12)
