@@ -1,9 +1,14 @@
 // tsim_device.h — device-side building blocks of the batched tactile-simulation step (gfx950 / CDNA4).
 //
-// Execution model: ONE ENVIRONMENT PER 64-LANE WAVEFRONT (block = 64 threads).  The environment's reduced
-// state (q, qd), the per-link world transforms / spatial velocities / wrenches and the Newton matrix live
-// in LDS for the whole kernel (all sub-steps of an env-step); HBM is touched only for the action, the
-// outputs and the tape.  Lane mappings inside one residual evaluation:
+// Execution model: block = ONE 64-LANE WAVEFRONT that carries 64 / LPE ENVIRONMENTS ("slots") of LPE = 64, 32 or 16
+// lanes each (template parameter; chosen per launch from the batch size).  An environment's reduced state (q, qd),
+// the per-link world transforms / spatial velocities / wrenches and the Newton matrix live in the slot's LDS region
+// for the whole kernel (all sub-steps of an env-step / episode); HBM is touched only for the action, the outputs and
+// the tape.  Inside the device functions `lane` is the lane index INSIDE the slot; every slot runs the same
+// instruction stream on its own environment (the model is shared, so model-dependent control flow is wave-uniform;
+// state-dependent decisions are per-slot predicates).  Most phases use only nr <= 16 lanes of a slot (lanes =
+// directions), which is why several slots per wavefront pay: the instruction count per environment is what bounds
+// this path.  Lane mappings inside one residual evaluation:
 //
 //   phase 1  (all lanes, uniform)     value kinematics + inertial wrench per link, root -> leaf
 //   phase 1t (lanes = directions)     exact tangents of link twist / acceleration / inertial wrench w.r.t. dof k,
@@ -196,6 +201,7 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_r(double 
   const int lo = dpp_i<CTRL, ROWMASK>((int)(b & 0xffffffffll)), hi = dpp_i<CTRL, ROWMASK>((int)(b >> 32));
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
+__device__ __forceinline__ int lane_bcast(int x, int lane_uniform) { return __builtin_amdgcn_readlane(x, lane_uniform); }
 __device__ __forceinline__ float lane_bcast(float x, int lane_uniform) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane_uniform));
 }
@@ -204,15 +210,32 @@ __device__ __forceinline__ double lane_bcast(double x, int lane_uniform) {
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane_uniform), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_uniform);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-// sum over the 64 lanes, result in every lane
-template <class R> __device__ __forceinline__ R wave_sum(R x) {
+// value of x in wavefront lane src (per-lane source, any pattern): LDS crossbar, no memory access
+__device__ __forceinline__ int lane_gather(int x, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, x); }
+__device__ __forceinline__ float lane_gather(float x, int src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double lane_gather(double x, int src) {
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// sum over the LPE lanes of the caller's slot, result in every lane of the slot
+template <int LPE, class R> __device__ __forceinline__ R seg_sum(R x) {
   x += dpp_r<0xB1, 0xf>(x);    // quad_perm [1,0,3,2]
   x += dpp_r<0x4E, 0xf>(x);    // quad_perm [2,3,0,1]
   x += dpp_r<0x141, 0xf>(x);   // row_half_mirror
   x += dpp_r<0x140, 0xf>(x);   // row_mirror      -> every lane of a 16-lane row holds the row total
+  if (LPE == 16) return x;
+  if (LPE == 32) return x + lane_gather(x, (int)threadIdx.x ^ 16);     // the other row of the slot
   x += dpp_r<0x142, 0xa>(x);   // row_bcast:15    -> rows 1 and 3 add the total of the row below
   x += dpp_r<0x143, 0xc>(x);   // row_bcast:31    -> rows 2 and 3 add the total of rows 0-1; lane 63 has the sum
   return lane_bcast(x, 63);
+}
+// value of x in lane src (inside the slot; the same for all lanes of a slot) of the caller's slot
+template <int LPE, class R> __device__ __forceinline__ R seg_bcast(R x, int src) {
+  if (LPE == TS_WAVE) return lane_bcast(x, __builtin_amdgcn_readfirstlane(src));
+  return lane_gather(x, ((int)threadIdx.x & ~(LPE - 1)) + src);
 }
 
 // ------------------------------------------------------------------------------------------------ per-block context
@@ -235,12 +258,10 @@ template <class R> struct Ctx {
 };
 #define TS_STAMP(c) do { if ((c).stamps) { if (threadIdx.x == 0 && (c).nstamp < 32) (c).stamps[(c).nstamp] = clock64(); (c).nstamp++; } } while (0)
 
-// number of LDS reals a block needs (host and device must agree). ni / nfrec: ints and leading reals of the model
-// blob that are staged in LDS (everything except the per-point SoA arrays); esz = sizeof(real).
-__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int ni, int nfrec, int esz) {
-  int nd = nr;
-  int n = nfrec + 2; (void)ni; (void)esz;
-  n += 15 * nr + nu;                       // q q0 qd0 qd qa g dq(2) dl(2) qp qdp qm1 qdm1 spare ; u
+// LDS reals of one environment's state (host and device must agree)
+__host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu) {
+  const int nd = nr;
+  int n = 15 * nr + nu;                    // q q0 qd0 qd qa g dq(2) dl(2) qp qdp qm1 qdm1 spare ; u
   n += 2 * nr * nr;                        // H, H2 (taped Newton matrix in the adjoint kernel)
   n += 4 * nr;                             // lamq lamv z rhs
   n += (nl + 1) * LK_SIZE;                 // LP
@@ -249,21 +270,33 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int ni, int 
   n += TS_PAIR_GROUP * PP_SIZE;            // PP
   n += TS_PAIR_GROUP * nd * PT_SIZE;       // PT
   n += 16 + 54;                            // scratch, expw
-  return n + 8;
+  return (n + 8 + 3) & ~3;                 // 16-byte multiples keep every slot's records equally aligned
+}
+// LDS reals of a block of nslot environments. nfrec: leading reals of the model blob that are staged in LDS (everything
+// except the per-point SoA arrays); one copy per block, or one per slot with per-environment tables.
+__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int nslot, bool env_tables) {
+  return (env_tables ? nslot : 1) * (nfrec + 2) + nslot * ts_lds_env_reals(nl, nr, nu) + 8;
 }
 
-template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, const R* Fenv = nullptr) {
+// LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
+// [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
+template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, const R* Fenv = nullptr) {
   // Stage the model's FLOAT tables in LDS (link / dof / motor / pair / sensor records): later reads are ds_read
   // broadcasts instead of ~500-cycle global loads.  The INT tables stay in global memory on purpose: they are
   // wave-uniform, so they travel through the scalar cache and all indexing / control flow stays on the SALU.
+  const int nfrec = I[TSIM_IH_FOFF_CPT];
   {
-    const int nfrec = I[TSIM_IH_FOFF_CPT];
     R* mf = lds;
-    const R* src = Fenv ? Fenv : F;          // per-environment float tables (domain randomisation) or the shared ones
-    for (int i = threadIdx.x; i < nfrec; i += TS_WAVE) mf[i] = src[i];
+    if (Fenv) {                                  // per-environment float tables (domain randomisation): one copy per slot
+      mf += slot * (nfrec + 2);
+      for (int i = lane; i < nfrec; i += lpe) mf[i] = Fenv[i];
+      lds += nslot * (nfrec + 2);
+    } else {
+      for (int i = threadIdx.x; i < nfrec; i += TS_WAVE) mf[i] = F[i];
+      lds += nfrec + 2;
+    }
     __syncthreads();
     c.Fg = F; c.F = mf; c.I = I;
-    lds += nfrec + 2;
     F = mf;
   }
   c.stamps = nullptr; c.nstamp = 0;
@@ -280,7 +313,7 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
   c.max_iter = I[TSIM_IH_MAX_ITER]; c.max_ls = I[TSIM_IH_MAX_LS];
   c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
   int nr = c.nr, nl = c.nl, nd = c.nd;
-  R* p = lds;
+  R* p = lds + slot * ts_lds_env_reals(nl, nr, c.nu);
   c.q = p; p += nr; c.q0 = p; p += nr; c.qd0 = p; p += nr; c.qd = p; p += nr; c.qa = p; p += nr;
   c.g = p; p += nr; c.dq = p; p += 2 * nr; c.dl = p; p += 2 * nr;
   c.qp = p; p += nr; c.qdp = p; p += nr; c.qm1 = p; p += nr; c.qdm1 = p; p += nr; c.u = p; p += c.nu;
@@ -296,8 +329,8 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
 }
 
 // world link: identity pose, zero velocity, gravity as base acceleration, zero wrench; all tangents zero.
-template <class R> __device__ inline void init_world(const Ctx<R>& c, int lane) {
-  for (int i = lane; i < LK_SIZE; i += TS_WAVE) {
+template <class R> __device__ inline void init_world(const Ctx<R>& c, int lane, int lpe) {
+  for (int i = lane; i < LK_SIZE; i += lpe) {
     R v = R(0);
     if (i == 0 || i == 4 || i == 8) v = R(1);
     if (i == LK_AV) v = -c.gx;
@@ -305,7 +338,7 @@ template <class R> __device__ inline void init_world(const Ctx<R>& c, int lane) 
     if (i == LK_AV + 2) v = -c.gz;
     c.LP[i] = v;
   }
-  for (int i = lane; i < c.nd * DT_SIZE; i += TS_WAVE) c.DT[i] = R(0);
+  for (int i = lane; i < c.nd * DT_SIZE; i += lpe) c.DT[i] = R(0);
 }
 
 __device__ __forceinline__ int anc_of(const int* I, int off_link, int link) {

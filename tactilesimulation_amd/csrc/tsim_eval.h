@@ -238,7 +238,7 @@ __device__ void pair_stage_tangent(const Ctx<R>& c, int pk, int slot, int lane, 
 // ================================================================================================ phase 2
 // lanes = contact points of the staged pairs.  Value wrench and, per relevant direction, its tangent — both in the
 // primitive frame — are accumulated per lane over the pair's chunks and reduced once per pair.
-template <class R, int NRM>
+template <class R, int NRM, int LPE>
 __device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
@@ -256,7 +256,7 @@ __device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
 #pragma unroll
     for (int e = 0; e < 6; ++e) acc[d][e] = R(0);
   bool any_hit = false;
-  for (int base = 0; base < npt; base += TS_WAVE) {
+  for (int base = 0; base < npt; base += LPE) {
     const int pidx = base + lane;
     bool hit = false;
     V3<R> cP = zero3<R>(), xP = cP, F = cP;
@@ -294,7 +294,7 @@ __device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
   {
     R s[6];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) s[e] = wave_sum(acc[0][e]);
+    for (int e = 0; e < 6; ++e) s[e] = seg_sum<LPE>(acc[0][e]);
     if (lane == 0) {
 #pragma unroll
       for (int e = 0; e < 6; ++e) S[PP_WN + e] = s[e];
@@ -305,7 +305,7 @@ __device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
     if (d < nd && ((anc >> d) & 1)) {
       R s[6];
 #pragma unroll
-      for (int e = 0; e < 6; ++e) s[e] = wave_sum(acc[d + 1][e]);
+      for (int e = 0; e < 6; ++e) s[e] = seg_sum<LPE>(acc[d + 1][e]);
       if (lane == 0) {
         R* T = c.PT + (slot * nd + d) * PT_SIZE;
 #pragma unroll
@@ -339,7 +339,7 @@ __device__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
   }
 }
 
-template <class R, int NRM>
+template <class R, int NRM, int LPE>
 __device__ void phase2(const Ctx<R>& c, int lane, R sq) {
   for (int p0 = 0; p0 < c.npair; p0 += TS_PAIR_GROUP) {
     const int pe = min(p0 + TS_PAIR_GROUP, c.npair);
@@ -352,7 +352,7 @@ __device__ void phase2(const Ctx<R>& c, int lane, R sq) {
     __syncthreads();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)
-      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_contacts<R, NRM>(c, pk, pk - p0, lane);
+      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
     __syncthreads();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // serial over pairs: two pairs may touch the same link
@@ -365,7 +365,7 @@ __device__ void phase2(const Ctx<R>& c, int lane, R sq) {
 // lanes = directions.  Leaf -> root: tau_j = W_j . F_subtree(link(j)); fold each link's wrench into its
 // parent; then the joint-space forces.  Result: g (value, LDS) and H[j][k] = d g_j / d dir_k (lane k owns
 // column k).  Both are scaled by h^2.
-template <class R, bool EXPJ>
+template <class R, bool EXPJ, int LPE>
 __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   const int nd = c.nd, k = lane, nr = c.nr;
   const bool act = lane < nr;
@@ -432,7 +432,7 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
     c.g[j] = gj; c.H[j * nr + j] = hjj;
   }
   __syncthreads();
-  for (int e = lane; e < nr * nr; e += TS_WAVE) c.H[e] *= h2;
+  for (int e = lane; e < nr * nr; e += LPE) c.H[e] *= h2;
   if (act) c.g[lane] *= h2;
   __syncthreads();
 }
@@ -442,7 +442,7 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
 // 4/3 q0 - 1/3 q_1 + 8/9 h qd0 - 2/9 h qd_1), not q1 itself: qd1 = qdp + cv dl, qdd1 = ca dl keep full relative
 // precision in fp32 (no q1 - q0 cancellation).  forward seeds: (1, cv, ca) -> H = dg/dq1 ;  adjoint seeds (1, 0, 0)
 // -> H = (1/ca) dr/dq  (BDF1: h^2 dr/dq).
-template <class R, int NRM, bool EXPJ>
+template <class R, int NRM, bool EXPJ, int LPE>
 __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   if (lane < c.nr) {
     const R d = c.dl[lane];
@@ -454,20 +454,20 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   TS_STAMP(c);
   phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
   TS_STAMP(c);
-  phase2<R, NRM>(c, lane, sq);
+  phase2<R, NRM, LPE>(c, lane, sq);
   TS_STAMP(c);
-  phase3<R, EXPJ>(c, lane, sq, sv);
+  phase3<R, EXPJ, LPE>(c, lane, sq, sv);
   TS_STAMP(c);
 }
 
 // ================================================================================================ dense solve
-// Gauss-Jordan with partial pivoting, one matrix row per lane held in registers, in precision S: fp64 for the
-// adjoint solves (their error goes straight into the gradient), the kernel's own precision for Newton steps (a Newton
-// direction with 1e-4 relative error still converges; the residual decides the answer).
-// Pivot search: 4 DPP steps inside the first 16-lane row; pivot row broadcast: v_readlane. No LDS traffic.
-// Solves A x = b (or A^T x = b), n <= NRM <= 16.
-template <class R, int NRM, class S = double>
-__device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane) {
+// Gauss-Jordan with partial pivoting, one matrix row per lane (lanes 0..n-1 of the slot) held in registers, in
+// precision S: fp64 for the adjoint solves (their error goes straight into the gradient) and for the Newton steps.
+// Pivot search: 4 DPP steps inside the slot's first 16-lane row; pivot row broadcast: v_readlane (one slot per
+// wavefront) or the LDS crossbar (several).  No LDS memory traffic.
+// Solves A x = b (or A^T x = b), n <= NRM <= 16; x is written only where `write` holds (a per-slot predicate).
+template <class R, int NRM, int LPE, class S = double>
+__device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
   S a[NRM], rb = S(0);
 #pragma unroll
   for (int j = 0; j < NRM; ++j) {
@@ -486,22 +486,22 @@ __device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose,
         if (om > mag || (om == mag && oi < idx)) { mag = om; idx = oi; } }
       TS_ARGMAX_STEP(0xB1) TS_ARGMAX_STEP(0x4E) TS_ARGMAX_STEP(0x141) TS_ARGMAX_STEP(0x140)
 #undef TS_ARGMAX_STEP
-      const int p = __builtin_amdgcn_readfirstlane(idx);
-      const S piv = lane_bcast(a[col], p);
+      const int p = seg_bcast<LPE>(idx, 0);            // the slot's first row holds the matrix rows
+      const S piv = seg_bcast<LPE>(a[col], p);
       const S f = (lane != p) ? a[col] / piv : S(0);
 #pragma unroll
       for (int j = 0; j < NRM; ++j) {
-        if (j >= col) { const S pj = lane_bcast(a[j], p); a[j] -= f * pj; }
+        if (j >= col) { const S pj = seg_bcast<LPE>(a[j], p); a[j] -= f * pj; }
       }
-      const S pb = lane_bcast(rb, p); rb -= f * pb;
+      const S pb = seg_bcast<LPE>(rb, p); rb -= f * pb;
       if (lane == p) { done = true; mycol = col; mypiv = piv; }
     }
   }
-  if (lane < n && mycol >= 0) x[mycol] = (R)(rb / mypiv);
+  if (write && lane < n && mycol >= 0) x[mycol] = (R)(rb / mypiv);
   __syncthreads();
 }
 
-template <class R> __device__ __forceinline__ R block_norm2(const R* v, int n, int lane) {
+template <int LPE, class R> __device__ __forceinline__ R block_norm2(const R* v, int n, int lane) {
   R s = lane < n ? v[lane] * v[lane] : R(0);
-  return t_sqrt(wave_sum(s));
+  return t_sqrt(seg_sum<LPE>(s));
 }

@@ -1,6 +1,6 @@
 // tsim_hip.hip — kernels + C ABI (include/tsim.h) of the MI355X-native batched tactile-simulation step.
 //
-// Kernels (one environment per 64-lane wavefront; see tsim_device.h):
+// Kernels (block = one 64-lane wavefront carrying 64 / LPE environments of LPE lanes each; see tsim_device.h):
 //   k_forward   : num_steps implicit BDF1 sub-steps (Newton + line search) with the action held, tape append,
 //                 q / qd / variables / tactile read-out          <- sim.set_u + sim.forward + getters
 //                                                                   (envs/redmax_torch_functions.py:131-136)
@@ -17,9 +17,6 @@
 #include "../../include/tsim.h"
 #include "tsim_eval.h"
 
-#ifndef TS_MIN_WAVES
-#define TS_MIN_WAVES 1     // second __launch_bounds__ argument (waves per SIMD the register allocator must allow)
-#endif
 
 // tape record per (sub-step, env): q[nr] qd[nr] H[nr*nr] u[nu]
 __host__ __device__ inline int ts_rec(int nr, int nu) { return 2 * nr + nr * nr + nu; }
@@ -27,10 +24,10 @@ __host__ __device__ inline int ts_rec(int nr, int nu) { return 2 * nr + nr * nr 
 // ================================================================================================ read-out
 // variables: lanes = end-effector points; tactile: lanes = taxels (coalesced SoA loads of position / frame,
 // 12 B per lane contiguous stores).  Each taxel is evaluated in the frame of the primitive it is tested against.
-template <class R>
-__device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
-  if (var_out) {
-    for (int e = lane; e < c.nvar; e += TS_WAVE) {
+template <int LPE, class R>
+__device__ void readout(const Ctx<R>& c, int lane, int env, bool wr, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
+  if (var_out && wr) {
+    for (int e = lane; e < c.nvar; e += LPE) {
       const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
       const V3<R> x = mulMv(ldm(c.LP + l * LK_SIZE + LK_R), ldv(c.F + c.foff_var + e * TSIM_VF_SIZE)) + ldv(c.LP + l * LK_SIZE + LK_P);
       R* o = var_out + (size_t)env * 3 * c.nvar + 3 * e;
@@ -49,9 +46,9 @@ __device__ void readout(const Ctx<R>& c, int lane, int env, R* var_out, R* tac_o
       __syncthreads();
       // this block's slice [tb, te) of the global taxel range, intersected with the sensor
       const int lo = max(tb, t0) - t0, hi = min(te, t0 + nt) - t0;
-      for (int base = lo; base < hi; base += TS_WAVE) {
+      for (int base = lo; base < hi; base += LPE) {
         const int t = t0 + base + lane;
-        if (base + lane >= hi) continue;
+        if (base + lane >= hi || !wr) continue;
         const R* tp = c.Fg + c.foff_tax + t;
         const V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
         V3<R> Fl = zero3<R>();                          // force on the taxel, sensor-link frame
@@ -87,16 +84,21 @@ template <class R> struct FwdArgs {
   R* prev; int has_prev;  // state before the previous sub-step [B][2 nr] (BDF2 history across launches)
 };
 
-template <class R, int NRM, bool EXPJ>
-__global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a) {
+template <class R, int NRM, bool EXPJ, int LPE, int MINW>
+__global__ void __launch_bounds__(TS_WAVE, MINW) k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
+  constexpr int NS = TS_WAVE / LPE;
+  const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;       // lane: inside the slot
   // Stragglers set the kernel time (all environments wait for the one with the most Newton work), so environments that
-  // were expensive in the previous env-step are dispatched first: block b runs environment order[b].
-  const int env = a.order ? a.order[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  // were expensive in the previous env-step are dispatched first: slot s of block b runs environment order[b NS + s]
+  // (neighbours in that order have similar work, which also keeps the slots of one wavefront together).
+  const int eidx = blockIdx.x * NS + slot;
+  const bool valid = eidx < a.B;                                        // a batch that is no multiple of NS: idle slot
+  const int env = a.order ? a.order[min(eidx, a.B - 1)] : min(eidx, a.B - 1);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
-  init_world(c, lane);
+  init_world(c, lane, LPE);
   {
     const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
     if (lane < nr) { c.q0[lane] = st[lane]; c.qd0[lane] = st[nr + lane]; }
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
   __syncthreads();
   R* dlbase = c.dq + nr;
   int bad = 0; bool nonfinite = false;
-  long long evals = 0;
+  int evals = 0;
   const bool bdf2_model = c.I[TSIM_IH_INTEGRATOR] == 2;
   bool has_prev = a.has_prev != 0;
   if (bdf2_model && has_prev && lane < nr) {
@@ -133,7 +135,9 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
     __syncthreads();
     // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
-    // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).
+    // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).  The state is per slot
+    // (identical in all lanes of a slot); a slot that has finished its sub-step keeps evaluating at its final iterate
+    // (same numbers again) until every slot of the wavefront has finished.
     // Globalisation: backtracking on ||g||.  ||g|| has non-smooth local minima next to contact /
     // friction kinks where no short step along the Newton direction reduces it; there the full Newton step is taken
     // anyway (it lands across the kink, from where the iteration normally converges in two or three steps).  A
@@ -142,13 +146,15 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     // decrease.
     R gn = R(0), alpha = R(1);
     int iter = 0, ls = -1, kicks = 0;          // ls < 0: the evaluation just done is not a line-search trial
-    bool conv = false, forced = false, giving_up = false, deep = false;
+    bool conv = false, forced = false, giving_up = false, deep = false, fin = false;
     while (true) {
-      evaluate<R, NRM, EXPJ>(c, lane, sq, sv, sa); ++evals;
-      const R gnew = block_norm2(c.g, nr, lane);
-      if (giving_up) { gn = gnew; conv = gn < R(100) * c.tol; break; }       // back at the last accepted iterate
-      if (ls >= 0 && !forced) {                // this was a line-search trial
-        if (!(gnew < gn)) {
+      evaluate<R, NRM, EXPJ, LPE>(c, lane, sq, sv, sa);
+      const R gnew = block_norm2<LPE>(c.g, nr, lane);
+      bool solve = false;
+      if (!fin) {
+        ++evals;
+        if (giving_up) { gn = gnew; conv = gn < R(100) * c.tol; fin = true; }      // back at the last accepted iterate
+        else if (ls >= 0 && !forced && !(gnew < gn)) {                             // a rejected line-search trial
           if (!deep && ls >= min(c.max_ls, TSIM_LS_SHORT)) {
             if (kicks < TSIM_KICK_MAX) {
               ++kicks; forced = true;
@@ -164,29 +170,36 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
             alpha *= R(0.5); ++ls;
             if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
           }
-          __syncthreads();
-          continue;
+        } else {
+          if (ls >= 0) ++iter;
+          forced = false;
+          gn = gnew;
+          if (!(gn == gn)) { nonfinite = true; fin = true; }
+          else if (gn < c.tol) { conv = true; fin = true; }
+          else if (iter >= c.max_iter) fin = true;
+          else {
+            solve = true;
+            if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
+          }
         }
       }
-      if (ls >= 0) ++iter;
-      forced = false;
-      gn = gnew;
-      if (!(gn == gn)) { nonfinite = true; break; }
-      if (gn < c.tol) { conv = true; break; }
-      if (iter >= c.max_iter) break;
-      if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
       __syncthreads();
-      solve_lanes<R, NRM, double>(c.H, c.rhs, c.dq, nr, false, lane);
-      alpha = R(1); ls = 0;
-      if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-      __syncthreads();
+      if (__any(solve)) {
+        solve_lanes<R, NRM, LPE, double>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+        if (solve) {
+          alpha = R(1); ls = 0;
+          if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+        }
+        __syncthreads();
+      }
+      if (__all(fin)) break;
     }
     if (!conv) ++bad;
     // commit the sub-step: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
-    if (a.record) {
+    if (a.record && valid) {
       R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
       if (lane < nr) { rec[lane] = c.q[lane]; rec[nr + lane] = c.qd[lane]; }
-      for (int e = lane; e < nr * nr; e += TS_WAVE) rec[2 * nr + e] = c.H[e];
+      for (int e = lane; e < nr * nr; e += LPE) rec[2 * nr + e] = c.H[e];
       if (lane < nu) rec[2 * nr + nr * nr + lane] = c.u[lane];
     }
     __syncthreads();
@@ -194,23 +207,25 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_forward(FwdArgs<R> a)
     has_prev = true;
     __syncthreads();
   }
-  if (lane < nr) {
+  if (lane < nr && valid) {
     const size_t o = ((size_t)f * a.B + env) * nr + lane;
     if (a.q_out) a.q_out[o] = c.q0[lane];
     if (a.qd_out) a.qd_out[o] = c.qd0[lane];
   }
   // link poses / velocities in LDS are those of the accepted state (last evaluation)
-  readout(c, lane, env, a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
-          a.tac_out ? a.tac_out + (size_t)f * a.B * 3 * c.ntax : nullptr);
+  readout<LPE>(c, lane, env, valid, a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
+               a.tac_out ? a.tac_out + (size_t)f * a.B * 3 * c.ntax : nullptr);
   __syncthreads();
   }
-  if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = c.qdm1[lane]; }
-  if (!a.record) {
-    R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
-    if (lane < nr) { st[lane] = c.q0[lane]; st[nr + lane] = c.qd0[lane]; }
+  if (valid) {
+    if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = c.qdm1[lane]; }
+    if (!a.record) {
+      R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
+      if (lane < nr) { st[lane] = c.q0[lane]; st[nr + lane] = c.qd0[lane]; }
+    }
+    if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
+    if (a.evals && lane == 0) a.evals[env] = evals;
   }
-  if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
-  if (a.evals && lane == 0) a.evals[env] = (int)evals;
 }
 
 // ================================================================================================ LPT ordering
@@ -236,16 +251,16 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, 1, 0, lane, TS_WAVE, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
   const int nr = c.nr, REC = ts_rec(nr, c.nu);
-  init_world(c, lane);
+  init_world(c, lane, TS_WAVE);
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
   if (lane < nr) { c.q[lane] = st[lane]; c.qd[lane] = st[nr + lane]; c.qa[lane] = R(0); }
   __syncthreads();
   phase1<R, false, true>(c, lane, R(0), R(0), R(0));
   // high-resolution sensors (RollingBall: 40 000 taxels): blockIdx.y selects a slice of the taxels, so one
   // environment's read-out spreads over many CUs; 12 B/lane contiguous stores, SoA coalesced loads
-  readout(c, lane, env, blockIdx.y == 0 ? a.var_out : nullptr, a.tac_out, (int)blockIdx.y * a.slice, ((int)blockIdx.y + 1) * a.slice);
+  readout<TS_WAVE>(c, lane, env, true, blockIdx.y == 0 ? a.var_out : nullptr, a.tac_out, (int)blockIdx.y * a.slice, ((int)blockIdx.y + 1) * a.slice);
 }
 
 // ================================================================================================ debug evaluation
@@ -256,9 +271,9 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, 1, 0, lane, TS_WAVE, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu;
-  init_world(c, lane);
+  init_world(c, lane, TS_WAVE);
   if (lane < nr) {
     c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane];
     c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane];
@@ -268,14 +283,14 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   __syncthreads();
   if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve
     c.stamps = a.cyc + (size_t)env * 32;
-    evaluate<R, 8, false>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    evaluate<R, 8, false, TS_WAVE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
     if (lane < nr) c.rhs[lane] = -c.g[lane];
     __syncthreads();
-    solve_lanes<R, 8>(c.H, c.rhs, c.dq, nr, false, lane);
+    solve_lanes<R, 8, TS_WAVE>(c.H, c.rhs, c.dq, nr, false, lane);
     TS_STAMP(c);
     if (lane == 0) for (int i = c.nstamp; i < 32; ++i) c.stamps[i] = 0;
   } else {
-    evaluate<R, 16, true>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    evaluate<R, 16, true, TS_WAVE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
   }
   if (lane < nr) a.g[(size_t)env * nr + lane] = c.g[lane];
   for (int e = lane; e < nr * nr; e += TS_WAVE) a.H[(size_t)env * nr * nr + e] = c.H[e];
@@ -314,7 +329,7 @@ __device__ R mass_times_z(const Ctx<R>& c, int j) {
 // q-tangents (seeds (1,0,0)) are in LDS.  Tactile: reverse mode at the taxel level — each lane forms the gradient of
 // w . out w.r.t. the pair's relative displacement and relative twist (12 numbers, primitive frame); one reduction
 // per (sensor, primitive); lanes = directions then dot it with the pair's per-direction records.
-template <class R>
+template <int LPE, class R>
 __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac) {
   const int nd = c.nd, nr = c.nr;
   if (wvar && lane < nr) {
@@ -349,7 +364,7 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
 #pragma unroll
       for (int e = 0; e < 12; ++e) g[e] = R(0);
       bool any_live = false;
-      for (int base = 0; base < nt; base += TS_WAVE) {
+      for (int base = 0; base < nt; base += LPE) {
         const bool valid = base + lane < nt;
         const int t = t0 + (valid ? base + lane : 0);
         const R* tp = c.Fg + c.foff_tax + t;
@@ -379,7 +394,7 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
       }
       if (!any_live) continue;
 #pragma unroll
-      for (int e = 0; e < 12; ++e) g[e] = wave_sum(g[e]);
+      for (int e = 0; e < 12; ++e) g[e] = seg_sum<LPE>(g[e]);
       // lanes = directions
       pair_stage_tangent(c, pk, 0, lane, R(1), 0);
       if (lane < nr) {
@@ -402,16 +417,19 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
   __syncthreads();
 }
 
-template <class R, int NRM, bool EXPJ>
-__global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a) {
+template <class R, int NRM, bool EXPJ, int LPE, int MINW>
+__global__ void __launch_bounds__(TS_WAVE, MINW) k_backward(BwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
-  const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
+  constexpr int NS = TS_WAVE / LPE;
+  const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
+  const bool valid = (int)blockIdx.x * NS + slot < a.B;
+  const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
   R* H2 = c.H2;    // taped Newton matrix of the sub-step
-  init_world(c, lane);
+  init_world(c, lane, LPE);
   if (lane < nr) { c.lamq[lane] = a.lamq[(size_t)env * nr + lane]; c.lamv[lane] = a.lamv[(size_t)env * nr + lane]; }
   __syncthreads();
   R du_frame = R(0);
@@ -425,7 +443,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
       c.qa[lane] = (r1[nr + lane] - r0[nr + lane]) / c.h;       // discrete acceleration, no position cancellation
     }
     if (lane < nu) c.u[lane] = r1[2 * nr + nr * nr + lane];
-    for (int e = lane; e < nr * nr; e += TS_WAVE) H2[e] = r1[2 * nr + e];
+    for (int e = lane; e < nr * nr; e += LPE) H2[e] = r1[2 * nr + e];
     __syncthreads();
     phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
     // direct partials of the loss w.r.t. this sub-step's outputs
@@ -435,13 +453,13 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
       const size_t so = a.frames ? (size_t)fr * a.B + env : (size_t)env * (a.n / a.seed_stride) + fr;
       if (a.df_dq && lane < nr) c.lamq[lane] += a.df_dq[so * nr + lane];
       __syncthreads();
-      output_vjp(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, (a.df_dtac && ntac3) ? a.df_dtac + so * ntac3 : nullptr);
+      output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, (a.df_dtac && ntac3) ? a.df_dtac + so * ntac3 : nullptr);
     }
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.lamv[lane] / c.h;
     __syncthreads();
-    solve_lanes<R, NRM>(H2, c.rhs, c.z, nr, true, lane);
-    phase2<R, NRM>(c, lane, R(1));
-    phase3<R, EXPJ>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
+    solve_lanes<R, NRM, LPE>(H2, c.rhs, c.z, nr, true, lane);
+    phase2<R, NRM, LPE>(c, lane, R(1));
+    phase3<R, EXPJ, LPE>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
     if (lane < nr) {
       R yq = R(0);
       for (int i = 0; i < nr; ++i) yq += c.z[i] * c.H[i * nr + lane];
@@ -449,7 +467,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
       c.lamq[lane] -= yq;
       c.lamv[lane] = c.h * ym;
     }
-    if (lane < nu) {
+    if (lane < nu && valid) {
       const int* mi = c.I + c.off_motor + lane * TSIM_MI_SIZE;
       const R* mf = c.F + c.foff_motor + lane * TSIM_MF_SIZE;
       R dtu;
@@ -464,7 +482,7 @@ __global__ void __launch_bounds__(TS_WAVE, TS_MIN_WAVES) k_backward(BwdArgs<R> a
     }
     __syncthreads();
   }
-  if (lane < nr) { a.lamq[(size_t)env * nr + lane] = c.lamq[lane]; a.lamv[(size_t)env * nr + lane] = c.lamv[lane]; }
+  if (lane < nr && valid) { a.lamq[(size_t)env * nr + lane] = c.lamq[lane]; a.lamv[(size_t)env * nr + lane] = c.lamv[lane]; }
 }
 
 // ================================================================================================ host side
@@ -486,7 +504,9 @@ struct tsim_batch {
   void* prev; int has_prev;      // BDF2: state before the previous sub-step [B][2 nr]
   int has_exp;                   // model contains a rotation-vector joint
   int t_cur, record;
-  size_t lds_bytes, esz;
+  int lpe_forced, minw_forced;   // launch shape forced by TSIM_LPE / TSIM_MINW (0 = choose from the batch size)
+  int n_simd;                    // SIMDs of the device (CUs x 4)
+  size_t esz;
   std::vector<CacheEntry> cache;
 };
 
@@ -519,6 +539,57 @@ template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, i
   if (qd) qd[i] = tape_rec[(size_t)env * rec + nr + k];
 }
 
+// dynamic LDS of a block of nslot environments
+static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
+  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, nslot, b->dFenv != nullptr);
+  return ((size_t)reals * b->esz + 15) / 16 * 16;
+}
+// Launch shape of the forward / backward kernels.
+// Lanes per environment (LPE): one environment per wavefront uses <= nr of the 64 lanes in most phases; packing 2 or 4
+// environments into a wavefront divides the instruction count per environment — as long as enough wavefronts remain
+// to give every SIMD one (the smallest LPE with B / (64 / LPE) >= #SIMDs), and at least 4 blocks' LDS fit a CU.
+// Register budget (MINW = second __launch_bounds__ argument): these kernels want ~270 registers; with one wavefront per
+// SIMD (or fp64, where a 256-register budget spills heavily) they get them, with more wavefronts than SIMDs the fp32
+// kernels are held to 256 so that two wavefronts share a SIMD (measured, profiles/r01_lpe_sweep.json).
+struct LaunchShape { int lpe, minw; unsigned grid; size_t lds; };
+static LaunchShape launch_shape(const tsim_batch* b) {
+  LaunchShape L;
+  int lpe = b->lpe_forced;
+  if (!lpe) {
+    lpe = TS_WAVE;
+    while (lpe > 16 && (long long)b->B * (lpe / 2) / TS_WAVE >= b->n_simd) lpe /= 2;
+  }
+  if (b->has_exp) lpe = TS_WAVE;
+  const size_t lds_cap = b->lpe_forced ? 64 * 1024 : 40 * 1024;
+  while (lpe < TS_WAVE && lds_bytes_for(b, TS_WAVE / lpe) > lds_cap) lpe *= 2;
+  L.lpe = lpe;
+  const int ns = TS_WAVE / lpe;
+  L.grid = (unsigned)((b->B + ns - 1) / ns);
+  L.lds = lds_bytes_for(b, ns);
+  L.minw = (b->dtype == TSIM_F32 && (int)L.grid > b->n_simd && !b->has_exp) ? 2 : 1;
+  if (b->minw_forced) L.minw = b->has_exp ? 1 : b->minw_forced;
+  return L;
+}
+#define TS_LAUNCH_W(KERNEL, R, NRM, LPE, L, st, a) do {                                                                  \
+    if (L.minw == 2) hipLaunchKernelGGL((KERNEL<R, NRM, false, LPE, 2>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);     \
+    else hipLaunchKernelGGL((KERNEL<R, NRM, false, LPE, 1>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                 \
+  } while (0)
+// kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
+// compiled out otherwise: it costs registers in every evaluation); LPE, MINW as above
+#define TS_LAUNCH(KERNEL, R, b, st, a) do {                                                                              \
+    const LaunchShape L = launch_shape(b);                                                                               \
+    if (b->has_exp) hipLaunchKernelGGL((KERNEL<R, 16, true, 64, 1>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);         \
+    else if (b->nr <= 8) {                                                                                               \
+      if (L.lpe == 64) TS_LAUNCH_W(KERNEL, R, 8, 64, L, st, a);                                                          \
+      else if (L.lpe == 32) TS_LAUNCH_W(KERNEL, R, 8, 32, L, st, a);                                                     \
+      else TS_LAUNCH_W(KERNEL, R, 8, 16, L, st, a);                                                                      \
+    } else {                                                                                                             \
+      if (L.lpe == 64) TS_LAUNCH_W(KERNEL, R, 16, 64, L, st, a);                                                         \
+      else if (L.lpe == 32) TS_LAUNCH_W(KERNEL, R, 16, 32, L, st, a);                                                    \
+      else TS_LAUNCH_W(KERNEL, R, 16, 16, L, st, a);                                                                     \
+    }                                                                                                                    \
+  } while (0)
+
 template <class R>
 static int launch_forward(tsim_batch* b, const void* u, int nframes, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
   FwdArgs<R> a;
@@ -526,11 +597,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, int nsub, v
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
   a.prev = (R*)b->prev; a.has_prev = b->has_prev;
-  // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
-  // compiled out otherwise: it costs registers in every evaluation)
-  if (b->has_exp) hipLaunchKernelGGL((k_forward<R, 16, true>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
-  else if (b->nr <= 8) hipLaunchKernelGGL((k_forward<R, 8, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
-  else hipLaunchKernelGGL((k_forward<R, 16, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
   if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
   else if (b->B >= 256) {
@@ -547,9 +614,7 @@ static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, co
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du;
-  if (b->has_exp) hipLaunchKernelGGL((k_backward<R, 16, true>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
-  else if (b->nr <= 8) hipLaunchKernelGGL((k_backward<R, 8, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
-  else hipLaunchKernelGGL((k_backward<R, 16, false>), dim3(b->B), dim3(TS_WAVE), b->lds_bytes, st, a);
+  TS_LAUNCH(k_backward, R, b, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -566,7 +631,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   if (I[TSIM_IH_INTEGRATOR] != 1 && I[TSIM_IH_INTEGRATOR] != 2) return fail("unknown integrator");
   const int nl = I[TSIM_IH_NL], nr = I[TSIM_IH_NR], nu = I[TSIM_IH_NU];
   int n_exp = 0;
-  if (nr > 16 || nr < 1 || nu > TS_WAVE) return fail("ndof_r must be in 1..16");
+  if (nr > 16 || nr < 1 || nu > 16) return fail("ndof_r must be in 1..16 and ndof_u <= 16");
   for (int i = 1; i <= nl; ++i) {
     int jt = I[I[TSIM_IH_OFF_LINK] + (i - 1) * TSIM_LI_SIZE + TSIM_LI_JTYPE];
     if (jt != TSIM_J_REVOLUTE && jt != TSIM_J_PRISMATIC && jt != TSIM_J_PLANAR && jt != TSIM_J_TRANSLATIONAL && jt != TSIM_J_SPHERICAL_EXP)
@@ -582,11 +647,18 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->nl = nl; b->nr = nr; b->nu = nu; b->nvar = I[TSIM_IH_NVAR]; b->ntax = I[TSIM_IH_NTAXEL];
   b->rec = ts_rec(nr, nu);
   b->esz = dtype == TSIM_F32 ? 4 : 8;
-  int reals = ts_lds_reals(nl, nr, nu, I[TSIM_IH_NI], I[TSIM_IH_FOFF_CPT], (int)b->esz);
-  b->lds_bytes = ((size_t)reals * b->esz + 15) / 16 * 16;
-  if (b->lds_bytes > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   b->t_cur = 0; b->record = 0; b->has_exp = n_exp > 0;
-  b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT]; b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
+  b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT];
+  b->lpe_forced = 0;
+  b->minw_forced = 0;
+  if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
+  if (const char* e = getenv("TSIM_MINW")) { const int v = atoi(e); if (v == 1 || v == 2) b->minw_forced = v; }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    b->n_simd = 4 * cus;
+  }
+  if (lds_bytes_for(b, 1) > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, b->I.size() * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
@@ -617,7 +689,11 @@ int tsim_batch_size(const tsim_batch* b) { return b->B; }
 int tsim_dtype(const tsim_batch* b) { return b->dtype; }
 double tsim_timestep(const tsim_batch* b) { return b->F[TSIM_FH_H]; }
 int tsim_tape_len(const tsim_batch* b) { return b->record ? b->t_cur : 0; }
-int tsim_launch_info(const tsim_batch* b, int32_t* out) { out[0] = (int32_t)b->lds_bytes; out[1] = TS_WAVE; out[2] = b->B; return 0; }
+int tsim_launch_info(const tsim_batch* b, int32_t* out) {
+  const LaunchShape L = launch_shape(b);
+  out[0] = (int32_t)L.lds; out[1] = TS_WAVE; out[2] = (int32_t)L.grid; out[3] = L.lpe; out[4] = L.minw;
+  return 0;
+}
 int tsim_last_evals(tsim_batch* b, int32_t* host_out) {
   if (hipSetDevice(b->device) != hipSuccess || hipMemcpy(host_out, b->evals, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_evals: copy failed");
   return 0;
@@ -686,10 +762,10 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   dim3 grid(b->B, ny > 0 ? ny : 1);
   if (b->dtype == TSIM_F32) {
     ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out, slice};
-    hipLaunchKernelGGL(k_readout<float>, grid, dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_readout<float>, grid, dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
   } else {
     ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out, slice};
-    hipLaunchKernelGGL(k_readout<double>, grid, dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_readout<double>, grid, dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -779,10 +855,10 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
   HIPCHK(hipSetDevice(b->device));
   if (b->dtype == TSIM_F32) {
     DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles};
-    hipLaunchKernelGGL(k_debug_eval<float>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_debug_eval<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
   } else {
     DbgArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles};
-    hipLaunchKernelGGL(k_debug_eval<double>, dim3(b->B), dim3(TS_WAVE), b->lds_bytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_debug_eval<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());
   return 0;
