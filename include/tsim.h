@@ -125,7 +125,7 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
  * static launch geometry of the forward / backward kernels): out[0] = LDS bytes per block, out[1] = threads per block,
  * out[2] = blocks, out[3] = lanes per environment (64 / 32 / 16: a 64-lane block carries 1 / 2 / 4 environments; chosen
  * from the batch size and the device's SIMD count, override with the environment variable TSIM_LPE at
- * tsim_batch_create), out[4] = wavefronts per SIMD the kernel variant is compiled for (1 / 2; TSIM_MINW). out = int32[5]. */
+ * tsim_batch_create). out = int32[4]. */
 int tsim_launch_info(const tsim_batch* b, int32_t* out);
 
 /* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */

@@ -84,8 +84,8 @@ template <class R> struct FwdArgs {
   R* prev; int has_prev;  // state before the previous sub-step [B][2 nr] (BDF2 history across launches)
 };
 
-template <class R, int NRM, bool EXPJ, int LPE, int MINW>
-__global__ void __launch_bounds__(TS_WAVE, MINW) k_forward(FwdArgs<R> a) {
+template <class R, int NRM, bool EXPJ, int LPE>
+__global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   constexpr int NS = TS_WAVE / LPE;
@@ -417,8 +417,8 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
   __syncthreads();
 }
 
-template <class R, int NRM, bool EXPJ, int LPE, int MINW>
-__global__ void __launch_bounds__(TS_WAVE, MINW) k_backward(BwdArgs<R> a) {
+template <class R, int NRM, bool EXPJ, int LPE>
+__global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   constexpr int NS = TS_WAVE / LPE;
@@ -504,7 +504,7 @@ struct tsim_batch {
   void* prev; int has_prev;      // BDF2: state before the previous sub-step [B][2 nr]
   int has_exp;                   // model contains a rotation-vector joint
   int t_cur, record;
-  int lpe_forced, minw_forced;   // launch shape forced by TSIM_LPE / TSIM_MINW (0 = choose from the batch size)
+  int lpe_forced;                // lanes per environment forced by TSIM_LPE (0 = choose from the batch size)
   int n_simd;                    // SIMDs of the device (CUs x 4)
   size_t esz;
   std::vector<CacheEntry> cache;
@@ -548,10 +548,9 @@ static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
 // Lanes per environment (LPE): one environment per wavefront uses <= nr of the 64 lanes in most phases; packing 2 or 4
 // environments into a wavefront divides the instruction count per environment — as long as enough wavefronts remain
 // to give every SIMD one (the smallest LPE with B / (64 / LPE) >= #SIMDs), and at least 4 blocks' LDS fit a CU.
-// Register budget (MINW = second __launch_bounds__ argument): these kernels want ~270 registers; with one wavefront per
-// SIMD (or fp64, where a 256-register budget spills heavily) they get them, with more wavefronts than SIMDs the fp32
-// kernels are held to 256 so that two wavefronts share a SIMD (measured, profiles/r01_lpe_sweep.json).
-struct LaunchShape { int lpe, minw; unsigned grid; size_t lds; };
+// These kernels use ~270 registers, i.e. one wavefront per SIMD; holding them to 256 for two per SIMD spills and is
+// slower at every batch size measured (profiles/r01_launch_shape_ab.txt), larger batches simply run in rounds.
+struct LaunchShape { int lpe; unsigned grid; size_t lds; };
 static LaunchShape launch_shape(const tsim_batch* b) {
   LaunchShape L;
   int lpe = b->lpe_forced;
@@ -566,28 +565,20 @@ static LaunchShape launch_shape(const tsim_batch* b) {
   const int ns = TS_WAVE / lpe;
   L.grid = (unsigned)((b->B + ns - 1) / ns);
   L.lds = lds_bytes_for(b, ns);
-  L.minw = (b->dtype == TSIM_F32 && (int)L.grid > b->n_simd && !b->has_exp) ? 2 : 1;
-  if (b->minw_forced) L.minw = b->has_exp ? 1 : b->minw_forced;
   return L;
 }
-#define TS_LAUNCH_W(KERNEL, R, NRM, LPE, L, st, a) do {                                                                  \
-    if (L.minw == 2) hipLaunchKernelGGL((KERNEL<R, NRM, false, LPE, 2>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);     \
-    else hipLaunchKernelGGL((KERNEL<R, NRM, false, LPE, 1>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                 \
-  } while (0)
 // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
-// compiled out otherwise: it costs registers in every evaluation); LPE, MINW as above
+// compiled out otherwise: it costs registers in every evaluation); LPE as above
+#define TS_LAUNCH_L(KERNEL, R, NRM, L, st, a) do {                                                                       \
+    if (L.lpe == 64) hipLaunchKernelGGL((KERNEL<R, NRM, false, 64>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);         \
+    else if (L.lpe == 32) hipLaunchKernelGGL((KERNEL<R, NRM, false, 32>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);    \
+    else hipLaunchKernelGGL((KERNEL<R, NRM, false, 16>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                     \
+  } while (0)
 #define TS_LAUNCH(KERNEL, R, b, st, a) do {                                                                              \
     const LaunchShape L = launch_shape(b);                                                                               \
-    if (b->has_exp) hipLaunchKernelGGL((KERNEL<R, 16, true, 64, 1>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);         \
-    else if (b->nr <= 8) {                                                                                               \
-      if (L.lpe == 64) TS_LAUNCH_W(KERNEL, R, 8, 64, L, st, a);                                                          \
-      else if (L.lpe == 32) TS_LAUNCH_W(KERNEL, R, 8, 32, L, st, a);                                                     \
-      else TS_LAUNCH_W(KERNEL, R, 8, 16, L, st, a);                                                                      \
-    } else {                                                                                                             \
-      if (L.lpe == 64) TS_LAUNCH_W(KERNEL, R, 16, 64, L, st, a);                                                         \
-      else if (L.lpe == 32) TS_LAUNCH_W(KERNEL, R, 16, 32, L, st, a);                                                    \
-      else TS_LAUNCH_W(KERNEL, R, 16, 16, L, st, a);                                                                     \
-    }                                                                                                                    \
+    if (b->has_exp) hipLaunchKernelGGL((KERNEL<R, 16, true, 64>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);            \
+    else if (b->nr <= 8) TS_LAUNCH_L(KERNEL, R, 8, L, st, a);                                                            \
+    else TS_LAUNCH_L(KERNEL, R, 16, L, st, a);                                                                           \
   } while (0)
 
 template <class R>
@@ -650,9 +641,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->t_cur = 0; b->record = 0; b->has_exp = n_exp > 0;
   b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT];
   b->lpe_forced = 0;
-  b->minw_forced = 0;
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
-  if (const char* e = getenv("TSIM_MINW")) { const int v = atoi(e); if (v == 1 || v == 2) b->minw_forced = v; }
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
@@ -691,7 +680,7 @@ double tsim_timestep(const tsim_batch* b) { return b->F[TSIM_FH_H]; }
 int tsim_tape_len(const tsim_batch* b) { return b->record ? b->t_cur : 0; }
 int tsim_launch_info(const tsim_batch* b, int32_t* out) {
   const LaunchShape L = launch_shape(b);
-  out[0] = (int32_t)L.lds; out[1] = TS_WAVE; out[2] = (int32_t)L.grid; out[3] = L.lpe; out[4] = L.minw;
+  out[0] = (int32_t)L.lds; out[1] = TS_WAVE; out[2] = (int32_t)L.grid; out[3] = L.lpe;
   return 0;
 }
 int tsim_last_evals(tsim_batch* b, int32_t* host_out) {

@@ -208,6 +208,6 @@ class BatchSim:
         return out
 
     def launch_info(self):
-        out = (C.c_int32 * 5)()
+        out = (C.c_int32 * 4)()
         capi.lib().tsim_launch_info(self._h, out)
-        return {"lds_bytes": out[0], "threads": out[1], "blocks": out[2], "lanes_per_env": out[3], "waves_per_simd": out[4]}
+        return {"lds_bytes": out[0], "threads": out[1], "blocks": out[2], "lanes_per_env": out[3]}
