@@ -87,22 +87,26 @@ int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, 
                         const void* df_dtac, void* df_du, void* stream);
 
 /* The open-loop episode of EpisodicSimFunction.forward             envs/redmax_torch_functions.py:46-57
- *   for t in range(T): sim.set_u(actions[t]); sim.forward(n); q, variables, tactile = getters
+ *   for t in range(T): sim.set_u(actions[t]); sim.forward(n); q, variables = getters;
+ *                      if tactile_masks[t]: tactile = get_tactile_force_vector()
  * as ONE launch: frame f applies u[f] for num_steps sub-steps and writes its outputs to slot f.
  *   u [num_frames][B][ndof_u];  q_out, qd_out [num_frames][B][ndof_r], var_out [num_frames][B][ndof_var],
- *   tac_out [num_frames][B][ndof_tactile] (any may be NULL);  status [B]: non-converged sub-steps of the whole call.
+ *   tac_out [num_masked][B][ndof_tactile] (any may be NULL);  status [B]: non-converged sub-steps of the whole call.
+ *   tactile_slot: DEVICE int32[num_frames], slot of frame f in tac_out or < 0 for "no tactile read-out at this frame"
+ *   (the tactile_masks of :55-57 as an exclusive prefix count); NULL = every frame, slot f.
  * Results are bit-identical to num_frames calls of tsim_step; no environment waits for the slowest one of the batch
  * between env-steps, which is where the per-step launches lose their time. */
-int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, void* q_out, void* qd_out,
-                 void* var_out, void* tac_out, int32_t* status, void* stream);
+int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, const int32_t* tactile_slot,
+                 void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, void* stream);
 
 /* sim.backward() of EpisodicSimFunction.backward                  envs/redmax_torch_functions.py:77-92
  * Adjoint of the newest num_frames * num_steps sub-steps in one launch.  Seeds are the partials w.r.t. the outputs of
  * each frame (time-major like tsim_rollout's outputs): df_dq [num_frames][B][ndof_r], df_dvar [num_frames][B][ndof_var],
- * df_dtac [num_frames][B][ndof_tactile], any may be NULL.  df_du [num_frames][B][ndof_u] = gradient w.r.t. u[f]
+ * df_dtac [num_masked][B][ndof_tactile] (tactile_slot as in tsim_rollout), any may be NULL.
+ * df_du [num_frames][B][ndof_u] = gradient w.r.t. u[f]
  * (summed over the frame's sub-steps).  Continues / leaves the carried adjoint like tsim_backward_steps. */
-int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const void* df_dq, const void* df_dvar,
-                          const void* df_dtac, void* df_du, void* stream);
+int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const int32_t* tactile_slot,
+                          const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream);
 
 /* sim.backward() results df_dq0 / df_dqdot0                    envs/redmax_torch_functions.py:92-100
  * = the carried adjoint once the whole tape has been popped. [B][ndof_r] each. */

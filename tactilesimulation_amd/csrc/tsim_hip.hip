@@ -78,6 +78,7 @@ template <class R> struct FwdArgs {
   const int* I; const R* F; const R* Fenv; int fstride;
   int B, nsub, record, t0;
   int nframes;            // env-steps in this launch; frame f reads u[f][B][nu] and writes *_out[f][B][...] (tsim_rollout)
+  const int* tac_slot;    // [nframes] slot of frame f in tac_out, < 0: no tactile read-out for that frame; null: slot f
   R* tape; const R* u;
   R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
   const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
@@ -213,8 +214,9 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     if (a.qd_out) a.qd_out[o] = c.qd0[lane];
   }
   // link poses / velocities in LDS are those of the accepted state (last evaluation)
+  const int tslot = a.tac_slot ? a.tac_slot[f] : f;
   readout<LPE>(c, lane, env, valid, a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
-               a.tac_out ? a.tac_out + (size_t)f * a.B * 3 * c.ntax : nullptr);
+               (a.tac_out && tslot >= 0) ? a.tac_out + (size_t)tslot * a.B * 3 * c.ntax : nullptr);
   __syncthreads();
   }
   if (valid) {
@@ -303,6 +305,7 @@ template <class R> struct BwdArgs {
   int seed_stride;        // sub-step j (0 = oldest of the n) carries direct loss partials iff (j + 1) % seed_stride == 0
   int frames;             // 0: seeds [B][n / seed_stride][.], df_du [B][n][nu] per sub-step (tsim_backward_steps)
                           // 1: seeds [n / seed_stride][B][.], df_du [n / seed_stride][B][nu] summed per env-step (tsim_backward_episode)
+  const int* tac_slot;    // frames mode: slot of frame f in df_dtac (< 0: no tactile seed), null: slot f
   const R* tape;
   const R *df_dq, *df_dvar, *df_dtac;
   R *lamq, *lamv, *df_du;
@@ -451,9 +454,12 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
     if (seeded) {
       const int fr = j / a.seed_stride;
       const size_t so = a.frames ? (size_t)fr * a.B + env : (size_t)env * (a.n / a.seed_stride) + fr;
+      const int tslot = (a.frames && a.tac_slot) ? a.tac_slot[fr] : 0;
+      const size_t sot = (a.frames && a.tac_slot) ? (size_t)max(tslot, 0) * a.B + env : so;
       if (a.df_dq && lane < nr) c.lamq[lane] += a.df_dq[so * nr + lane];
       __syncthreads();
-      output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, (a.df_dtac && ntac3) ? a.df_dtac + so * ntac3 : nullptr);
+      output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr,
+                      (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr);
     }
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.lamv[lane] / c.h;
     __syncthreads();
@@ -582,9 +588,9 @@ static LaunchShape launch_shape(const tsim_batch* b) {
   } while (0)
 
 template <class R>
-static int launch_forward(tsim_batch* b, const void* u, int nframes, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
+static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32_t* tac_slot, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
   FwdArgs<R> a;
-  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = tac_slot;
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
   a.prev = (R*)b->prev; a.has_prev = b->has_prev;
@@ -600,9 +606,9 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, int nsub, v
 }
 
 template <class R>
-static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, hipStream_t st) {
+static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, const int32_t* tac_slot, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, hipStream_t st) {
   BwdArgs<R> a;
-  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames; a.tac_slot = tac_slot;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du;
   TS_LAUNCH(k_backward, R, b, st, a);
@@ -726,8 +732,8 @@ int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd
   if (!u && b->nu > 0) return fail("step: u is null");
   if (b->record && b->t_cur + num_steps > b->cap) return fail("step: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
   HIPCHK(hipSetDevice(b->device));
-  int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, 1, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
-                                : launch_forward<double>(b, u, 1, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
+  int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, 1, nullptr, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
+                                : launch_forward<double>(b, u, 1, nullptr, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
   if (rc) return rc;
   if (b->record) b->t_cur += num_steps;
   b->has_prev = 1;
@@ -768,27 +774,27 @@ int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, 
   if (seed_mode != 0 && seed_mode != 1) return fail("backward_steps: bad seed_mode");
   HIPCHK(hipSetDevice(b->device));
   const int stride = seed_mode == 1 ? 1 : n;
-  int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, n, stride, 0, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
-                                : launch_backward<double>(b, n, stride, 0, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
+  int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, n, stride, 0, nullptr, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
+                                : launch_backward<double>(b, n, stride, 0, nullptr, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
   if (rc) return rc;
   b->t_cur -= n;
   return 0;
 }
 
-int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, void* stream) {
+int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, const int32_t* tactile_slot, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, void* stream) {
   if (num_frames <= 0 || num_steps <= 0) return fail("rollout: num_frames and num_steps must be positive");
   if (!u && b->nu > 0) return fail("rollout: u is null");
   if (b->record && b->t_cur + (long long)num_frames * num_steps > b->cap) return fail("rollout: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
   HIPCHK(hipSetDevice(b->device));
-  int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, num_frames, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
-                                : launch_forward<double>(b, u, num_frames, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
+  int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, num_frames, tactile_slot, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
+                                : launch_forward<double>(b, u, num_frames, tactile_slot, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
   if (rc) return rc;
   if (b->record) b->t_cur += num_frames * num_steps;
   b->has_prev = 1;
   return 0;
 }
 
-int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream) {
+int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const int32_t* tactile_slot, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream) {
   if (!b->record) return fail("backward_episode: reset(backward_flag=True) was not called");
   if (b->I[TSIM_IH_INTEGRATOR] != 1) return fail("backward_episode: the adjoint is implemented for BDF1 models only (the reference's BDF2 model, tactile_pad.xml, is forward-only)");
   if (num_frames <= 0 || num_steps <= 0) return fail("backward_episode: num_frames and num_steps must be positive");
@@ -796,8 +802,8 @@ int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const vo
   if (n > b->t_cur) return fail("backward_episode: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
   if (!df_du && b->nu > 0) return fail("backward_episode: df_du is null");
   HIPCHK(hipSetDevice(b->device));
-  int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, (int)n, num_steps, 1, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
-                                : launch_backward<double>(b, (int)n, num_steps, 1, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
+  int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, (int)n, num_steps, 1, tactile_slot, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
+                                : launch_backward<double>(b, (int)n, num_steps, 1, tactile_slot, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
   if (rc) return rc;
   b->t_cur -= (int)n;
   return 0;

@@ -7,6 +7,8 @@
   pinned by tests/test_protocol.py against a trace recorded from the reference's functions.
 * `BatchedStepSimFunction` — the MI355X-native counterpart: B environments per call, tensors stay on the device, one
   forward kernel launch per env-step and one adjoint launch per env-step (tactilesimulation_amd.host.BatchSim).
+* `BatchedEpisodicSimFunction` — batched counterpart of EpisodicSimFunction: the whole open-loop episode of B
+  environments in ONE forward launch and ONE adjoint launch (tsim_rollout / tsim_backward_episode).
 """
 import numpy as np
 import torch
@@ -141,3 +143,46 @@ class BatchedStepSimFunction(autograd.Function):
         if not ctx.need_du:
             return None, None, None, None
         return du.sum(dim=1).to(ctx.in_dtype), None, None, None
+
+
+class BatchedEpisodicSimFunction(autograd.Function):
+    """(q0[B, ndof_r], qdot0[B, ndof_r], actions[T, B, ndof_u], tactile_masks bool[T], batch_sim, grad_mode, num_steps=1)
+        -> qs[T, B, ndof_r], vars[T, B, ndof_var], tactiles[sum(mask), B, ndof_tactile]
+
+    Batched, device-resident counterpart of EpisodicSimFunction (envs/redmax_torch_functions.py:11-109): same argument
+    order and meaning with a batch axis after the time axis, the reference's `forward(1)` per action generalised to
+    `num_steps` sub-steps per action.  Like the reference it saves the tape on the backward cache in forward and pops it
+    in backward, so several episodes may be forwarded before their backward passes (newest first)."""
+
+    @staticmethod
+    def forward(ctx, q0, qdot0, actions, tactile_masks, sim, grad_mode, num_steps=1):
+        ctx.sim, ctx.T, ctx.num_steps = sim, int(actions.shape[0]), int(num_steps)
+        ctx.need = (q0.requires_grad, qdot0.requires_grad, actions.requires_grad)
+        ctx.in_dtype = actions.dtype
+        ctx.tactile_masks = tactile_masks
+        sim.reset(q0.detach(), qdot0.detach(), backward_flag=grad_mode)
+        out = sim.rollout(actions.detach(), ctx.num_steps, tactile_mask=tactile_masks)
+        qs, vars_, tacs = out["q"], out.get("var"), out.get("tactile")
+        if vars_ is None:
+            vars_ = qs.new_zeros((ctx.T, sim.B, 0))
+        if tacs is None:
+            tacs = qs.new_zeros((0, sim.B, 0))
+        ctx.status = out["status"]
+        if grad_mode:
+            sim.cache_save()
+        res = tuple(t.to(actions.dtype) for t in (qs, vars_, tacs))
+        if not grad_mode:
+            ctx.mark_non_differentiable(*res)
+        return res
+
+    @staticmethod
+    def backward(ctx, df_dq, df_dvar, df_dtactile):
+        sim = ctx.sim
+        sim.cache_pop()
+        du = sim.backward_episode(ctx.T, ctx.num_steps, df_dq, df_dvar if sim.ndof_var else None,
+                                  df_dtactile if (sim.ndof_tactile and df_dtactile.shape[0] > 0) else None,
+                                  tactile_mask=ctx.tactile_masks)
+        lq, lv = sim.get_adjoint()
+        g = (lq.to(ctx.in_dtype) if ctx.need[0] else None, lv.to(ctx.in_dtype) if ctx.need[1] else None,
+             du.to(ctx.in_dtype) if ctx.need[2] else None)
+        return g + (None, None, None, None)

@@ -114,9 +114,20 @@ class BatchSim:
                                         _ptr(o.get("tactile")), _ptr(o["status"]), self._stream()))
         return o
 
-    def rollout(self, u, num_steps=1, want_qd=False, want_var=True, want_tactile=True):
+    def _tactile_slots(self, T, tactile_mask):
+        """tactile_masks (bool[T]) of EpisodicSimFunction -> (device int32[T] slot map, number of masked frames)."""
+        if tactile_mask is None:
+            return None, T
+        m = torch.as_tensor(tactile_mask).to(device=self.device).reshape(-1).bool()
+        if m.numel() != T:
+            raise ValueError("tactile_mask: expected %d entries, got %d" % (T, m.numel()))
+        slots = torch.where(m, torch.cumsum(m.int(), 0) - 1, torch.full_like(m, -1, dtype=torch.int64)).to(torch.int32).contiguous()
+        return slots, int(m.sum().item())
+
+    def rollout(self, u, num_steps=1, want_qd=False, want_var=True, want_tactile=True, tactile_mask=None):
         """Open-loop episode in one launch (include/tsim.h tsim_rollout): u [T, B, ndof_u] -> dict of [T, B, dim] outputs
-        (+ status [B]); the same results as T calls of step()."""
+        (+ status [B]); the same results as T calls of step().  tactile_mask (bool[T]): tactile only for the masked
+        frames, output [n_masked, B, ndof_tactile]."""
         if u.dim() != 3 or u.shape[1] != self.B or u.shape[2] != self.ndof_u:
             raise ValueError("rollout: u must be [T, %d, %d], got %s" % (self.B, self.ndof_u, tuple(u.shape)))
         T = int(u.shape[0])
@@ -127,27 +138,32 @@ class BatchSim:
             o["qd"] = new(self.ndof_r)
         if want_var and self.ndof_var:
             o["var"] = new(self.ndof_var)
+        slots, nm = self._tactile_slots(T, tactile_mask)
         if want_tactile and self.ndof_tactile:
-            o["tactile"] = new(self.ndof_tactile)
-        capi.check(capi.lib().tsim_rollout(self._h, _ptr(u), T, int(num_steps), _ptr(o["q"]), _ptr(o.get("qd")), _ptr(o.get("var")),
-                                           _ptr(o.get("tactile")), _ptr(o["status"]), self._stream()))
+            o["tactile"] = torch.empty((nm, self.B, self.ndof_tactile), device=self.device, dtype=self.dtype)
+        capi.check(capi.lib().tsim_rollout(self._h, _ptr(u), T, int(num_steps), _ptr(slots), _ptr(o["q"]), _ptr(o.get("qd")),
+                                           _ptr(o.get("var")), _ptr(o.get("tactile")), _ptr(o["status"]), self._stream()))
         return o
 
-    def backward_episode(self, num_frames, num_steps, df_dq=None, df_dvar=None, df_dtactile=None):
-        """Adjoint of the newest num_frames env-steps (num_steps sub-steps each) in one launch. Seeds [T, B, dim] or None;
-        returns df_du [T, B, ndof_u] (gradient w.r.t. the action of each frame)."""
+    def backward_episode(self, num_frames, num_steps, df_dq=None, df_dvar=None, df_dtactile=None, tactile_mask=None):
+        """Adjoint of the newest num_frames env-steps (num_steps sub-steps each) in one launch. Seeds [T, B, dim] or None
+        (df_dtactile [n_masked, B, dim] with tactile_mask); returns df_du [T, B, ndof_u] (gradient w.r.t. the action of
+        each frame)."""
         T = int(num_frames)
+        slots, nm = self._tactile_slots(T, tactile_mask)
 
-        def chk(t, dim, name):
+        def chk(t, dim, name, n=T):
             if t is None or dim == 0:
                 return None
             t = t.to(device=self.device, dtype=self.dtype).contiguous()
-            if tuple(t.shape) != (T, self.B, dim):
-                raise ValueError("%s: expected [%d, %d, %d], got %s" % (name, T, self.B, dim, tuple(t.shape)))
+            if tuple(t.shape) != (n, self.B, dim):
+                raise ValueError("%s: expected [%d, %d, %d], got %s" % (name, n, self.B, dim, tuple(t.shape)))
             return t
-        a, b, c = chk(df_dq, self.ndof_r, "df_dq"), chk(df_dvar, self.ndof_var, "df_dvar"), chk(df_dtactile, self.ndof_tactile, "df_dtactile")
+        a, b = chk(df_dq, self.ndof_r, "df_dq"), chk(df_dvar, self.ndof_var, "df_dvar")
+        c = chk(df_dtactile, self.ndof_tactile, "df_dtactile", nm) if nm > 0 else None
         du = torch.empty((T, self.B, self.ndof_u), device=self.device, dtype=self.dtype)
-        capi.check(capi.lib().tsim_backward_episode(self._h, T, int(num_steps), _ptr(a), _ptr(b), _ptr(c), _ptr(du), self._stream()))
+        capi.check(capi.lib().tsim_backward_episode(self._h, T, int(num_steps), _ptr(slots), _ptr(a), _ptr(b), _ptr(c), _ptr(du),
+                                                    self._stream()))
         return du
 
     def get_state(self):

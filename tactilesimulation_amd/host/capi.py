@@ -25,8 +25,8 @@ _SIGS = {
     "tsim_get_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tsim_readout": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tsim_backward_steps": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
-    "tsim_rollout": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "tsim_backward_episode": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_rollout": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_backward_episode": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tsim_get_adjoint": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tsim_cache_save": (C.c_int, [_vp, _vp]), "tsim_cache_pop": (C.c_int, [_vp, _vp]), "tsim_cache_clear": (C.c_int, [_vp]),
     "tsim_debug_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

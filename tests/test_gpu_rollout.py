@@ -76,3 +76,42 @@ def test_episode_adjoint_matches_oracle(pusher_model):
         sq[S - 1::S], sv[S - 1::S], st[S - 1::S] = wq, wv, wt
         g = o.backward_steps(n, sq, sv, st).reshape(T, S, nu).sum(1)
         assert np.abs(du[:, e] - g).max() < 1e-4 * max(np.abs(g).max(), 1e-12)
+
+
+def test_batched_episodic_function_with_tactile_masks(pusher_model):
+    """BatchedEpisodicSimFunction (rows a3/a4 batched): masked tactile frames, dL/dq0, dL/dqdot0, dL/dactions against the
+    per-step entry points with zero seeds at the unmasked frames."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.functions import BatchedEpisodicSimFunction
+    B, T, S = 6, 9, 1                                   # forward(1) per action, as the reference's episodic function
+    q0_np, u_np, _ = push_workload(B, T, seed=12)
+    dev, dt = "cuda:0", torch.float64
+    mask = torch.tensor([0, 1, 1, 0, 0, 1, 0, 1, 0], dtype=torch.bool)
+    q0 = torch.tensor(q0_np, device=dev, dtype=dt, requires_grad=True)
+    qd0 = (0.05 * torch.randn(B, q0.shape[1], generator=torch.Generator().manual_seed(3))).to(dev, dt).requires_grad_(True)
+    act = torch.tensor(u_np, device=dev, dtype=dt).transpose(0, 1).contiguous().requires_grad_(True)
+    sim = BatchSim(pusher_model, B, dtype=dt, tape_capacity=T * S)
+    qs, vs, ts = BatchedEpisodicSimFunction.apply(q0, qd0, act, mask, sim, True, S)
+    assert qs.shape == (T, B, sim.ndof_r) and vs.shape == (T, B, sim.ndof_var) and ts.shape == (int(mask.sum()), B, sim.ndof_tactile)
+    g = torch.Generator().manual_seed(4)
+    wq, wv = torch.randn(qs.shape, generator=g).to(dev, dt), torch.randn(vs.shape, generator=g).to(dev, dt)
+    wt = (10 * torch.randn(ts.shape, generator=g)).to(dev, dt)
+    ((qs * wq).sum() + (vs * wv).sum() + (ts * wt).sum()).backward()
+
+    ref = BatchSim(pusher_model, B, dtype=dt, tape_capacity=T * S)
+    ref.reset(q0.detach(), qd0.detach(), backward_flag=True)
+    k = 0
+    for t in range(T):
+        o = ref.step(act.detach()[t], S)
+        assert torch.equal(o["q"], qs[t].detach()) and torch.equal(o["var"], vs[t].detach())
+        if mask[t]:
+            assert torch.equal(o["tactile"], ts[k].detach())
+            k += 1
+    du = torch.zeros_like(act)
+    slot = (torch.cumsum(mask.int(), 0) - 1).tolist()
+    for t in reversed(range(T)):
+        wtt = wt[slot[t]] if mask[t] else torch.zeros(B, sim.ndof_tactile, device=dev, dtype=dt)
+        du[t] = ref.backward_steps(S, wq[t], wv[t], wtt).sum(1)
+    lq, lv = ref.get_adjoint()
+    for got, want in ((act.grad, du), (q0.grad, lq), (qd0.grad, lv)):
+        assert float((got - want).abs().max()) <= 1e-11 * max(float(want.abs().max()), 1.0)
