@@ -115,3 +115,54 @@ def test_batched_episodic_function_with_tactile_masks(pusher_model):
     lq, lv = ref.get_adjoint()
     for got, want in ((act.grad, du), (q0.grad, lq), (qd0.grad, lv)):
         assert float((got - want).abs().max()) <= 1e-11 * max(float(want.abs().max()), 1.0)
+
+
+def _grasp_actions(gp, q0):
+    """The five-stage grasp of envs/stable_grasp_env.py:197-229 (move, close, lift + capture, put down, open) with
+    shorter stages: linearly interpolated joint-position targets [x, y, z, yaw, finger, finger]."""
+    lift, gh, fp = 0.2029862 + 0.03, 0.2029862, -0.008
+    tq = [q0[:6].copy()] + [np.array([0, gp, h, 0, f, f]) for h, f in ((gh, fp), (gh, fp), (lift, fp), (lift, fp), (gh, fp), (gh, fp), (gh, q0[4]))]
+    ns = [6, 3, 10, 4, 10, 3, 5]
+    return np.array([(tq[s + 1] - tq[s]) / ns[s] * (i + 1) + tq[s] for s in range(len(ns)) for i in range(ns[s])])
+
+
+@pytest.mark.parametrize("dtype,tq,tt", [(torch.float64, 1e-8, 1e-6), (torch.float32, 2e-4, 2e-2)])
+def test_stable_grasp_episode_matches_oracle(dtype, tq, tt):
+    """StableGrasp (stable_grasp.xml: 12 dofs, position-controlled gripper, 11 rigidly joined boxes, 2 pads): the env's
+    grasp episode through BatchedEpisodicSimFunction with a tactile capture mask, against the oracle frame by frame."""
+    import os
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.model import blob as Bl
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.functions import BatchedEpisodicSimFunction
+    from oracle.oracle import OracleSim
+    m = load_model(os.path.join(os.path.dirname(__file__), "golden", "models", "stable_grasp.npz"))
+    m.F[Bl.TSIM_FH_TOL] = 1e-12 if dtype == torch.float64 else 1e-8
+    gps = [0.0, 0.02, -0.035]
+    Bn = len(gps)
+    q0 = np.zeros((Bn, 12)); q0[:, 2] = 0.2; q0[:, 4] = q0[:, 5] = -0.03
+    acts = np.stack([_grasp_actions(g, q0[e]) for e, g in enumerate(gps)], axis=1)        # [T, B, 6]
+    T = acts.shape[0]
+    mask = torch.zeros(T, dtype=torch.bool); mask[14] = True; mask[21] = True
+    dev = "cuda:0"
+    sim = BatchSim(m, Bn, dtype=dtype, tape_capacity=1)
+    qs, _, tacs = BatchedEpisodicSimFunction.apply(torch.tensor(q0, device=dev, dtype=dtype), torch.zeros(Bn, 12, device=dev, dtype=dtype),
+                                                   torch.tensor(acts, device=dev, dtype=dtype), mask, sim, False, 1)
+    assert tacs.shape == (2, Bn, sim.ndof_tactile)
+    qs, tacs = qs.double().cpu().numpy(), tacs.double().cpu().numpy()
+    o = OracleSim(m)
+    lifted = 0.0
+    for e in range(Bn):
+        o.reset(q0[e])
+        k = 0
+        for t in range(T):
+            assert o.forward(acts[t, e], 1) == 0
+            q, _ = o.state()
+            assert np.abs(qs[t, e] - q).max() < tq, (e, t)
+            if mask[t]:
+                _, tac = o.outputs()
+                assert np.abs(tac).max() > 1e-3                                       # the pads do press on the object
+                assert np.abs(tacs[k, e] - tac).max() < tt * np.abs(tac).max(), (e, t)
+                k += 1
+            lifted = max(lifted, q[8])
+    assert lifted > 5e-3                                                               # the object left the table
