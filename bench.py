@@ -14,7 +14,7 @@ no data-path exchange (weak scaling); the only collective is the GD outer loop's
 (29 574 fp32 = 118 296 B), issued once per episode.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
-(the fp64 CPU oracle — this build's restatement, NOT DiffRedMax — on a bounded sample, 1 thread).
+(the fp64 CPU oracle — this build's restatement, NOT DiffRedMax — on a bounded sample, 1 thread and all host cores).
 """
 import argparse
 import json
@@ -266,7 +266,9 @@ def main():
 
 
 def cpu_baseline(model, S, with_backward):
-    """fp64 CPU oracle (oracle/tsim_oracle.cpp — the build's own restatement) on a bounded sample, 1 thread."""
+    """fp64 CPU oracle (oracle/tsim_oracle.cpp — the build's own restatement) on a bounded sample of the same workload:
+    one thread, and all host cores (environments are independent: one oracle instance per thread, ctypes releases the GIL)."""
+    import threading
     from oracle.oracle import OracleSim
     from tests.workloads import push_workload
     nenv, nstep = 8, 100
@@ -275,13 +277,34 @@ def cpu_baseline(model, S, with_backward):
     o.bench_rollout(q0[:1], u[:1, :5], S, with_backward)       # warm
     t0 = time.perf_counter()
     n, _ = o.bench_rollout(q0, u, S, with_backward)
-    dt = time.perf_counter() - t0
+    dt1 = time.perf_counter() - t0
     st = o.stats()
-    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d env-steps of the same TactilePush workload, %s, fp64, g++ -O3, 1 thread; "
-                      "mean Newton iterations/sub-step %.2f" % (nenv, nstep, "fwd+adjoint" if with_backward else "fwd only",
-                                                                st["newton_iters"] / max(st["substeps"], 1)),
-            "host_cpus": os.cpu_count()}
+    single = n / dt1
+    # all cores: 2 environments x 100 env-steps per thread
+    nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per = 2
+    q0m, um, _ = push_workload(per * nthr, nstep, seed=1)
+    sims = [OracleSim(model) for _ in range(nthr)]
+    done = [0] * nthr
+
+    def work(i):
+        done[i], _ = sims[i].bench_rollout(q0m[i * per:(i + 1) * per], um[i * per:(i + 1) * per], S, with_backward)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+    c0 = os.times()
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dtm = time.perf_counter() - t0
+    c1 = os.times()
+    busy = ((c1.user - c0.user) + (c1.system - c0.system)) / dtm      # cores actually kept busy (cgroup limits show here)
+    what = "fwd+adjoint" if with_backward else "fwd only"
+    return {"value": sum(done) / dtm, "unit": "env-steps/s", "cores": nthr, "kind": "port",
+            "sample": "%d threads x %d envs x %d env-steps of the same TactilePush workload, %s, fp64, g++ -O3 (one oracle instance "
+                      "per thread); single thread: %d envs x %d env-steps; mean Newton iterations/sub-step %.2f"
+                      % (nthr, per, nstep, what, nenv, nstep, st["newton_iters"] / max(st["substeps"], 1)),
+            "single_thread_value": single, "host_cpus": os.cpu_count(), "cores_busy": busy}
 
 
 if __name__ == "__main__":
