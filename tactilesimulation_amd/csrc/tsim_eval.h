@@ -178,8 +178,8 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
         dA = PdA + dAJ + crm(dV, VJ) + crm(V, dVJ);
         if (is_exp) dA = dA + (own ? dBexp : crm(dxi, Bvec));
         // inertial wrench  F = I A + V x* (I V);  d(I m) = dxi x* (I m) - I (dxi x m) + I dm
-        const S6<R> dh = crf(dxi, h) - imul(mass, cw, Ic, crm(dxi, V)) + imul(mass, cw, Ic, dV);
-        dF = crf(dxi, IA) - imul(mass, cw, Ic, crm(dxi, A)) + imul(mass, cw, Ic, dA) + crf(dV, h) + crf(V, dh);
+        const S6<R> dh = crf(dxi, h) + imul(mass, cw, Ic, dV - crm(dxi, V));
+        dF = crf(dxi, IA) + imul(mass, cw, Ic, dA - crm(dxi, A)) + crf(dV, h) + crf(V, dh);
       }
       st6(D + DT_VW, dV); st6(D + DT_AW, dA); st6(D + DT_FN, dF);
     }

@@ -268,14 +268,17 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
 // ================================================================================================ debug evaluation
 template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; };
 
-template <class R>
+template <class R, int LPE>
 __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
-  const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, 1, 0, lane, TS_WAVE, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
+  constexpr int NS = TS_WAVE / LPE;
+  const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
+  const bool valid = (int)blockIdx.x * NS + slot < a.B;
+  const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu;
-  init_world(c, lane, TS_WAVE);
+  init_world(c, lane, LPE);
   if (lane < nr) {
     c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane];
     c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane];
@@ -283,19 +286,20 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   }
   if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
   __syncthreads();
-  if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve
+  if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve; one row
+                 // per wavefront (the row of its first environment), the other rows stay zero
     c.stamps = a.cyc + (size_t)env * 32;
-    evaluate<R, 8, false, TS_WAVE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    evaluate<R, 8, false, LPE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
     if (lane < nr) c.rhs[lane] = -c.g[lane];
     __syncthreads();
-    solve_lanes<R, 8, TS_WAVE>(c.H, c.rhs, c.dq, nr, false, lane);
+    solve_lanes<R, 8, LPE>(c.H, c.rhs, c.dq, nr, false, lane);
     TS_STAMP(c);
-    if (lane == 0) for (int i = c.nstamp; i < 32; ++i) c.stamps[i] = 0;
+    if (lane == 0 && valid) for (int i = (slot == 0 ? c.nstamp : 0); i < 32; ++i) c.stamps[i] = 0;
   } else {
-    evaluate<R, 16, true, TS_WAVE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    evaluate<R, 16, true, LPE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
   }
-  if (lane < nr) a.g[(size_t)env * nr + lane] = c.g[lane];
-  for (int e = lane; e < nr * nr; e += TS_WAVE) a.H[(size_t)env * nr * nr + e] = c.H[e];
+  if (lane < nr && valid) a.g[(size_t)env * nr + lane] = c.g[lane];
+  if (valid) for (int e = lane; e < nr * nr; e += LPE) a.H[(size_t)env * nr * nr + e] = c.H[e];
 }
 
 // ================================================================================================ backward kernel
@@ -848,12 +852,21 @@ int tsim_cache_clear(tsim_batch* b) {
 
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u, void* g_out, void* H_out, long long* cycles, void* stream) {
   HIPCHK(hipSetDevice(b->device));
+  // one environment per wavefront, unless TSIM_LPE forces a packed shape for the cycle stamps (nr <= 8 models only)
+  const int lpe = (cycles && b->lpe_forced && !b->has_exp && b->nr <= 8) ? b->lpe_forced : TS_WAVE;
+  const int ns = TS_WAVE / lpe;
+  const dim3 grid((b->B + ns - 1) / ns), blk(TS_WAVE);
+  const size_t lds = lds_bytes_for(b, ns);
   if (b->dtype == TSIM_F32) {
     DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles};
-    hipLaunchKernelGGL(k_debug_eval<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
+    if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<float, 16>), grid, blk, lds, (hipStream_t)stream, a);
+    else if (lpe == 32) hipLaunchKernelGGL((k_debug_eval<float, 32>), grid, blk, lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_debug_eval<float, 64>), grid, blk, lds, (hipStream_t)stream, a);
   } else {
     DbgArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles};
-    hipLaunchKernelGGL(k_debug_eval<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
+    if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<double, 16>), grid, blk, lds, (hipStream_t)stream, a);
+    else if (lpe == 32) hipLaunchKernelGGL((k_debug_eval<double, 32>), grid, blk, lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_debug_eval<double, 64>), grid, blk, lds, (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());
   return 0;

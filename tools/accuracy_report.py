@@ -77,6 +77,7 @@ def phase_cycles(dtype, B=4096):
     for _ in range(3):
         g, H, cyc = sim.debug_eval(q1, q0, qd0, u, cycles=True)
     c = cyc.double().cpu().numpy()
+    c = c[c[:, 0] != 0]                     # packed shapes (TSIM_LPE): one stamped row per wavefront
     n = int((c[0] != 0).sum())
     d = np.diff(c[:, :n], axis=1).mean(0)
     # stamp order: start | phase1 | phase1t | per pair group: stage value, stage tangent, contacts, (fold ends at phase2 end) | phase3 | solve
