@@ -236,10 +236,123 @@ __device__ void pair_stage_tangent(const Ctx<R>& c, int pk, int slot, int lane, 
 }
 
 // ================================================================================================ phase 2
-// lanes = contact points of the staged pairs.  Value wrench and, per relevant direction, its tangent — both in the
-// primitive frame — are accumulated per lane over the pair's chunks and reduced once per pair.
+// lanes = contact points of the staged pairs.  Everything is linear in the 12 numbers that describe a direction for the
+// pair (relative displacement dth, drho and d(relative twist) dw, dv, primitive frame):
+//     dx  = dth x c + drho                      (c: material point, x: contact point — they differ for sphere-on-plane)
+//     dxd = dv + dw x x + wrel x dx
+//     dF  = Jx dx + Jv dxd ,   dn = dx x F + x x dF
+// so a lane accumulates, over its points, the value wrench (6) and the 6 x 12 matrix M with (dn; dF) = M (dth, drho, dw,
+// dv) — independent of the number of directions; one segmented reduction per pair; then lanes = directions apply M to
+// their own 12-vector.  (The first version evaluated dF, dn per point AND per direction: 7 x 54 FMA per point on
+// TactilePush against ~170 here.)
 template <class R, int NRM, int LPE>
-__device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
+__device__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane) {
+  const int nd = c.nd;
+  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+  const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+  const int pt0 = pi[TSIM_PI_PT0], npt = pi[TSIM_PI_NPT];
+  const int prim = pi[TSIM_PI_PRIM];
+  const bool sphere_plane = (pi[TSIM_PI_FLAGS] & 2) != 0;
+  R* S = c.PP + slot * PP_SIZE;
+  const M3<R> RPA = ldm(S + PP_RPA);
+  const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+  R w0[6], M[6][12];               // value wrench (n; F) and d(n; F) / d(dth, drho, dw, dv)
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    w0[e] = R(0);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) M[e][j] = R(0);
+  }
+  bool any_hit = false;
+  for (int base = 0; base < npt; base += LPE) {
+    const int pidx = base + lane;
+    bool hit = false;
+    V3<R> cP = zero3<R>(), xP = cP, F = cP;
+    M3<R> Jx, Jv;
+    if (pidx < npt) {
+      const R* cp = c.Fg + c.foff_cpt + pt0 + pidx;        // SoA: consecutive lanes -> consecutive addresses
+      cP = mulMv(RPA, mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt])) + pPA;
+      xP = cP;
+      if (sphere_plane) xP.z -= pf[TSIM_PF_SHAPE];         // lowest point of the sphere (plane normal = +z of P)
+      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv);
+    }
+    if (!__any(hit)) continue;
+    any_hit = true;
+    if (hit) {
+      const V3<R> n0 = cross3(xP, F);
+      w0[0] += n0.x; w0[1] += n0.y; w0[2] += n0.z; w0[3] += F.x; w0[4] += F.y; w0[5] += F.z;
+      // columns of dF:  d/d(drho) = K = Jx + Jv [wrel]x ;  d/d(dth) = -K [c]x ;  d/d(dw) = -Jv [x]x ;  d/d(dv) = Jv
+      // (row r of A [w]x is (A_r x w)^T)
+      V3<R> Kr[3], Ath[3], Aw[3], Jvr[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const V3<R> jv = mk3<R>(Jv.m[3 * r], Jv.m[3 * r + 1], Jv.m[3 * r + 2]);
+        Jvr[r] = jv;
+        Kr[r] = mk3<R>(Jx.m[3 * r], Jx.m[3 * r + 1], Jx.m[3 * r + 2]) + cross3(jv, wrel);
+        Ath[r] = cross3(cP, Kr[r]);                        // -(K_r x c)
+        Aw[r] = cross3(xP, jv);                            // -(Jv_r x x)
+      }
+      // dF rows as 12-vectors
+      R dFm[3][12];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        dFm[r][0] = Ath[r].x; dFm[r][1] = Ath[r].y; dFm[r][2] = Ath[r].z;
+        dFm[r][3] = Kr[r].x;  dFm[r][4] = Kr[r].y;  dFm[r][5] = Kr[r].z;
+        dFm[r][6] = Aw[r].x;  dFm[r][7] = Aw[r].y;  dFm[r][8] = Aw[r].z;
+        dFm[r][9] = Jvr[r].x; dFm[r][10] = Jvr[r].y; dFm[r][11] = Jvr[r].z;
+      }
+      // dn = x x dF - F x dx ,  dx = -[c]x dth + drho :   -F x dx has columns  F x (c x e_j)  (dth)  and  -(F x e_j)  (drho)
+      const R xx[3] = {xP.x, xP.y, xP.z};
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const R a0 = dFm[0][j], a1 = dFm[1][j], a2 = dFm[2][j];
+        M[0][j] += xx[1] * a2 - xx[2] * a1;
+        M[1][j] += xx[2] * a0 - xx[0] * a2;
+        M[2][j] += xx[0] * a1 - xx[1] * a0;
+        M[3][j] += a0; M[4][j] += a1; M[5][j] += a2;
+      }
+      // F x (c x e_j) = c (F.e_j) - e_j (F.c)
+      const R Fc = dot3(F, cP);
+      M[0][0] += cP.x * F.x - Fc; M[1][0] += cP.y * F.x;      M[2][0] += cP.z * F.x;
+      M[0][1] += cP.x * F.y;      M[1][1] += cP.y * F.y - Fc; M[2][1] += cP.z * F.y;
+      M[0][2] += cP.x * F.z;      M[1][2] += cP.y * F.z;      M[2][2] += cP.z * F.z - Fc;
+      // -(F x e_j):  j = x: (0, -Fz, Fy) ; y: (Fz, 0, -Fx) ; z: (-Fy, Fx, 0)
+      M[1][3] -= F.z; M[2][3] += F.y;
+      M[0][4] += F.z; M[2][4] -= F.x;
+      M[0][5] -= F.y; M[1][5] += F.x;
+    }
+  }
+  if (!any_hit) return;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    w0[e] = seg_sum<LPE>(w0[e]);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) M[e][j] = seg_sum<LPE>(M[e][j]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) S[PP_WN + e] = w0[e];
+  }
+  if (lane < nd) {                 // lanes = directions: (dn; dF) = M t, t = this direction's staged 12-vector
+    R* T = c.PT + (slot * nd + lane) * PT_SIZE;
+    R t[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) t[j] = T[j];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      R acc = R(0);
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc += M[e][j] * t[j];
+      T[PT_WN + e] = acc;
+    }
+  }
+}
+
+// The per-direction form: dF, dn evaluated per point and per relevant direction (54 FMA each), 6 (1 + directions)
+// accumulators.  Kept for fp64, where the 78 accumulators of the matrix form cost 156 registers and the kernel loses more
+// to spills than it gains (measured: 3.07 M vs 2.84 M env-steps/s at two environments per wavefront).
+template <class R, int NRM, int LPE>
+__device__ void pair_contacts_per_direction(const Ctx<R>& c, int pk, int slot, int lane) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
@@ -313,6 +426,12 @@ __device__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
       }
     }
   }
+}
+
+template <class R, int NRM, int LPE>
+__device__ __forceinline__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
+  if (sizeof(R) == 4) pair_contacts_matrix<R, NRM, LPE>(c, pk, slot, lane);
+  else pair_contacts_per_direction<R, NRM, LPE>(c, pk, slot, lane);
 }
 
 // lanes = directions: bring the staged pair's wrench (value + tangent k) to the world frame and fold it into the links

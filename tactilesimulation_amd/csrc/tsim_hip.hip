@@ -556,20 +556,31 @@ static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
 }
 // Launch shape of the forward / backward kernels.
 // Lanes per environment (LPE): one environment per wavefront uses <= nr of the 64 lanes in most phases; packing 2 or 4
-// environments into a wavefront divides the instruction count per environment — as long as enough wavefronts remain
-// to give every SIMD one (the smallest LPE with B / (64 / LPE) >= #SIMDs), and at least 4 blocks' LDS fit a CU.
-// These kernels use ~270 registers, i.e. one wavefront per SIMD; holding them to 256 for two per SIMD spills and is
-// slower at every batch size measured (profiles/r01_launch_shape_ab.txt), larger batches simply run in rounds.
+// environments into a wavefront divides the instruction count per environment.  These kernels hold one wavefront per
+// SIMD (~270 registers; holding them to 256 for two per SIMD spills and is slower at every batch size measured,
+// profiles/r01_launch_shape_ab.txt) and a lone wavefront is latency-bound, so the time of a launch is
+//     rounds x latency(LPE),   rounds = ceil(wavefronts / #SIMDs),   latency(64 : 32 : 16) ~ 1 : 1.07 : 1.13
+// (phase stamps, tools/phase_cycles.py).  The launch takes the LPE that minimises it, subject to the block's LDS
+// leaving room for four blocks per CU.
 struct LaunchShape { int lpe; unsigned grid; size_t lds; };
 static LaunchShape launch_shape(const tsim_batch* b) {
   LaunchShape L;
   int lpe = b->lpe_forced;
+  const size_t lds_cap = b->lpe_forced ? 64 * 1024 : 40 * 1024;
   if (!lpe) {
     lpe = TS_WAVE;
-    while (lpe > 16 && (long long)b->B * (lpe / 2) / TS_WAVE >= b->n_simd) lpe /= 2;
+    double best = 1e30;
+    const int cand[3] = {64, 32, 16};
+    const double lat[3] = {1.0, 1.07, 1.13};
+    for (int i = 0; i < 3; ++i) {
+      const int ns = TS_WAVE / cand[i];
+      if (i > 0 && lds_bytes_for(b, ns) > lds_cap) break;
+      const long long waves = ((long long)b->B + ns - 1) / ns;
+      const double t = (double)((waves + b->n_simd - 1) / b->n_simd) * lat[i];
+      if (t < best) { best = t; lpe = cand[i]; }
+    }
   }
   if (b->has_exp) lpe = TS_WAVE;
-  const size_t lds_cap = b->lpe_forced ? 64 * 1024 : 40 * 1024;
   while (lpe < TS_WAVE && lds_bytes_for(b, TS_WAVE / lpe) > lds_cap) lpe *= 2;
   L.lpe = lpe;
   const int ns = TS_WAVE / lpe;
