@@ -253,6 +253,7 @@ template <class R> struct Ctx {
   R *qp, *qdp, *qm1, *qdm1;               // predictor of the implicit step; state before the previous sub-step (BDF2)
   R *expw;                                // rotation-vector joint: d W_m / d theta_k, 9 x 6 reals
   R *LP, *WP, *DT, *PP, *PT, *scr;
+  const int* LI;                          // sweep schedule + per-link int records in LDS (ts_sched layout below)
   long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
   mutable int nstamp;
 };
@@ -274,9 +275,19 @@ __host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu) {
 }
 // LDS reals of a block of nslot environments. nfrec: leading reals of the model blob that are staged in LDS (everything
 // except the per-point SoA arrays); one copy per block, or one per slot with per-environment tables.
-__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int nslot, bool env_tables) {
-  return (env_tables ? nslot : 1) * (nfrec + 2) + nslot * ts_lds_env_reals(nl, nr, nu) + 8;
+__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int nslot, bool env_tables, int nsched, int esz) {
+  return (env_tables ? nslot : 1) * (nfrec + 2) + ((nsched * 4 + esz - 1) / esz + 3) / 4 * 4 + nslot * ts_lds_env_reals(nl, nr, nu) + 8;
 }
+
+// Sweep schedule (built on the host from the link parents, appended to the device copy of the int blob at I[TSIM_IH_NI]):
+// the links of different root branches (sub-trees hanging off the world) are independent in the root->leaf sweep, so
+// lane k < nr walks only the links of the branch of its own dof k — all branches advance together, and the sweep takes
+// max(branch size) steps instead of nl.
+//   S[0] = number of ints, S[1] = steps, S[2 + l] = branch of lane l (l < 16; -1: lane has no dof),
+//   S[TS_SCHED_ENT + step * 16 + l] = link visited by lane l at that step | leader << 8 (0: none; the leader lane of a
+//   branch stores the link's value record), then per link 8 ints: parent, joint type, dof0, ndof, ancestor mask, branch.
+enum { TS_SCHED_BRANCH = 2, TS_SCHED_ENT = 18, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
+__device__ __forceinline__ int ts_sched_rec(const int* S) { return TS_SCHED_ENT + S[1] * 16; }
 
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
@@ -294,6 +305,14 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
     } else {
       for (int i = threadIdx.x; i < nfrec; i += TS_WAVE) mf[i] = F[i];
       lds += nfrec + 2;
+    }
+    {                                            // sweep schedule + link int records (one copy per block)
+      const int* S = I + I[TSIM_IH_NI];
+      const int ns = S[0];
+      int* li = reinterpret_cast<int*>(lds);
+      for (int i = threadIdx.x; i < ns; i += TS_WAVE) li[i] = S[i];
+      c.LI = li;
+      lds += ((ns * 4 + (int)sizeof(R) - 1) / (int)sizeof(R) + 3) / 4 * 4;
     }
     __syncthreads();
     c.Fg = F; c.F = mf; c.I = I;
@@ -338,7 +357,7 @@ template <class R> __device__ inline void init_world(const Ctx<R>& c, int lane, 
     if (i == LK_AV + 2) v = -c.gz;
     c.LP[i] = v;
   }
-  for (int i = lane; i < c.nd * DT_SIZE; i += lpe) c.DT[i] = R(0);
+  for (int i = lane; i < (c.nl + 1) * c.nd * DT_SIZE; i += lpe) c.DT[i] = R(0);    // incl. the (link, dof) records no sweep writes
 }
 
 __device__ __forceinline__ int anc_of(const int* I, int off_link, int link) {

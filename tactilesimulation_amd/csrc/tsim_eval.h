@@ -12,26 +12,40 @@
 #include "tsim_device.h"
 
 // ================================================================================================ phase 1 (+ 1t)
-// One root -> leaf sweep does both the values (every lane computes the same numbers, lane 0 stores them) and, on
-// lanes k < nr, the tangents w.r.t. dof k (seeds: q_k += eps*sq, qd_k += eps*sv, qdd_k += eps*sa).
-// The parent's state is carried in registers when the parent is the previous link of the sweep (chains) or the world,
-// so the common case has no LDS round trip and no barrier inside the sweep.
+// One root -> leaf sweep does both the values and, on lanes k < nr, the tangents w.r.t. dof k (seeds: q_k += eps*sq,
+// qd_k += eps*sv, qdd_k += eps*sa).  Lane k walks the links of the root branch of its dof k only (ts_sched in
+// tsim_device.h): the branches advance together, one link per step; every lane of a branch computes that link's values
+// (the branch's leader lane stores them), its own tangent, and carries the parent's state in registers when the parent
+// is the link it processed in the previous step (chains), so the common case has no LDS round trip.
 template <class R, bool TANGENT, bool EXPJ>
 __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   const int k = lane, nd = c.nd;
   const bool act = TANGENT && lane < c.nr;
-  M3<R> pR; V3<R> pp; S6<R> pV, pA, pdV, pdA;        // state of the previously processed link
+  const int* S = c.LI;
+  const int nsteps = S[1], rec0 = ts_sched_rec(S);
+  const int l16 = lane & 15;
+  const int mybranch = lane < 16 ? S[TS_SCHED_BRANCH + l16] : -1;
+  if (act) {                                         // wrench tangents of the links outside this lane's branch start at zero
+    for (int i = 1; i <= c.nl; ++i)                  // (contacts couple branches: phase 2 adds to them)
+      if (S[rec0 + (i - 1) * TS_LR_SIZE + TS_LR_BRANCH] != mybranch) st6(c.DT + (i * nd + k) * DT_SIZE + DT_FN, zero6<R>());
+  }
+  M3<R> pR; V3<R> pp; S6<R> pV, pA, pdV, pdA;        // state of the link this lane processed in the previous step
   S6<R> Wk = zero6<R>();                             // twist column of this lane's own dof, once its link has been swept
   pR = ldm(c.LP + LK_R); pp = zero3<R>(); pV = zero6<R>(); pA = zero6<R>(); pdV = zero6<R>(); pdA = zero6<R>();
-  for (int i = 1; i <= c.nl; ++i) {
-    const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
+  int prev = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    __syncthreads();                                 // value records stored by the leaders in the previous step
+    const int ent = lane < 16 ? S[TS_SCHED_ENT + st * 16 + l16] : 0;
+    const int i = ent & 0xff;
+    const bool leader = (ent >> 8) != 0;
+    if (i == 0) continue;
+    const int* li = S + rec0 + (i - 1) * TS_LR_SIZE;
     const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
-    const int par = li[TSIM_LI_PARENT], jt = li[TSIM_LI_JTYPE], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
+    const int par = li[TS_LR_PARENT], jt = li[TS_LR_JTYPE], k0 = li[TS_LR_DOF0], ndj = li[TS_LR_NDOF], ancm = li[TS_LR_ANCMASK];
     R* X = c.LP + i * LK_SIZE;
     M3<R> PR; V3<R> Pp; S6<R> PV, PA, PdV = zero6<R>(), PdA = zero6<R>();
-    if (par == i - 1 && i > 1) { PR = pR; Pp = pp; PV = pV; PA = pA; PdV = pdV; PdA = pdA; }
+    if (par == prev && par > 0) { PR = pR; Pp = pp; PV = pV; PA = pA; PdV = pdV; PdA = pdA; }
     else {
-      if (par > 0) __syncthreads();                 // a non-adjacent parent was stored by lane 0 earlier in this sweep
       const R* P = c.LP + par * LK_SIZE;
       PR = ldm(P + LK_R); Pp = ldv(P + LK_P); PV = ld6(P + LK_W); PA = ld6(P + LK_AW);
       if (act && par > 0) { const R* Dp = c.DT + (par * nd + k) * DT_SIZE; PdV = ld6(Dp + DT_VW); PdA = ld6(Dp + DT_AW); }
@@ -86,7 +100,7 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
         for (int m = 0; m < 3; ++m) {
           const V3<R> bm = mulMv(R0, mk3<R>(JL[m].d[kk].v, JL[3 + m].d[kk].v, JL[6 + m].d[kk].v));
           dWm[m] = mk6<R>(bm, cross3(Xp, bm));
-          if (lane == 0) st6(c.expw + (m * 3 + kk) * 6, dWm[m]);
+          if (leader) st6(c.expw + (m * 3 + kk) * 6, dWm[m]);
         }
         if (k == k0 + kk) {
           dWexp[0] = dWm[0]; dWexp[1] = dWm[1]; dWexp[2] = dWm[2];
@@ -146,7 +160,7 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
     Ic[5] = T.m[3] * XR.m[6] + T.m[4] * XR.m[7] + T.m[5] * XR.m[8];
     const R mass = lf[TSIM_LF_MASS];
     const S6<R> h = imul(mass, cw, Ic, V), IA = imul(mass, cw, Ic, A);
-    if (lane == 0) {
+    if (leader) {
       stm(X + LK_R, XR); stv(X + LK_P, Xp); st6(X + LK_W, V); st6(X + LK_AW, A); st6(X + LK_FN, IA + crf(V, h));
       stv(X + LK_C, cw);
 #pragma unroll
@@ -158,7 +172,7 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
     if (act) {
       R* D = c.DT + (i * nd + k) * DT_SIZE;
       S6<R> dF = zero6<R>();
-      if ((li[TSIM_LI_ANCMASK] >> k) & 1) {          // dof k moves link i
+      if ((ancm >> k) & 1) {                         // dof k moves link i
         // W_k: this joint's column, or an ancestor's column saved in this lane's registers when its link was swept
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) if (k == k0 + kk && kk < ndj) Wk = Wj[kk];
@@ -183,7 +197,7 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
       }
       st6(D + DT_VW, dV); st6(D + DT_AW, dA); st6(D + DT_FN, dF);
     }
-    pR = XR; pp = Xp; pV = V; pA = A; pdV = dV; pdA = dA;
+    pR = XR; pp = Xp; pV = V; pA = A; pdV = dV; pdA = dA; prev = i;
   }
   __syncthreads();
 }

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "../../include/tsim.h"
@@ -515,13 +516,55 @@ struct tsim_batch {
   int has_exp;                   // model contains a rotation-vector joint
   int t_cur, record;
   int lpe_forced;                // lanes per environment forced by TSIM_LPE (0 = choose from the batch size)
+  int nsched;                    // ints of the sweep schedule appended to dI
   int n_simd;                    // SIMDs of the device (CUs x 4)
   size_t esz;
   std::vector<CacheEntry> cache;
 };
 
+// sweep schedule of the link tree (layout: ts_sched in tsim_device.h)
+static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
+  const int nl = I[TSIM_IH_NL], nr = I[TSIM_IH_NR], ol = I[TSIM_IH_OFF_LINK];
+  std::vector<int> parent(nl + 1, 0), branch(nl + 1, -1), dof_link(nr, 0);
+  std::vector<std::vector<int>> links;                       // links of each root branch, parents before children
+  for (int i = 1; i <= nl; ++i) {
+    const int32_t* li = &I[ol + (i - 1) * TSIM_LI_SIZE];
+    parent[i] = li[TSIM_LI_PARENT];
+    if (parent[i] == 0) { branch[i] = (int)links.size(); links.emplace_back(); }
+    else branch[i] = branch[parent[i]];
+    links[branch[i]].push_back(i);
+    for (int k = li[TSIM_LI_DOF0]; k < li[TSIM_LI_DOF0] + li[TSIM_LI_NDOF]; ++k) dof_link[k] = i;
+  }
+  int nsteps = 0;
+  for (auto& l : links) nsteps = std::max(nsteps, (int)l.size());
+  std::vector<int> leader(links.size(), -1);                 // lowest dof lane of each branch
+  for (int k = nr - 1; k >= 0; --k) leader[branch[dof_link[k]]] = k;
+  std::vector<int32_t> S(TS_SCHED_ENT + nsteps * 16 + nl * TS_LR_SIZE, 0);
+  S[0] = (int32_t)S.size(); S[1] = nsteps;
+  for (int l = 0; l < 16; ++l) S[TS_SCHED_BRANCH + l] = l < nr ? branch[dof_link[l]] : -1;
+  for (int st = 0; st < nsteps; ++st)
+    for (int l = 0; l < nr && l < 16; ++l) {
+      const int br = branch[dof_link[l]];
+      if (st < (int)links[br].size()) S[TS_SCHED_ENT + st * 16 + l] = links[br][st] | ((leader[br] == l) ? 0x100 : 0);
+    }
+  const int rec0 = TS_SCHED_ENT + nsteps * 16;
+  for (int i = 1; i <= nl; ++i) {
+    const int32_t* li = &I[ol + (i - 1) * TSIM_LI_SIZE];
+    int32_t* r = &S[rec0 + (i - 1) * TS_LR_SIZE];
+    r[TS_LR_PARENT] = li[TSIM_LI_PARENT]; r[TS_LR_JTYPE] = li[TSIM_LI_JTYPE]; r[TS_LR_DOF0] = li[TSIM_LI_DOF0];
+    r[TS_LR_NDOF] = li[TSIM_LI_NDOF]; r[TS_LR_ANCMASK] = li[TSIM_LI_ANCMASK]; r[TS_LR_BRANCH] = branch[i];
+  }
+  return S;
+}
+
 static int upload_model(tsim_batch* b, hipStream_t st) {
   HIPCHK(hipMemcpyAsync(b->dI, b->I.data(), b->I.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  {
+    const std::vector<int32_t> S = build_sched(b->I);        // appended to the device copy at I[TSIM_IH_NI]
+    if ((int)S.size() != b->nsched) return fail("sweep schedule size changed");
+    HIPCHK(hipMemcpyAsync(b->dI + b->I.size(), S.data(), S.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   if (b->dtype == TSIM_F32) {
     std::vector<float> f(b->F.begin(), b->F.end());
     HIPCHK(hipMemcpyAsync(b->dF, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -551,7 +594,7 @@ template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, i
 
 // dynamic LDS of a block of nslot environments
 static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
-  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, nslot, b->dFenv != nullptr);
+  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, nslot, b->dFenv != nullptr, b->nsched, (int)b->esz);
   return ((size_t)reals * b->esz + 15) / 16 * 16;
 }
 // Launch shape of the forward / backward kernels.
@@ -662,6 +705,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->t_cur = 0; b->record = 0; b->has_exp = n_exp > 0;
   b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT];
   b->lpe_forced = 0;
+  b->nsched = (int)build_sched(b->I).size();
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
   {
     int cus = 0;
@@ -670,7 +714,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   }
   if (lds_bytes_for(b, 1) > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
-  if (hipMalloc(&b->dI, b->I.size() * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
+  if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
       hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * b->esz) != hipSuccess) {
     tsim_batch_destroy(b);
