@@ -284,9 +284,11 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, i
 // lane k < nr walks only the links of the branch of its own dof k — all branches advance together, and the sweep takes
 // max(branch size) steps instead of nl.
 //   S[0] = number of ints, S[1] = steps, S[2 + l] = branch of lane l (l < 16; -1: lane has no dof),
+//   S[18 + b] = leader lane of branch b, S[34] = number of branches,
 //   S[TS_SCHED_ENT + step * 16 + l] = link visited by lane l at that step | leader << 8 (0: none; the leader lane of a
 //   branch stores the link's value record), then per link 8 ints: parent, joint type, dof0, ndof, ancestor mask, branch.
-enum { TS_SCHED_BRANCH = 2, TS_SCHED_ENT = 18, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
+// The leaf->root projection (phase 3) uses the same lists backwards, one lane per (direction, branch).
+enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_ENT = 36, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
 __device__ __forceinline__ int ts_sched_rec(const int* S) { return TS_SCHED_ENT + S[1] * 16; }
 
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]

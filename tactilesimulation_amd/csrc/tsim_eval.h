@@ -500,44 +500,53 @@ __device__ void phase2(const Ctx<R>& c, int lane, R sq) {
 // column k).  Both are scaled by h^2.
 template <class R, bool EXPJ, int LPE>
 __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
-  const int nd = c.nd, k = lane, nr = c.nr;
+  const int nd = c.nd, nr = c.nr;
   const bool act = lane < nr;
   const R h2 = R(1) / c.ca;      // g = r / ca  (BDF1: h^2 r)
-  const S6<R> Wk = act ? ld6(c.WP + k * 6) : zero6<R>();
-  // A child's subtree wrench is handed to its parent in registers when the parent is the next link of the sweep
-  // (chains); only branching parents go through LDS (+ one barrier).
-  S6<R> cF = zero6<R>(), cdF = zero6<R>();
-  int carry_to = -1;
-  for (int i = c.nl; i >= 1; --i) {
-    const int* li = c.I + c.off_link + (i - 1) * TSIM_LI_SIZE;
-    const int par = li[TSIM_LI_PARENT], k0 = li[TSIM_LI_DOF0], ndj = li[TSIM_LI_NDOF];
-    S6<R> F = ld6(c.LP + i * LK_SIZE + LK_FN);
-    S6<R> dF = act ? ld6(c.DT + (i * nd + k) * DT_SIZE + DT_FN) : zero6<R>();
-    if (carry_to == i) { F = F + cF; dF = dF + cdF; }
-    if (act) {
-      const bool moves = (li[TSIM_LI_ANCMASK] >> k) & 1;
+  // One lane per (direction k, root branch b): it sweeps the links of branch b leaf -> root for direction k (the
+  // branches are independent here too; contacts coupled them in phase 2 already).  A child's subtree wrench is handed to
+  // its parent in registers when the parent is the next link of the lane's sweep (chains); only branching parents go
+  // through LDS.
+  const int* S = c.LI;
+  const int nsteps = S[1], rec0 = ts_sched_rec(S), ntask = S[TS_SCHED_NB] * nr;
+  for (int t0 = 0; t0 < ntask; t0 += LPE) {
+    const int t = t0 + lane;
+    const bool has = t < ntask;
+    const int b = has ? t / nr : 0, k = has ? t - b * nr : 0;
+    const int col = S[TS_SCHED_LEADER + b];
+    const S6<R> Wk = ld6(c.WP + k * 6);
+    S6<R> cF = zero6<R>(), cdF = zero6<R>();
+    int carry_to = -1;
+    for (int st = nsteps - 1; st >= 0; --st) {
+      __syncthreads();                               // wrenches folded into branching parents in the previous step
+      const int i = has ? (S[TS_SCHED_ENT + st * 16 + col] & 0xff) : 0;
+      if (i == 0) continue;
+      const int* li = S + rec0 + (i - 1) * TS_LR_SIZE;
+      const int par = li[TS_LR_PARENT], k0 = li[TS_LR_DOF0], ndj = li[TS_LR_NDOF];
+      S6<R> F = ld6(c.LP + i * LK_SIZE + LK_FN);
+      S6<R> dF = ld6(c.DT + (i * nd + k) * DT_SIZE + DT_FN);
+      if (carry_to == i) { F = F + cF; dF = dF + cdF; }
+      const bool moves = (li[TS_LR_ANCMASK] >> k) & 1;
       for (int j = k0; j < k0 + ndj; ++j) {
         const S6<R> Wj = ld6(c.WP + j * 6);
         R dtau = dot6(Wj, dF);
         if (moves) {
-          const bool same_exp = EXPJ && li[TSIM_LI_JTYPE] == TSIM_J_SPHERICAL_EXP && k >= k0 && k < k0 + ndj;
+          const bool same_exp = EXPJ && li[TS_LR_JTYPE] == TSIM_J_SPHERICAL_EXP && k >= k0 && k < k0 + ndj;
           const S6<R> dW = same_exp ? ld6(c.expw + ((j - k0) * 3 + (k - k0)) * 6) : crm(Wk, Wj);
           dtau += sq * dot6(dW, F);
         }
         c.H[j * nr + k] = dtau;
-        if (lane == 0) c.g[j] = dot6(Wj, F);
+        if (k == 0) c.g[j] = dot6(Wj, F);
+      }
+      if (par > 0) {
+        const int nxt = st > 0 ? (S[TS_SCHED_ENT + (st - 1) * 16 + col] & 0xff) : 0;
+        if (par == nxt) { cF = F; cdF = dF; carry_to = par; }
+        else {
+          acc6(c.DT + (par * nd + k) * DT_SIZE + DT_FN, dF, R(1));
+          if (k == 0) acc6(c.LP + par * LK_SIZE + LK_FN, F, R(1));
+        }
       }
     }
-    bool via_lds = false;
-    if (par > 0) {
-      if (par == i - 1) { cF = F; cdF = dF; carry_to = par; }
-      else {
-        via_lds = true;
-        if (act) acc6(c.DT + (par * nd + k) * DT_SIZE + DT_FN, dF, R(1));
-        if (lane == 0) acc6(c.LP + par * LK_SIZE + LK_FN, F, R(1));
-      }
-    }
-    if (via_lds) __syncthreads();
   }
   __syncthreads();
   // joint-space forces: damping, limits (lanes = dofs), then motors

@@ -542,6 +542,8 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
   std::vector<int32_t> S(TS_SCHED_ENT + nsteps * 16 + nl * TS_LR_SIZE, 0);
   S[0] = (int32_t)S.size(); S[1] = nsteps;
   for (int l = 0; l < 16; ++l) S[TS_SCHED_BRANCH + l] = l < nr ? branch[dof_link[l]] : -1;
+  for (size_t b = 0; b < links.size() && b < 16; ++b) S[TS_SCHED_LEADER + b] = leader[b];
+  S[TS_SCHED_NB] = (int32_t)links.size();
   for (int st = 0; st < nsteps; ++st)
     for (int l = 0; l < nr && l < 16; ++l) {
       const int br = branch[dof_link[l]];
