@@ -1,5 +1,9 @@
 // tsim_device.h — device-side building blocks of the batched tactile-simulation step (gfx950 / CDNA4).
 //
+// Every device function here and in tsim_eval.h is __forceinline__: a kernel is one function.  (Out-of-line calls would
+// pass the LDS pointers of Ctx as flat pointers — slower, and a backend assertion in this toolchain; the AMDGPU inliner
+// stops inlining into callers above a basic-block budget unless told so explicitly.)
+//
 // Execution model: block = ONE 64-LANE WAVEFRONT that carries 64 / LPE ENVIRONMENTS ("slots") of LPE = 64, 32 or 16
 // lanes each (template parameter; chosen per launch from the batch size).  An environment's reduced state (q, qd),
 // the per-link world transforms / spatial velocities / wrenches and the Newton matrix live in the slot's LDS region
@@ -290,10 +294,14 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, i
 // The leaf->root projection (phase 3) uses the same lists backwards, one lane per (direction, branch).
 enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_ENT = 36, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
 __device__ __forceinline__ int ts_sched_rec(const int* S) { return TS_SCHED_ENT + S[1] * 16; }
+// ... followed by a copy of the contact-pair int records (TSIM_PI_*), for the lanes = pairs staging of phase 2
+template <class C> __device__ __forceinline__ const int* ts_pair_rec(const C& c, int pk) {
+  return c.LI + ts_sched_rec(c.LI) + c.nl * TS_LR_SIZE + pk * TSIM_PI_SIZE;
+}
 
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
-template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, const R* Fenv = nullptr) {
+template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, const R* Fenv = nullptr) {
   // Stage the model's FLOAT tables in LDS (link / dof / motor / pair / sensor records): later reads are ds_read
   // broadcasts instead of ~500-cycle global loads.  The INT tables stay in global memory on purpose: they are
   // wave-uniform, so they travel through the scalar cache and all indexing / control flow stays on the SALU.
@@ -350,7 +358,7 @@ template <class R> __device__ inline void ctx_init(Ctx<R>& c, const int* I, cons
 }
 
 // world link: identity pose, zero velocity, gravity as base acceleration, zero wrench; all tangents zero.
-template <class R> __device__ inline void init_world(const Ctx<R>& c, int lane, int lpe) {
+template <class R> __device__ __forceinline__ void init_world(const Ctx<R>& c, int lane, int lpe) {
   for (int i = lane; i < LK_SIZE; i += lpe) {
     R v = R(0);
     if (i == 0 || i == 4 || i == 8) v = R(1);

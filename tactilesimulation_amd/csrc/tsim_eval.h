@@ -18,7 +18,7 @@
 // (the branch's leader lane stores them), its own tangent, and carries the parent's state in registers when the parent
 // is the link it processed in the previous step (chains), so the common case has no LDS round trip.
 template <class R, bool TANGENT, bool EXPJ>
-__device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+__device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   const int k = lane, nd = c.nd;
   const bool act = TANGENT && lane < c.nr;
   const int* S = c.LI;
@@ -203,10 +203,11 @@ __device__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
 }
 
 // ================================================================================================ staged pairs
-// value record of pair pk in slot: pose of A in the primitive frame, relative twist (A w.r.t. B) in that frame
+// value record of pair pk in slot: pose of A in the primitive frame, relative twist (A w.r.t. B) in that frame.
+// pk may differ between lanes (lanes = pairs in phase 2); `store`: this lane writes the record.
 template <class R>
-__device__ void pair_stage_value(const Ctx<R>& c, int pk, int slot, int lane) {
-  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+__device__ __forceinline__ void pair_stage_value(const Ctx<R>& c, int pk, int slot, bool store) {
+  const int* pi = ts_pair_rec(c, pk);
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
   const R* A = c.LP + pi[TSIM_PI_LINKA] * LK_SIZE;
   const R* B = c.LP + pi[TSIM_PI_LINKB] * LK_SIZE;
@@ -216,24 +217,26 @@ __device__ void pair_stage_value(const Ctx<R>& c, int pk, int slot, int lane) {
   const M3<R> RPA = mulMtM(RP, ldm(A + LK_R));
   const V3<R> pPA = mulMtv(RP, ldv(A + LK_P) - pP);
   const S6<R> Vrel = to_frame(RP, pP, ld6(A + LK_W) - ld6(B + LK_W));
-  if (lane == 0) {
+  if (store) {
     R* S = c.PP + slot * PP_SIZE;
     stm(S + PP_RPA, RPA); stv(S + PP_PPA, pPA); st6(S + PP_WREL, Vrel); stm(S + PP_RP, RP); stv(S + PP_PP, pP);
     st6(S + PP_WN, zero6<R>());
   }
 }
-// per-direction record (lane = direction k): relative displacement and d(relative twist), both in the primitive frame.
+// per-direction record of (pair pk, direction k): relative displacement and d(relative twist), both in the primitive
+// frame.  pk and k may differ between lanes (lanes = (pair, direction) in phase 2).
 // vmode 0: tangents of the current seeds (link records DT);  vmode 1: d/d(qd_k) only (d twist = W_k, poses fixed).
 template <class R>
-__device__ void pair_stage_tangent(const Ctx<R>& c, int pk, int slot, int lane, R sq, int vmode) {
-  const int k = lane, nd = c.nd;
+__device__ __forceinline__ void pair_stage_tangent(const Ctx<R>& c, int pk, int slot, int k, R sq, int vmode) {
+  const int nd = c.nd;
   if (k >= c.nr) return;
-  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+  const int* pi = ts_pair_rec(c, pk);
   const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB];
   const R* S = c.PP + slot * PP_SIZE;
   R* T = c.PT + (slot * nd + k) * PT_SIZE;
-  const R inA = ((anc_of(c.I, c.off_link, la) >> k) & 1) ? R(1) : R(0);
-  const R inB = ((anc_of(c.I, c.off_link, lb) >> k) & 1) ? R(1) : R(0);
+  const int* LR = c.LI + ts_sched_rec(c.LI);
+  const R inA = (la > 0 && ((LR[(la - 1) * TS_LR_SIZE + TS_LR_ANCMASK] >> k) & 1)) ? R(1) : R(0);
+  const R inB = (lb > 0 && ((LR[(lb - 1) * TS_LR_SIZE + TS_LR_ANCMASK] >> k) & 1)) ? R(1) : R(0);
   const M3<R> RP = ldm(S + PP_RP);
   const V3<R> pP = ldv(S + PP_PP);
   const S6<R> Wk = ld6(c.WP + k * 6);
@@ -260,7 +263,7 @@ __device__ void pair_stage_tangent(const Ctx<R>& c, int pk, int slot, int lane, 
 // their own 12-vector.  (The first version evaluated dF, dn per point AND per direction: 7 x 54 FMA per point on
 // TactilePush against ~170 here.)
 template <class R, int NRM, int LPE>
-__device__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane) {
+__device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
@@ -366,7 +369,7 @@ __device__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane
 // accumulators.  Kept for fp64, where the 78 accumulators of the matrix form cost 156 registers and the kernel loses more
 // to spills than it gains (measured: 3.07 M vs 2.84 M env-steps/s at two environments per wavefront).
 template <class R, int NRM, int LPE>
-__device__ void pair_contacts_per_direction(const Ctx<R>& c, int pk, int slot, int lane) {
+__device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int pk, int slot, int lane) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
@@ -450,7 +453,7 @@ __device__ __forceinline__ void pair_contacts(const Ctx<R>& c, int pk, int slot,
 
 // lanes = directions: bring the staged pair's wrench (value + tangent k) to the world frame and fold it into the links
 template <class R>
-__device__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
+__device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
   const int k = lane, nd = c.nd;
   if (k >= c.nr) return;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
@@ -473,22 +476,25 @@ __device__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
 }
 
 template <class R, int NRM, int LPE>
-__device__ void phase2(const Ctx<R>& c, int lane, R sq) {
+__device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
+  const int nr = c.nr;
   for (int p0 = 0; p0 < c.npair; p0 += TS_PAIR_GROUP) {
-    const int pe = min(p0 + TS_PAIR_GROUP, c.npair);
-    for (int pk = p0; pk < pe; ++pk)
-      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_stage_value(c, pk, pk - p0, lane);
+    const int pe = min(p0 + TS_PAIR_GROUP, c.npair), np = pe - p0;
+    // lanes = pairs of the group: value records
+    if (lane < np && (ts_pair_rec(c, p0 + lane)[TSIM_PI_FLAGS] & 1)) pair_stage_value(c, p0 + lane, lane, true);
     __syncthreads();
     TS_STAMP(c);
+    // lanes = directions, serial over the pairs of the group.  (A lanes = (pair, direction) version of this step gave
+    // wrong adjoints in the 32-lane shape only — not understood, not kept.)
     for (int pk = p0; pk < pe; ++pk)
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_stage_tangent(c, pk, pk - p0, lane, sq, 0);
     __syncthreads();
     TS_STAMP(c);
-    for (int pk = p0; pk < pe; ++pk)
+    for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
     __syncthreads();
     TS_STAMP(c);
-    for (int pk = p0; pk < pe; ++pk)        // serial over pairs: two pairs may touch the same link
+    for (int pk = p0; pk < pe; ++pk)        // lanes = directions; serial over pairs: two pairs may touch the same link
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_fold(c, pk, pk - p0, lane, sq);
     __syncthreads();
   }
@@ -499,7 +505,7 @@ __device__ void phase2(const Ctx<R>& c, int lane, R sq) {
 // parent; then the joint-space forces.  Result: g (value, LDS) and H[j][k] = d g_j / d dir_k (lane k owns
 // column k).  Both are scaled by h^2.
 template <class R, bool EXPJ, int LPE>
-__device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
+__device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   const int nd = c.nd, nr = c.nr;
   const bool act = lane < nr;
   const R h2 = R(1) / c.ca;      // g = r / ca  (BDF1: h^2 r)
@@ -585,7 +591,7 @@ __device__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
 // precision in fp32 (no q1 - q0 cancellation).  forward seeds: (1, cv, ca) -> H = dg/dq1 ;  adjoint seeds (1, 0, 0)
 // -> H = (1/ca) dr/dq  (BDF1: h^2 dr/dq).
 template <class R, int NRM, bool EXPJ, int LPE>
-__device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+__device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   if (lane < c.nr) {
     const R d = c.dl[lane];
     c.qd[lane] = c.qdp[lane] + c.cv * d;
@@ -609,7 +615,7 @@ __device__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
 // wavefront) or the LDS crossbar (several).  No LDS memory traffic.
 // Solves A x = b (or A^T x = b), n <= NRM <= 16; x is written only where `write` holds (a per-slot predicate).
 template <class R, int NRM, int LPE, class S = double>
-__device__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
+__device__ __forceinline__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
   S a[NRM], rb = S(0);
 #pragma unroll
   for (int j = 0; j < NRM; ++j) {

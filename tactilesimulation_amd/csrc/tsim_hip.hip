@@ -26,7 +26,7 @@ __host__ __device__ inline int ts_rec(int nr, int nu) { return 2 * nr + nr * nr 
 // variables: lanes = end-effector points; tactile: lanes = taxels (coalesced SoA loads of position / frame,
 // 12 B per lane contiguous stores).  Each taxel is evaluated in the frame of the primitive it is tested against.
 template <int LPE, class R>
-__device__ void readout(const Ctx<R>& c, int lane, int env, bool wr, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
+__device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool wr, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
   if (var_out && wr) {
     for (int e = lane; e < c.nvar; e += LPE) {
       const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
@@ -43,7 +43,7 @@ __device__ void readout(const Ctx<R>& c, int lane, int env, bool wr, R* var_out,
     for (int j0 = 0; j0 < nsp || j0 == 0; j0 += TS_PAIR_GROUP) {
       const int je = min(j0 + TS_PAIR_GROUP, nsp);
       __syncthreads();
-      for (int j = j0; j < je; ++j) pair_stage_value(c, c.I[c.off_sprim + sp0 + j], j - j0, lane);
+      for (int j = j0; j < je; ++j) pair_stage_value(c, c.I[c.off_sprim + sp0 + j], j - j0, lane == 0);
       __syncthreads();
       // this block's slice [tb, te) of the global taxel range, intersected with the sensor
       const int lo = max(tb, t0) - t0, hi = min(te, t0 + nt) - t0;
@@ -318,7 +318,7 @@ template <class R> struct BwdArgs {
 
 // (M z)_j for lane j: direct sums over the links below dof j (no recursion, no scratch)
 template <class R>
-__device__ R mass_times_z(const Ctx<R>& c, int j) {
+__device__ __forceinline__ R mass_times_z(const Ctx<R>& c, int j) {
   R tau = R(0);
   const S6<R> Wj = ld6(c.WP + j * 6);
   for (int i = 1; i <= c.nl; ++i) {
@@ -338,7 +338,7 @@ __device__ R mass_times_z(const Ctx<R>& c, int j) {
 // w . out w.r.t. the pair's relative displacement and relative twist (12 numbers, primitive frame); one reduction
 // per (sensor, primitive); lanes = directions then dot it with the pair's per-direction records.
 template <int LPE, class R>
-__device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac) {
+__device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac) {
   const int nd = c.nd, nr = c.nr;
   if (wvar && lane < nr) {
     R acc = R(0);
@@ -363,7 +363,7 @@ __device__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wt
       const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
       const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
       __syncthreads();
-      pair_stage_value(c, pk, 0, lane);
+      pair_stage_value(c, pk, 0, lane == 0);
       __syncthreads();
       const R* S = c.PP;
       const M3<R> RPA = ldm(S + PP_RPA);
@@ -539,7 +539,8 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
   for (auto& l : links) nsteps = std::max(nsteps, (int)l.size());
   std::vector<int> leader(links.size(), -1);                 // lowest dof lane of each branch
   for (int k = nr - 1; k >= 0; --k) leader[branch[dof_link[k]]] = k;
-  std::vector<int32_t> S(TS_SCHED_ENT + nsteps * 16 + nl * TS_LR_SIZE, 0);
+  const int npair = I[TSIM_IH_NPAIR], op = I[TSIM_IH_OFF_PAIR];
+  std::vector<int32_t> S(TS_SCHED_ENT + nsteps * 16 + nl * TS_LR_SIZE + npair * TSIM_PI_SIZE, 0);
   S[0] = (int32_t)S.size(); S[1] = nsteps;
   for (int l = 0; l < 16; ++l) S[TS_SCHED_BRANCH + l] = l < nr ? branch[dof_link[l]] : -1;
   for (size_t b = 0; b < links.size() && b < 16; ++b) S[TS_SCHED_LEADER + b] = leader[b];
@@ -556,6 +557,7 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
     r[TS_LR_PARENT] = li[TSIM_LI_PARENT]; r[TS_LR_JTYPE] = li[TSIM_LI_JTYPE]; r[TS_LR_DOF0] = li[TSIM_LI_DOF0];
     r[TS_LR_NDOF] = li[TSIM_LI_NDOF]; r[TS_LR_ANCMASK] = li[TSIM_LI_ANCMASK]; r[TS_LR_BRANCH] = branch[i];
   }
+  for (int e = 0; e < npair * TSIM_PI_SIZE; ++e) S[rec0 + nl * TS_LR_SIZE + e] = I[op + e];      // pair int records
   return S;
 }
 
@@ -909,8 +911,8 @@ int tsim_cache_clear(tsim_batch* b) {
 
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u, void* g_out, void* H_out, long long* cycles, void* stream) {
   HIPCHK(hipSetDevice(b->device));
-  // one environment per wavefront, unless TSIM_LPE forces a packed shape for the cycle stamps (nr <= 8 models only)
-  const int lpe = (cycles && b->lpe_forced && !b->has_exp && b->nr <= 8) ? b->lpe_forced : TS_WAVE;
+  // one environment per wavefront, unless TSIM_LPE forces a packed shape (nr <= 8 models: the stamped variant is NRM 8)
+  const int lpe = (b->lpe_forced && !b->has_exp && (!cycles || b->nr <= 8)) ? b->lpe_forced : TS_WAVE;
   const int ns = TS_WAVE / lpe;
   const dim3 grid((b->B + ns - 1) / ns), blk(TS_WAVE);
   const size_t lds = lds_bytes_for(b, ns);
