@@ -606,7 +606,7 @@ static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
 // environments into a wavefront divides the instruction count per environment.  These kernels hold one wavefront per
 // SIMD (~270 registers; holding them to 256 for two per SIMD spills and is slower at every batch size measured,
 // profiles/r01_launch_shape_ab.txt) and a lone wavefront is latency-bound, so the time of a launch is
-//     rounds x latency(LPE),   rounds = ceil(wavefronts / #SIMDs),   latency(64 : 32 : 16) ~ 1 : 1.07 : 1.13
+//     rounds x latency(LPE),   rounds = ceil(wavefronts / #SIMDs),   latency(64 : 32 : 16) ~ 1 : 0.93 : 1.02
 // (phase stamps, tools/phase_cycles.py).  The launch takes the LPE that minimises it, subject to the block's LDS
 // leaving room for four blocks per CU.
 struct LaunchShape { int lpe; unsigned grid; size_t lds; };
@@ -618,7 +618,7 @@ static LaunchShape launch_shape(const tsim_batch* b) {
     lpe = TS_WAVE;
     double best = 1e30;
     const int cand[3] = {64, 32, 16};
-    const double lat[3] = {1.0, 1.07, 1.13};
+    const double lat[3] = {1.0, 0.93, 1.02};
     for (int i = 0; i < 3; ++i) {
       const int ns = TS_WAVE / cand[i];
       if (i > 0 && lds_bytes_for(b, ns) > lds_cap) break;
