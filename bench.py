@@ -220,7 +220,7 @@ def main():
         dom, dom_ms, dom_bytes, dom_frames = ("k_forward", fwd_ms, fb, fwd_frames) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb, bwd_frames)
         achieved = dom_bytes * B * dom_frames / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         value = B * world * args.steps / dt
-        traffic, traffic_src = None, None
+        traffic, traffic_src, issue = None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.dtype)
         if os.path.exists(pmc_file) and B == 4096:       # separate rocprofv3 --pmc run of this same command (tools/gpu_pmc.sh)
             try:
@@ -230,6 +230,11 @@ def main():
                 traffic = (2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024.0 * dom_frames / pj.get("frames_per_launch", 1)
                 traffic_src = ("profiles/" + os.path.basename(pmc_file) + " (2*FETCH_SIZE + WRITE_SIZE KiB per launch of %d env-steps, "
                                "scaled to %d)" % (pj.get("frames_per_launch", 1), dom_frames))
+                # what actually bounds the kernel: instruction issue of the one wavefront each SIMD holds (same PMC file)
+                issue = {"valu_insts_per_env_step": pk["SQ_INSTS_VALU"] / (4096.0 * pj.get("frames_per_launch", 1)),
+                         "wave_issuing_frac": pk["SQ_ACTIVE_INST_ANY"] / pk["SQ_WAVE_CYCLES"],
+                         "wave_valu_frac": pk["SQ_ACTIVE_INST_VALU"] / pk["SQ_WAVE_CYCLES"],
+                         "wavefronts": pk["SQ_WAVES"], "source": "profiles/" + os.path.basename(pmc_file)}
             except Exception:
                 pass
         res = {
@@ -246,6 +251,7 @@ def main():
                          "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb},
                          "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms},
                          "kernel_ms_per_env_step": {"k_forward": fwd_ms_step, "k_backward": bwd_ms_step},
+                         "issue": issue,
                          "note": "state stays in LDS across sub-steps, so this path is latency/VALU-bound, not HBM-bound (SURVEY.md §0.6)"},
             "launch": {"mode": args.launch,
                        "episode": "tsim_rollout + tsim_backward_episode: one launch each way per episode (EpisodicSimFunction's open-loop episode)",
