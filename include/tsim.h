@@ -59,6 +59,12 @@ int tsim_table_size(const tsim_batch* b);
  * adjoint. */
 int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag, void* stream);
 
+/* The same for the environments with mask[env] != 0 only (DEVICE int32[B]); the others keep their state.  This is what
+ * a batched roll-out collector does when single episodes end (the reference resets one `Simulation` at a time:
+ * envs/dclaw_rotate_env.py:181-199 reset() per env).  Forward-only batches only: the tape is shared by the batch.  On a
+ * BDF2 model the environment restarts with a constant-velocity history (q_-1 = q0 - h qd0). */
+int tsim_reset_masked(tsim_batch* b, const void* q0, const void* qd0, const int32_t* mask, void* stream);
+
 /* sim.set_u(u); sim.forward(num_steps, ...); sim.get_q(); sim.get_variables();
  * sim.get_tactile_force_vector()                               envs/redmax_torch_functions.py:131-136
  * (and :48-57 with num_steps = 1).  u: [B][ndof_u], held for num_steps implicit sub-steps.

@@ -588,6 +588,16 @@ template <class R> __global__ void k_set_state(R* tape, const R* q, const R* qd,
   tape[(size_t)env * rec + k] = q[i];
   tape[(size_t)env * rec + nr + k] = qd ? qd[i] : R(0);
 }
+// masked variant: only environments with mask[env] != 0 get the new state (record t of the tape)
+template <class R> __global__ void k_set_state_masked(R* tape_rec, const R* q, const R* qd, const int32_t* mask, R* prev, R h, int B, int nr, int rec) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nr) return;
+  int env = i / nr, k = i % nr;
+  if (!mask[env]) return;
+  tape_rec[(size_t)env * rec + k] = q[i];
+  tape_rec[(size_t)env * rec + nr + k] = qd ? qd[i] : R(0);
+  if (prev) { const R v = qd ? qd[i] : R(0); prev[(size_t)env * 2 * nr + k] = q[i] - h * v; prev[(size_t)env * 2 * nr + nr + k] = v; }
+}
 template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, int B, int nr, int rec) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nr) return;
@@ -787,6 +797,21 @@ int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag
   HIPCHK(hipMemsetAsync(b->lamq, 0, (size_t)b->B * b->nr * b->esz, st));
   HIPCHK(hipMemsetAsync(b->lamv, 0, (size_t)b->B * b->nr * b->esz, st));
   b->t_cur = 0; b->record = backward_flag ? 1 : 0; b->order_valid = 0; b->has_prev = 0;
+  return 0;
+}
+
+int tsim_reset_masked(tsim_batch* b, const void* q0, const void* qd0, const int32_t* mask, void* stream) {
+  if (!q0 || !mask) return fail("reset_masked: q0 / mask is null");
+  if (b->record) return fail("reset_masked: not while recording (the tape is shared by the batch): use reset");
+  HIPCHK(hipSetDevice(b->device));
+  hipStream_t st = (hipStream_t)stream;
+  int n = b->B * b->nr, blk = 256, grd = (n + blk - 1) / blk;
+  size_t off = (size_t)b->t_cur * b->B * b->rec;
+  // BDF2 models: the environment restarts with a constant-velocity history (q_-1 = q0 - h qd0, qd_-1 = qd0) [CHOICE]
+  void* prev = (b->I[TSIM_IH_INTEGRATOR] == 2 && b->has_prev) ? b->prev : nullptr;
+  if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_set_state_masked<float>, dim3(grd), dim3(blk), 0, st, (float*)b->tape + off, (const float*)q0, (const float*)qd0, mask, (float*)prev, (float)b->F[TSIM_FH_H], b->B, b->nr, b->rec);
+  else hipLaunchKernelGGL(k_set_state_masked<double>, dim3(grd), dim3(blk), 0, st, (double*)b->tape + off, (const double*)q0, (const double*)qd0, mask, (double*)prev, b->F[TSIM_FH_H], b->B, b->nr, b->rec);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -96,6 +96,16 @@ class BatchSim:
         qd0 = self._chk(qd0, self.ndof_r, "qd0")
         capi.check(capi.lib().tsim_reset(self._h, _ptr(q0), _ptr(qd0), int(bool(backward_flag)), self._stream()))
 
+    def reset_masked(self, q0, mask, qd0=None):
+        """New state for the environments with mask != 0 only (forward-only batches: roll-out collection)."""
+        q0 = self._chk(q0, self.ndof_r, "q0")
+        qd0 = self._chk(qd0, self.ndof_r, "qd0")
+        m = torch.as_tensor(mask).to(device=self.device).reshape(-1)
+        if m.numel() != self.B:
+            raise ValueError("mask: expected %d entries" % self.B)
+        m = (m != 0).to(torch.int32).contiguous()
+        capi.check(capi.lib().tsim_reset_masked(self._h, _ptr(q0), _ptr(qd0), _ptr(m), self._stream()))
+
     def step(self, u, num_steps=1, want_qd=False, want_var=True, want_tactile=True, out=None):
         """One env-step for all B environments. Returns dict(q, qd, var, tactile, status)."""
         u = self._chk(u, self.ndof_u, "u")

@@ -21,6 +21,7 @@ _SIGS = {
     "tsim_update_model": (C.c_int, [_vp, _ip, C.POINTER(C.c_double), _vp]),
     "tsim_reset": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "tsim_set_env_tables": (C.c_int, [_vp, _vp, _vp]), "tsim_table_size": (C.c_int, [_vp]),
+    "tsim_reset_masked": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "tsim_step": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tsim_get_state": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tsim_readout": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -166,3 +166,38 @@ def test_stable_grasp_episode_matches_oracle(dtype, tq, tt):
                 k += 1
             lifted = max(lifted, q[8])
     assert lifted > 5e-3                                                               # the object left the table
+
+
+def test_masked_reset_restarts_only_the_masked_environments(pusher_model):
+    """tsim_reset_masked: a roll-out collector restarts single environments; the others must not notice."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    B, T, S = 8, 10, 5
+    q0_np, u_np, _ = push_workload(B, T, seed=21)
+    dev, dt = "cuda:0", torch.float64
+    q0 = torch.tensor(q0_np, device=dev, dtype=dt)
+    u = torch.tensor(u_np, device=dev, dtype=dt).transpose(0, 1).contiguous()
+    a = BatchSim(pusher_model, B, dtype=dt, tape_capacity=0)
+    ref = BatchSim(pusher_model, B, dtype=dt, tape_capacity=0)
+    a.reset(q0, None, False); ref.reset(q0, None, False)
+    mask = torch.tensor([0, 1, 0, 0, 1, 0, 0, 1], device=dev)
+    sel, keep = mask.bool(), ~mask.bool()
+    t_reset = 4
+    early, late = [], []
+    for t in range(T):
+        if t == t_reset:
+            a.reset_masked(q0, mask)                          # envs 1, 4, 7 start over; their actions restart too
+        ua = u[t].clone()
+        if t >= t_reset:
+            ua[sel] = u[t - t_reset][sel]
+        oa = a.step(ua, S)
+        orf = ref.step(u[t], S)
+        assert torch.equal(oa["q"][keep], orf["q"][keep]) and torch.equal(oa["tactile"][keep], orf["tactile"][keep])
+        early.append(orf["q"][sel].clone())
+        if t >= t_reset:
+            late.append(oa["q"][sel].clone())
+    for x, y in zip(late, early):                               # the restarted envs replay their first steps exactly
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError):
+        rec = BatchSim(pusher_model, B, dtype=dt, tape_capacity=4)
+        rec.reset(q0, None, True)
+        rec.reset_masked(q0, mask)
