@@ -201,3 +201,35 @@ def test_masked_reset_restarts_only_the_masked_environments(pusher_model):
         rec = BatchSim(pusher_model, B, dtype=dt, tape_capacity=4)
         rec.reset(q0, None, True)
         rec.reset_masked(q0, mask)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-10), (torch.float32, 5e-4)])
+def test_launch_shapes_agree(pusher_model, dtype, tol, monkeypatch):
+    """1, 2 and 4 environments per wavefront (TSIM_LPE = 64 / 32 / 16, read at tsim_batch_create) run the same arithmetic
+    up to the summation order: forward outputs and the whole-episode adjoint of the three shapes agree to round-off."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    B, T, S = 11, 10, 5                                   # 11: the last wavefront of the packed shapes has idle slots
+    q0_np, u_np, _ = push_workload(B, T, seed=31)
+    dev = "cuda:0"
+    q0 = torch.tensor(q0_np, device=dev, dtype=dtype)
+    u = torch.tensor(u_np, device=dev, dtype=dtype).transpose(0, 1).contiguous()
+    g = torch.Generator().manual_seed(6)
+    res = {}
+    for lpe in (64, 32, 16):
+        monkeypatch.setenv("TSIM_LPE", str(lpe))
+        sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+        assert sim.launch_info()["lanes_per_env"] == lpe
+        sim.reset(q0, None, backward_flag=True)
+        out = sim.rollout(u, S)
+        if lpe == 64:
+            wq = torch.randn(out["q"].shape, generator=g).to(dev, dtype)
+            wv = torch.randn(out["var"].shape, generator=g).to(dev, dtype)
+            wt = (10 * torch.randn(out["tactile"].shape, generator=g)).to(dev, dtype)
+        du = sim.backward_episode(T, S, wq, wv, wt)
+        lq, lv = sim.get_adjoint()
+        assert int(out["status"].sum()) == 0
+        res[lpe] = {"q": out["q"], "var": out["var"], "tactile": out["tactile"], "du": du, "lq": lq, "lv": lv}
+    for lpe in (32, 16):
+        for k, ref in res[64].items():
+            err = float((res[lpe][k] - ref).abs().max())
+            assert err <= tol * max(float(ref.abs().max()), 1e-3), (lpe, k, err)
