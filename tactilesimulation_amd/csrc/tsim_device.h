@@ -14,13 +14,15 @@
 // directions), which is why several slots per wavefront pay: the instruction count per environment is what bounds
 // this path.  Lane mappings inside one residual evaluation:
 //
-//   phase 1  (all lanes, uniform)     value kinematics + inertial wrench per link, root -> leaf
-//   phase 1t (lanes = directions)     exact tangents of link twist / acceleration / inertial wrench w.r.t. dof k,
-//                                     propagated with world-frame spatial algebra (6-vectors, no matrices)
-//   phase 2  (lanes = contact points) penalty contact in the primitive's frame: force + its 3x3 local Jacobians,
-//                                     applied to the per-direction relative displacement / twist of the pair
-//                                     (12 reals per direction, LDS broadcast); wavefront DPP reductions
-//   phase 3  (lanes = directions)     projection on the joints, leaf -> root:  g  and  H[:,k]
+//   phase 1  (lanes = directions,     link values + exact tangents of link twist / acceleration / inertial wrench w.r.t.
+//             root branches together)  dof k, root -> leaf, world-frame spatial algebra (6-vectors); lane k walks only the
+//                                     links of the root branch of its dof (host-built schedule in LDS)
+//   phase 2  (lanes = pairs,          pair staging in the primitive's frame;
+//             lanes = contact points) penalty contact: force + its 3x3 local Jacobians -> per pair the wrench and its
+//                                     6 x 12 derivative w.r.t. the pair's relative displacement / twist (fp32; fp64
+//                                     evaluates per direction), segmented DPP reductions, applied by lanes = directions
+//   phase 3  (lanes = (direction,     projection on the joints, leaf -> root:  g  and  H[:,k]
+//             root branch))
 //
 // Replaces the per-sub-step C++ of the reference's absent DiffRedMax behind `sim.forward()` /
 // `sim.backward_steps()` (envs/redmax_torch_functions.py:132,167).  Formulation: DESIGN.md §1.

@@ -1,11 +1,13 @@
 // tsim_hip.hip — kernels + C ABI (include/tsim.h) of the MI355X-native batched tactile-simulation step.
 //
 // Kernels (block = one 64-lane wavefront carrying 64 / LPE environments of LPE lanes each; see tsim_device.h):
-//   k_forward   : num_steps implicit BDF1 sub-steps (Newton + line search) with the action held, tape append,
-//                 q / qd / variables / tactile read-out          <- sim.set_u + sim.forward + getters
-//                                                                   (envs/redmax_torch_functions.py:131-136)
+//   k_forward   : nframes env-steps of num_steps implicit BDF1 / BDF2 sub-steps (Newton + line search) with the action of
+//                 the frame held, tape append, q / qd / variables / tactile read-out per frame
+//                                                                <- sim.set_u + sim.forward + getters
+//                                                                   (envs/redmax_torch_functions.py:131-136; nframes > 1:
+//                                                                   the episode loop of :46-57)
 //   k_backward  : adjoint of the newest n taped sub-steps, carrying (lam_q, lam_v) across calls
-//                                                                <- sim.backward_steps(n)  (:151-170)
+//                                                                <- sim.backward_steps(n)  (:151-170), sim.backward() (:92)
 //   k_readout   : variables + tactile at the current state       <- get_variables / get_tactile_force_vector
 //   k_debug_eval: one residual + Newton-matrix evaluation (parity tests)
 #include <hip/hip_runtime.h>
