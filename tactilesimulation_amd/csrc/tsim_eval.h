@@ -477,7 +477,6 @@ __device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int
 
 template <class R, int NRM, int LPE>
 __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
-  const int nr = c.nr;
   for (int p0 = 0; p0 < c.npair; p0 += TS_PAIR_GROUP) {
     const int pe = min(p0 + TS_PAIR_GROUP, c.npair), np = pe - p0;
     // lanes = pairs of the group: value records

@@ -252,9 +252,7 @@ __global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* 
   const int nwaves = (B + ns - 1) / ns;
   for (int e = t; e < B; e += 1024) {
     const int r = atomicAdd(&base[min(evals[e], 63)], 1);       // rank of environment e, 0 = most expensive
-    int pos = (r % nwaves) * ns + r / nwaves;                   // slot r / nwaves of wavefront r % nwaves
-    if (pos >= B) pos = r;                                      // ragged last wavefront: cannot happen for r < B when B % ns == 0
-    order[pos] = e;
+    order[(r % nwaves) * ns + r / nwaves] = e;                  // slot r / nwaves of wavefront r % nwaves (B % ns == 0)
   }
 }
 
@@ -351,7 +349,7 @@ __device__ __forceinline__ R mass_times_z(const Ctx<R>& c, int j) {
 // per (sensor, primitive); lanes = directions then dot it with the pair's per-direction records.
 template <int LPE, class R>
 __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac) {
-  const int nd = c.nd, nr = c.nr;
+  const int nr = c.nr;
   if (wvar && lane < nr) {
     R acc = R(0);
     const S6<R> Wk = ld6(c.WP + lane * 6);
