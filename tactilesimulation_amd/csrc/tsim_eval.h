@@ -483,10 +483,20 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
     if (lane < np && (ts_pair_rec(c, p0 + lane)[TSIM_PI_FLAGS] & 1)) pair_stage_value(c, p0 + lane, lane, true);
     __syncthreads();
     TS_STAMP(c);
-    // lanes = directions, serial over the pairs of the group.  (A lanes = (pair, direction) version of this step gave
-    // wrong adjoints in the 32-lane shape only — not understood, not kept.)
-    for (int pk = p0; pk < pe; ++pk)
-      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_stage_tangent(c, pk, pk - p0, lane, sq, 0);
+    // lanes = (pair, direction): per-direction records
+    {
+      const int ntask = np * c.nr;
+      // wave-uniform trip count with the idle lanes masked inside: the lane-strided form (t = lane; t < ntask; t += LPE)
+      // of this loop produced wrong adjoints in the 32-lane shape only (toolchain issue with the divergent loop, not
+      // understood further; the whole GPU suite runs under TSIM_LPE = 64 / 32 / 16 because of it)
+      for (int t0 = 0; t0 < ntask; t0 += LPE) {
+        const int t = t0 + lane;
+        if (t < ntask) {
+          const int p = t / c.nr, k = t - p * c.nr;
+          if (ts_pair_rec(c, p0 + p)[TSIM_PI_FLAGS] & 1) pair_stage_tangent(c, p0 + p, p, k, sq, 0);
+        }
+      }
+    }
     __syncthreads();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
