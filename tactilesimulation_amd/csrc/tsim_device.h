@@ -247,7 +247,8 @@ template <int LPE, class R> __device__ __forceinline__ R seg_bcast(R x, int src)
 // ------------------------------------------------------------------------------------------------ per-block context
 template <class R> struct Ctx {
   const int* I; const R* F;               // model records (link / dof / motor / pair / sensor tables): staged in LDS
-  const R* Fg;                            // whole float blob in global memory (contact-point and taxel SoA arrays)
+  const R* Fg;                            // whole float blob in global memory (taxel SoA arrays; large contact-point arrays)
+  const R* CPT;                           // contact-point SoA arrays x[] y[] z[]: LDS copy when small, else global
   int nl, nr, nu, nvar, npair, ncpt, nsensor, ntax, nd;
   int off_link, off_dof, off_motor, off_var, off_pair, off_sensor, off_sprim;
   int foff_link, foff_dof, foff_motor, foff_var, foff_pair, foff_sensor, foff_cpt, foff_tax;
@@ -281,8 +282,16 @@ __host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu) {
 }
 // LDS reals of a block of nslot environments. nfrec: leading reals of the model blob that are staged in LDS (everything
 // except the per-point SoA arrays); one copy per block, or one per slot with per-environment tables.
-__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int nslot, bool env_tables, int nsched, int esz) {
-  return (env_tables ? nslot : 1) * (nfrec + 2) + ((nsched * 4 + esz - 1) / esz + 3) / 4 * 4 + nslot * ts_lds_env_reals(nl, nr, nu) + 8;
+// The contact-point SoA arrays (3 ncpt reals right behind the tables in the blob) are staged with the shared tables when
+// they are small (<= TS_CPT_LDS_BYTES): every residual evaluation reads all of them, and a lone wavefront cannot hide
+// ~600-cycle L2 latencies.
+#define TS_CPT_LDS_BYTES 8192
+__host__ __device__ inline int ts_cpt_staged(int ncpt, bool env_tables, int esz) {
+  return (!env_tables && 3 * ncpt * esz <= TS_CPT_LDS_BYTES) ? 3 * ncpt : 0;
+}
+__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int ncpt, int nslot, bool env_tables, int nsched, int esz) {
+  return (env_tables ? nslot : 1) * (nfrec + 2) + ts_cpt_staged(ncpt, env_tables, esz)
+       + ((nsched * 4 + esz - 1) / esz + 3) / 4 * 4 + nslot * ts_lds_env_reals(nl, nr, nu) + 8;
 }
 
 // Sweep schedule (built on the host from the link parents, appended to the device copy of the int blob at I[TSIM_IH_NI]):
@@ -315,8 +324,9 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
       for (int i = lane; i < nfrec; i += lpe) mf[i] = Fenv[i];
       lds += nslot * (nfrec + 2);
     } else {
-      for (int i = threadIdx.x; i < nfrec; i += TS_WAVE) mf[i] = F[i];
-      lds += nfrec + 2;
+      const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, (int)sizeof(R));      // tables (+ contact points)
+      for (int i = threadIdx.x; i < nst; i += TS_WAVE) mf[i] = F[i];
+      lds += nst + 2;
     }
     {                                            // sweep schedule + link int records (one copy per block)
       const int* S = I + I[TSIM_IH_NI];
@@ -328,6 +338,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     }
     __syncthreads();
     c.Fg = F; c.F = mf; c.I = I;
+    c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, (int)sizeof(R)) ? mf : F) + I[TSIM_IH_FOFF_CPT];
     F = mf;
   }
   c.stamps = nullptr; c.nstamp = 0;

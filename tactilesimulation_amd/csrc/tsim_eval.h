@@ -287,7 +287,7 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
     V3<R> cP = zero3<R>(), xP = cP, F = cP;
     M3<R> Jx, Jv;
     if (pidx < npt) {
-      const R* cp = c.Fg + c.foff_cpt + pt0 + pidx;        // SoA: consecutive lanes -> consecutive addresses
+      const R* cp = c.CPT + pt0 + pidx;                    // SoA: consecutive lanes -> consecutive addresses
       cP = mulMv(RPA, mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt])) + pPA;
       xP = cP;
       if (sphere_plane) xP.z -= pf[TSIM_PF_SHAPE];         // lowest point of the sphere (plane normal = +z of P)
@@ -392,7 +392,7 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
     V3<R> cP = zero3<R>(), xP = cP, F = cP;
     M3<R> Jx, Jv;
     if (pidx < npt) {
-      const R* cp = c.Fg + c.foff_cpt + pt0 + pidx;        // SoA: consecutive lanes -> consecutive addresses
+      const R* cp = c.CPT + pt0 + pidx;                    // SoA: consecutive lanes -> consecutive addresses
       cP = mulMv(RPA, mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt])) + pPA;
       xP = cP;
       if (sphere_plane) xP.z -= pf[TSIM_PF_SHAPE];         // lowest point of the sphere (plane normal = +z of P)

@@ -618,7 +618,7 @@ template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, i
 
 // dynamic LDS of a block of nslot environments
 static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
-  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, nslot, b->dFenv != nullptr, b->nsched, (int)b->esz);
+  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, b->I[TSIM_IH_NCPT], nslot, b->dFenv != nullptr, b->nsched, (int)b->esz);
   return ((size_t)reals * b->esz + 15) / 16 * 16;
 }
 // Launch shape of the forward / backward kernels.
