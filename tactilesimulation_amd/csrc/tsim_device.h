@@ -283,14 +283,14 @@ __host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu) {
 // LDS reals of a block of nslot environments. nfrec: leading reals of the model blob that are staged in LDS (everything
 // except the per-point SoA arrays); one copy per block, or one per slot with per-environment tables.
 // The contact-point SoA arrays (3 ncpt reals right behind the tables in the blob) are staged with the shared tables when
-// they are small (<= TS_CPT_LDS_BYTES): every residual evaluation reads all of them, and a lone wavefront cannot hide
-// ~600-cycle L2 latencies.
+// the host says so (S[TS_SCHED_STAGE_CPT]: they are small and do not cost the launch its lanes-per-environment shape):
+// every residual evaluation reads all of them, and a lone wavefront cannot hide ~600-cycle L2 latencies.
 #define TS_CPT_LDS_BYTES 8192
-__host__ __device__ inline int ts_cpt_staged(int ncpt, bool env_tables, int esz) {
-  return (!env_tables && 3 * ncpt * esz <= TS_CPT_LDS_BYTES) ? 3 * ncpt : 0;
+__host__ __device__ inline int ts_cpt_staged(int ncpt, bool env_tables, bool stage) {
+  return (!env_tables && stage) ? 3 * ncpt : 0;
 }
-__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int ncpt, int nslot, bool env_tables, int nsched, int esz) {
-  return (env_tables ? nslot : 1) * (nfrec + 2) + ts_cpt_staged(ncpt, env_tables, esz)
+__host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int ncpt, bool stage_cpt, int nslot, bool env_tables, int nsched, int esz) {
+  return (env_tables ? nslot : 1) * (nfrec + 2) + ts_cpt_staged(ncpt, env_tables, stage_cpt)
        + ((nsched * 4 + esz - 1) / esz + 3) / 4 * 4 + nslot * ts_lds_env_reals(nl, nr, nu) + 8;
 }
 
@@ -299,11 +299,11 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, i
 // lane k < nr walks only the links of the branch of its own dof k — all branches advance together, and the sweep takes
 // max(branch size) steps instead of nl.
 //   S[0] = number of ints, S[1] = steps, S[2 + l] = branch of lane l (l < 16; -1: lane has no dof),
-//   S[18 + b] = leader lane of branch b, S[34] = number of branches,
+//   S[18 + b] = leader lane of branch b, S[34] = number of branches, S[35] = stage the contact-point arrays in LDS,
 //   S[TS_SCHED_ENT + step * 16 + l] = link visited by lane l at that step | leader << 8 (0: none; the leader lane of a
 //   branch stores the link's value record), then per link 8 ints: parent, joint type, dof0, ndof, ancestor mask, branch.
 // The leaf->root projection (phase 3) uses the same lists backwards, one lane per (direction, branch).
-enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_ENT = 36, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
+enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_STAGE_CPT = 35, TS_SCHED_ENT = 36, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
 __device__ __forceinline__ int ts_sched_rec(const int* S) { return TS_SCHED_ENT + S[1] * 16; }
 // ... followed by a copy of the contact-pair int records (TSIM_PI_*), for the lanes = pairs staging of phase 2
 template <class C> __device__ __forceinline__ const int* ts_pair_rec(const C& c, int pk) {
@@ -324,7 +324,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
       for (int i = lane; i < nfrec; i += lpe) mf[i] = Fenv[i];
       lds += nslot * (nfrec + 2);
     } else {
-      const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, (int)sizeof(R));      // tables (+ contact points)
+      const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, I[I[TSIM_IH_NI] + TS_SCHED_STAGE_CPT] != 0);   // tables (+ contact points)
       for (int i = threadIdx.x; i < nst; i += TS_WAVE) mf[i] = F[i];
       lds += nst + 2;
     }
@@ -338,7 +338,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     }
     __syncthreads();
     c.Fg = F; c.F = mf; c.I = I;
-    c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, (int)sizeof(R)) ? mf : F) + I[TSIM_IH_FOFF_CPT];
+    c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, I[I[TSIM_IH_NI] + TS_SCHED_STAGE_CPT] != 0) ? mf : F) + I[TSIM_IH_FOFF_CPT];
     F = mf;
   }
   c.stamps = nullptr; c.nstamp = 0;

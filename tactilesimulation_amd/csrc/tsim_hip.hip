@@ -527,6 +527,7 @@ struct tsim_batch {
   int t_cur, record;
   int lpe_forced;                // lanes per environment forced by TSIM_LPE (0 = choose from the batch size)
   int nsched;                    // ints of the sweep schedule appended to dI
+  int stage_cpt;                 // the contact-point arrays are staged in LDS with the shared tables
   int n_simd;                    // SIMDs of the device (CUs x 4)
   size_t esz;
   std::vector<CacheEntry> cache;
@@ -574,8 +575,9 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
 static int upload_model(tsim_batch* b, hipStream_t st) {
   HIPCHK(hipMemcpyAsync(b->dI, b->I.data(), b->I.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
   {
-    const std::vector<int32_t> S = build_sched(b->I);        // appended to the device copy at I[TSIM_IH_NI]
+    std::vector<int32_t> S = build_sched(b->I);              // appended to the device copy at I[TSIM_IH_NI]
     if ((int)S.size() != b->nsched) return fail("sweep schedule size changed");
+    S[TS_SCHED_STAGE_CPT] = b->stage_cpt;
     HIPCHK(hipMemcpyAsync(b->dI + b->I.size(), S.data(), S.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -618,7 +620,7 @@ template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, i
 
 // dynamic LDS of a block of nslot environments
 static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
-  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, b->I[TSIM_IH_NCPT], nslot, b->dFenv != nullptr, b->nsched, (int)b->esz);
+  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, b->I[TSIM_IH_NCPT], b->stage_cpt != 0, nslot, b->dFenv != nullptr, b->nsched, (int)b->esz);
   return ((size_t)reals * b->esz + 15) / 16 * 16;
 }
 // Launch shape of the forward / backward kernels.
@@ -736,7 +738,13 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     b->n_simd = 4 * cus;
   }
-  if (lds_bytes_for(b, 1) > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
+  b->stage_cpt = 0;
+  if (lds_bytes_for(b, 1) > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
+  if ((size_t)3 * I[TSIM_IH_NCPT] * b->esz <= TS_CPT_LDS_BYTES) {      // stage the contact points if the shape survives it
+    const int lpe0 = launch_shape(b).lpe;
+    b->stage_cpt = 1;
+    if (launch_shape(b).lpe != lpe0) b->stage_cpt = 0;
+  } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
