@@ -137,6 +137,9 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
  * from the batch size and the device's SIMD count, override with the environment variable TSIM_LPE at
  * tsim_batch_create). out = int32[4]. */
 int tsim_launch_info(const tsim_batch* b, int32_t* out);
+/* Force 16 / 32 / 64 lanes per environment (0 = automatic again).  For callers that split a batch into groups on several
+ * streams: each group is then small, but the groups together should still fill the device. */
+int tsim_set_lanes_per_env(tsim_batch* b, int lanes);
 
 /* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */
 int tsim_last_evals(tsim_batch* b, int32_t* host_out);

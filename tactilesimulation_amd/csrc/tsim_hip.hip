@@ -780,6 +780,25 @@ int tsim_launch_info(const tsim_batch* b, int32_t* out) {
   out[0] = (int32_t)L.lds; out[1] = TS_WAVE; out[2] = (int32_t)L.grid; out[3] = L.lpe;
   return 0;
 }
+int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
+  if (lanes != 0 && lanes != 16 && lanes != 32 && lanes != 64) return fail("set_lanes_per_env: 0 (automatic), 16, 32 or 64");
+  b->lpe_forced = lanes;
+  b->order_valid = 0;
+  // the contact-point staging decision depends on the shape: redo it, the flag lives in the device copy of the schedule
+  const int old = b->stage_cpt;
+  b->stage_cpt = 0;
+  if ((size_t)3 * b->I[TSIM_IH_NCPT] * b->esz <= TS_CPT_LDS_BYTES) {
+    const int lpe0 = launch_shape(b).lpe;
+    b->stage_cpt = 1;
+    if (launch_shape(b).lpe != lpe0) b->stage_cpt = 0;
+  }
+  if (b->stage_cpt != old) {
+    HIPCHK(hipSetDevice(b->device));
+    const int32_t v = b->stage_cpt;
+    HIPCHK(hipMemcpy(b->dI + b->I.size() + TS_SCHED_STAGE_CPT, &v, sizeof(v), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
 int tsim_last_evals(tsim_batch* b, int32_t* host_out) {
   if (hipSetDevice(b->device) != hipSuccess || hipMemcpy(host_out, b->evals, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_evals: copy failed");
   return 0;

@@ -233,6 +233,10 @@ class BatchSim:
         capi.check(capi.lib().tsim_last_evals(self._h, out.ctypes.data_as(capi._ip)))
         return out
 
+    def set_lanes_per_env(self, lanes):
+        """16 / 32 / 64 lanes per environment, 0 = automatic (include/tsim.h tsim_set_lanes_per_env)."""
+        capi.check(capi.lib().tsim_set_lanes_per_env(self._h, int(lanes)))
+
     def launch_info(self):
         out = (C.c_int32 * 4)()
         capi.lib().tsim_launch_info(self._h, out)

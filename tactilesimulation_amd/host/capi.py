@@ -32,6 +32,7 @@ _SIGS = {
     "tsim_cache_save": (C.c_int, [_vp, _vp]), "tsim_cache_pop": (C.c_int, [_vp, _vp]), "tsim_cache_clear": (C.c_int, [_vp]),
     "tsim_debug_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tsim_launch_info": (C.c_int, [_vp, _ip]),
+    "tsim_set_lanes_per_env": (C.c_int, [_vp, C.c_int]),
     "tsim_last_evals": (C.c_int, [_vp, _ip]),
     "tsim_last_error": (C.c_char_p, []),
 }

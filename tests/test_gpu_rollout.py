@@ -207,6 +207,7 @@ def test_masked_reset_restarts_only_the_masked_environments(pusher_model):
 def test_launch_shapes_agree(pusher_model, dtype, tol, monkeypatch):
     """1, 2 and 4 environments per wavefront (TSIM_LPE = 64 / 32 / 16, read at tsim_batch_create) run the same arithmetic
     up to the summation order: forward outputs and the whole-episode adjoint of the three shapes agree to round-off."""
+    monkeypatch.delenv("TSIM_LPE", raising=False)
     from tactilesimulation_amd.host.batch import BatchSim
     B, T, S = 11, 10, 5                                   # 11: the last wavefront of the packed shapes has idle slots
     q0_np, u_np, _ = push_workload(B, T, seed=31)
@@ -216,8 +217,13 @@ def test_launch_shapes_agree(pusher_model, dtype, tol, monkeypatch):
     g = torch.Generator().manual_seed(6)
     res = {}
     for lpe in (64, 32, 16):
-        monkeypatch.setenv("TSIM_LPE", str(lpe))
-        sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+        if lpe == 32:
+            monkeypatch.setenv("TSIM_LPE", "32")              # either way of forcing the shape
+            sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+            monkeypatch.delenv("TSIM_LPE")
+        else:
+            sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+            sim.set_lanes_per_env(lpe)
         assert sim.launch_info()["lanes_per_env"] == lpe
         sim.reset(q0, None, backward_flag=True)
         out = sim.rollout(u, S)

@@ -13,6 +13,9 @@ def run(G, B=4096, T=100, S=5, dtype=torch.float32, reps=2, bwd=True):
     q0_np, u_np, _ = push_workload(B, T, seed=0)
     Bg = B // G
     sims = [BatchSim(model, Bg, device="cuda:0", dtype=dtype, tape_capacity=T * S) for _ in range(G)]
+    if G > 1:
+        for s_ in sims:
+            s_.set_lanes_per_env(16)                     # small groups, but together they should still fill the chip
     streams = [torch.cuda.Stream(dev) for _ in range(G)]
     q0 = [torch.tensor(q0_np[g * Bg:(g + 1) * Bg], device=dev, dtype=dtype) for g in range(G)]
     u = [torch.tensor(u_np[g * Bg:(g + 1) * Bg], device=dev, dtype=dtype).transpose(0, 1).contiguous() for g in range(G)]
