@@ -38,6 +38,49 @@ def rollout_loss(env, actor, horizon, q0=None, goal=None, disturbances=None):
     return total
 
 
+class GraphedRollout:
+    """rollout_loss + backward of one episode captured in ONE HIP graph (torch.cuda.CUDAGraph): the closed loop issues ~40
+    small launches per env-step (policy MLP, observation / reward formulas, autograd, one simulator launch each way), which
+    an eager-mode host cannot feed fast enough; a replay costs one launch.  q0 [B, 7], goal [B, 3], disturbances
+    [T, B, 2] are STATIC device tensors: write new episode data into them (copy_) before replay().  After replay(),
+    `loss` holds -sum of rewards and the actor's .grad the un-normalised policy gradient (then allreduce / clip / step as
+    in train_epoch).  The simulator's host-side tape counters are advanced at capture time and end where they started
+    (forward pushes, backward pops), so every replay is a whole episode."""
+
+    def __init__(self, env, actor, horizon, q0, goal, disturbances, warmup=2):
+        self.env, self.actor, self.horizon = env, actor, horizon
+        self.q0, self.goal, self.dist = q0, goal, disturbances
+        side = torch.cuda.Stream(env.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                         # eager warm-up on a side stream (allocator, lazy init)
+            for _ in range(warmup):
+                for p in actor.parameters():
+                    p.grad = None
+                rollout_loss(env, actor, horizon, q0=q0, goal=goal, disturbances=disturbances).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        for p in actor.parameters():
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = rollout_loss(env, actor, horizon, q0=q0, goal=goal, disturbances=disturbances)
+            self.loss.backward()
+
+    def replay(self):
+        self.graph.replay()
+        return self.loss
+
+
+def train_epoch_graphed(gr, optimizer, global_episodes, grad_clip=1.0):
+    """train_epoch with the roll-out and its backward replayed from a HIP graph (GraphedRollout)."""
+    loss = gr.replay()                                        # static tensor: clone it to keep a value across epochs
+    params = list(gr.actor.parameters())
+    allreduce_policy_grad_(params, global_episodes)
+    if grad_clip:
+        torch.nn.utils.clip_grad_norm_(params, grad_clip)
+    optimizer.step()
+    return loss
+
+
 def train_epoch(env, actor, optimizer, horizon, global_episodes, grad_clip=1.0, **rollout_kw):
     """One optimiser step on `global_episodes` episodes (= sum over ranks of env.B): local BPTT, ONE all-reduce of the
     flat gradient, normalisation by the global episode count, then clip-by-global-norm and Adam (gd.py:157-164,258)."""

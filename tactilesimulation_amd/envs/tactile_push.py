@@ -36,6 +36,8 @@ class BatchedTactilePushEnv:
 
     # ------------------------------------------------------------------ helpers
     def _t(self, a):
+        if torch.is_tensor(a):                       # device tensors pass through (no host round trip: graph capture)
+            return a.to(device=self.device, dtype=self.dtype)
         return torch.as_tensor(np.asarray(a), device=self.device, dtype=self.dtype)
 
     def _obs(self, q, tactile):

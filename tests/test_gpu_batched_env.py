@@ -79,3 +79,36 @@ def test_policy_gradient_matches_finite_differences(pusher_model):
     l0 = train_epoch(env, actor, opt, T, B, **kw)
     l1 = train_epoch(env, actor, opt, T, B, **kw)
     assert np.isfinite(l0) and np.isfinite(l1)
+
+
+def test_graphed_rollout_matches_eager(pusher_model):
+    """algorithms/batched_gd.GraphedRollout: the episode + its backward replayed from one HIP graph give the loss and the
+    policy gradient of the eager loop, also after new episode data has been written into the static inputs."""
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.algorithms.batched_gd import Actor, rollout_loss, GraphedRollout
+    B, T = 6, 5
+    dt = torch.float64
+    rng = np.random.default_rng(2)
+    env = BatchedTactilePushEnv(pusher_model, B, dtype=dt, gradient=True, seed=5, tape_steps=T)
+    env.reset()
+    q0, goal = env.q0.clone(), env.goal.clone()
+    D = torch.tensor(rng.uniform(-1, 1, size=(T, B, 2)), device="cuda")
+    torch.manual_seed(0)
+    actor = Actor(dtype=dt).cuda()
+    gr = GraphedRollout(env, actor, T, q0, goal, D)
+    for trial in range(2):
+        if trial == 1:                                         # a new episode: different goals and disturbances
+            goal.copy_(goal + torch.tensor([0.01, -0.02, 0.03], device="cuda"))
+            D.copy_(torch.tensor(rng.uniform(-1, 1, size=(T, B, 2)), device="cuda"))
+        lg = float(gr.replay().detach())
+        got = [p.grad.clone() for p in actor.parameters() if p.grad is not None]
+        ref_env = BatchedTactilePushEnv(pusher_model, B, dtype=dt, gradient=True, seed=5, tape_steps=T)
+        for p in actor.parameters():
+            p.grad = None if trial == 99 else p.grad           # the graph owns the .grad tensors: keep them
+        params = [p for p in actor.parameters()]
+        le = rollout_loss(ref_env, actor, T, q0=q0, goal=goal, disturbances=D)
+        ref = torch.autograd.grad(le, [p for p in params if p.requires_grad], allow_unused=True)
+        ref = [r for r in ref if r is not None]
+        assert abs(lg - float(le.detach())) < 1e-9 * abs(float(le.detach()))
+        for a, b in zip(got, ref):
+            assert float((a - b).abs().max()) < 1e-8 * max(float(b.abs().max()), 1.0)
