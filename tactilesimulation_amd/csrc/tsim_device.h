@@ -107,6 +107,18 @@ template <class T> __device__ __forceinline__ S6<T> operator*(S6<T> x, T s) { re
 template <class T> __device__ __forceinline__ T dot6(S6<T> m, S6<T> f) { return dot3(m.a, f.a) + dot3(m.l, f.l); }
 template <class T> __device__ __forceinline__ S6<T> crm(S6<T> v, S6<T> m) { return mk6<T>(cross3(v.a, m.a), cross3(v.a, m.l) + cross3(v.l, m.a)); }   // v x m
 template <class T> __device__ __forceinline__ S6<T> crf(S6<T> v, S6<T> f) { return mk6<T>(cross3(v.a, f.a) + cross3(v.l, f.l), cross3(v.a, f.l)); }   // v x* f
+// precision changes (the pose chain and the penetration depths are kept in double inside the fp32 kernels, see Ctx)
+template <class T, class U> __device__ __forceinline__ V3<T> cvt3(V3<U> v) { return mk3<T>((T)v.x, (T)v.y, (T)v.z); }
+template <class T, class U> __device__ __forceinline__ M3<T> cvtm(const M3<U>& A) { M3<T> B;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) B.m[i] = (T)A.m[i];
+  return B; }
+template <class T, class U> __device__ __forceinline__ V3<T> ldv_as(const U* p) { return mk3<T>((T)p[0], (T)p[1], (T)p[2]); }
+template <class T, class U> __device__ __forceinline__ M3<T> ldm_as(const U* p) { M3<T> A;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) A.m[i] = (T)p[i];
+  return A; }
+__device__ __forceinline__ void t_sincos_d(double x, double& s, double& c) { sincos(x, &s, &c); }
 template <class T> __device__ __forceinline__ S6<T> ld6(const T* p) { return mk6<T>(ldv(p), ldv(p + 3)); }
 template <class T> __device__ __forceinline__ void st6(T* p, S6<T> v) { stv(p, v.a); stv(p + 3, v.l); }
 // p[0..6) += s * v   (read-modify-write of a 6-vector in LDS)
@@ -260,6 +272,13 @@ template <class R> struct Ctx {
   R *qp, *qdp, *qm1, *qdm1;               // predictor of the implicit step; state before the previous sub-step (BDF2)
   R *expw;                                // rotation-vector joint: d W_m / d theta_k, 9 x 6 reals
   R *LP, *WP, *DT, *PP, *PT, *scr;
+  // High-precision side of the geometry (double also in the fp32 kernels): a penetration depth of 1e-4 m is the
+  // difference of positions of 0.1 ... 0.3 m — 2e-4 relative error if the pose chain is fp32, which is what flips
+  // contact / friction branches over a long roll-out (profiles/r01_fp32_vs_fp64_scale.json).  Positions q, link poses,
+  // staged pair poses and the point -> primitive-frame transform are double; velocities, forces, tangents are R.
+  double *qD, *q0D, *qpD, *qm1D;          // q1 = qpD + dl, state before the sub-step, predictor, state before that (BDF2)
+  double *LPd;                            // per link: R (9) + p (3)
+  double *PPd;                            // per staged pair: R_PA (9) + p_PA (3)
   const int* LI;                          // sweep schedule + per-link int records in LDS (ts_sched layout below)
   long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
   mutable int nstamp;
@@ -267,9 +286,11 @@ template <class R> struct Ctx {
 #define TS_STAMP(c) do { if ((c).stamps) { if (threadIdx.x == 0 && (c).nstamp < 32) (c).stamps[(c).nstamp] = clock64(); (c).nstamp++; } } while (0)
 
 // LDS reals of one environment's state (host and device must agree)
-__host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu) {
+__host__ __device__ inline int ts_lds_env_doubles(int nl, int nr) { return 4 * nr + (nl + 1) * 12 + TS_PAIR_GROUP * 12; }
+__host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu, int esz) {
   const int nd = nr;
-  int n = 15 * nr + nu;                    // q q0 qd0 qd qa g dq(2) dl(2) qp qdp qm1 qdm1 spare ; u
+  int n = ts_lds_env_doubles(nl, nr) * (8 / esz);   // the double block comes first (8-byte aligned)
+  n += 15 * nr + nu;                       // q q0 qd0 qd qa g dq(2) dl(2) qp qdp qm1 qdm1 spare ; u
   n += 2 * nr * nr;                        // H, H2 (taped Newton matrix in the adjoint kernel)
   n += 4 * nr;                             // lamq lamv z rhs
   n += (nl + 1) * LK_SIZE;                 // LP
@@ -289,9 +310,13 @@ __host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu) {
 __host__ __device__ inline int ts_cpt_staged(int ncpt, bool env_tables, bool stage) {
   return (!env_tables && stage) ? 3 * ncpt : 0;
 }
+// reals of the staged-table region of a block, a multiple of 4 (what follows holds doubles: keep it 8-byte aligned)
+__host__ __device__ inline int ts_tab_reals(int nfrec, int ncpt, int nslot, bool env_tables, bool stage_cpt) {
+  return ((env_tables ? nslot : 1) * (nfrec + 2) + ts_cpt_staged(ncpt, env_tables, stage_cpt) + 3) & ~3;
+}
 __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, int ncpt, bool stage_cpt, int nslot, bool env_tables, int nsched, int esz) {
-  return (env_tables ? nslot : 1) * (nfrec + 2) + ts_cpt_staged(ncpt, env_tables, stage_cpt)
-       + ((nsched * 4 + esz - 1) / esz + 3) / 4 * 4 + nslot * ts_lds_env_reals(nl, nr, nu) + 8;
+  return ts_tab_reals(nfrec, ncpt, nslot, env_tables, stage_cpt)
+       + ((nsched * 4 + esz - 1) / esz + 3) / 4 * 4 + nslot * ts_lds_env_reals(nl, nr, nu, esz) + 8;
 }
 
 // Sweep schedule (built on the host from the link parents, appended to the device copy of the int blob at I[TSIM_IH_NI]):
@@ -322,12 +347,11 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     if (Fenv) {                                  // per-environment float tables (domain randomisation): one copy per slot
       mf += slot * (nfrec + 2);
       for (int i = lane; i < nfrec; i += lpe) mf[i] = Fenv[i];
-      lds += nslot * (nfrec + 2);
     } else {
       const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, I[I[TSIM_IH_NI] + TS_SCHED_STAGE_CPT] != 0);   // tables (+ contact points)
       for (int i = threadIdx.x; i < nst; i += TS_WAVE) mf[i] = F[i];
-      lds += nst + 2;
     }
+    lds += ts_tab_reals(nfrec, I[TSIM_IH_NCPT], nslot, Fenv != nullptr, I[I[TSIM_IH_NI] + TS_SCHED_STAGE_CPT] != 0);
     {                                            // sweep schedule + link int records (one copy per block)
       const int* S = I + I[TSIM_IH_NI];
       const int ns = S[0];
@@ -355,7 +379,14 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
   c.max_iter = I[TSIM_IH_MAX_ITER]; c.max_ls = I[TSIM_IH_MAX_LS];
   c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
   int nr = c.nr, nl = c.nl, nd = c.nd;
-  R* p = lds + slot * ts_lds_env_reals(nl, nr, c.nu);
+  R* p = lds + slot * ts_lds_env_reals(nl, nr, c.nu, (int)sizeof(R));
+  {
+    double* d = reinterpret_cast<double*>(p);
+    c.qD = d; d += nr; c.q0D = d; d += nr; c.qpD = d; d += nr; c.qm1D = d; d += nr;
+    c.LPd = d; d += (nl + 1) * 12;
+    c.PPd = d; d += TS_PAIR_GROUP * 12;
+    p = reinterpret_cast<R*>(d);
+  }
   c.q = p; p += nr; c.q0 = p; p += nr; c.qd0 = p; p += nr; c.qd = p; p += nr; c.qa = p; p += nr;
   c.g = p; p += nr; c.dq = p; p += 2 * nr; c.dl = p; p += 2 * nr;
   c.qp = p; p += nr; c.qdp = p; p += nr; c.qm1 = p; p += nr; c.qdm1 = p; p += nr; c.u = p; p += c.nu;
@@ -381,6 +412,7 @@ template <class R> __device__ __forceinline__ void init_world(const Ctx<R>& c, i
     c.LP[i] = v;
   }
   for (int i = lane; i < (c.nl + 1) * c.nd * DT_SIZE; i += lpe) c.DT[i] = R(0);    // incl. the (link, dof) records no sweep writes
+  for (int i = lane; i < 12; i += lpe) c.LPd[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
 }
 
 __device__ __forceinline__ int anc_of(const int* I, int off_link, int link) {
@@ -391,27 +423,30 @@ __device__ __forceinline__ int anc_of(const int* I, int off_link, int link) {
 // DiffHand penalty model in the primitive's frame: d < 0:  fn = (-kn + kd ddot) d,  ft = -min(kt |vt|, mu |fn|) vt/|vt|.
 // x = point in the primitive frame, v = its velocity relative to the primitive (same frame).
 // Returns the force on the point; with JAC also Jx = dF/dx and Jv = dF/dv (exact: the law is piecewise smooth).
+// xh: the same point in double — the signed distance (a small difference of large numbers) is taken from it.
 template <class R, bool JAC>
-__device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv) {
+__device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv, V3<double> xh) {
   const R kn = kp[0], kt = kp[1], mu = kp[2], kd = kp[3];
   R d; V3<R> n;
   R ncurv = R(0);          // N = dn/dx = ncurv * (Pm - n n^T), Pm = diag(1, 1, pz)
   R pz = R(1);
-  if (prim == TSIM_P_PLANE) { d = x.z; n = mk3<R>(R(0), R(0), R(1)); }
+  if (prim == TSIM_P_PLANE) { d = (R)xh.z; n = mk3<R>(R(0), R(0), R(1)); }
   else if (prim == TSIM_P_CUBOID) {
-    const R ex = t_abs(x.x) - shape[0], ey = t_abs(x.y) - shape[1], ez = t_abs(x.z) - shape[2];
-    if (ex >= ey && ex >= ez) { const R s = x.x >= R(0) ? R(1) : R(-1); d = ex; n = mk3<R>(s, R(0), R(0)); }
-    else if (ey >= ez)        { const R s = x.y >= R(0) ? R(1) : R(-1); d = ey; n = mk3<R>(R(0), s, R(0)); }
-    else                      { const R s = x.z >= R(0) ? R(1) : R(-1); d = ez; n = mk3<R>(R(0), R(0), s); }
+    const double ex = fabs(xh.x) - (double)shape[0], ey = fabs(xh.y) - (double)shape[1], ez = fabs(xh.z) - (double)shape[2];
+    if (ex >= ey && ex >= ez) { const R s = xh.x >= 0.0 ? R(1) : R(-1); d = (R)ex; n = mk3<R>(s, R(0), R(0)); }
+    else if (ey >= ez)        { const R s = xh.y >= 0.0 ? R(1) : R(-1); d = (R)ey; n = mk3<R>(R(0), s, R(0)); }
+    else                      { const R s = xh.z >= 0.0 ? R(1) : R(-1); d = (R)ez; n = mk3<R>(R(0), R(0), s); }
   } else if (prim == TSIM_P_SPHERE) {
-    const R r2 = dot3(x, x);
-    if (r2 < R(1e-24)) return false;
-    const R r = t_sqrt(r2); d = r - shape[0]; n = x * (R(1) / r); ncurv = R(1) / r;
+    const double r2 = xh.x * xh.x + xh.y * xh.y + xh.z * xh.z;
+    if (r2 < 1e-24) return false;
+    const double rr = sqrt(r2);
+    const R r = (R)rr; d = (R)(rr - (double)shape[0]); n = x * (R(1) / r); ncurv = R(1) / r;
   } else {
-    const R rho = t_sqrt(x.x * x.x + x.y * x.y);
-    const R dr = rho - shape[0], dz = t_abs(x.z) - shape[1];
-    if (dr > dz && rho > R(1e-12)) { d = dr; const R ir = R(1) / rho; n = mk3<R>(x.x * ir, x.y * ir, R(0)); ncurv = ir; pz = R(0); }
-    else { const R s = x.z >= R(0) ? R(1) : R(-1); d = dz; n = mk3<R>(R(0), R(0), s); }
+    const double rhod = sqrt(xh.x * xh.x + xh.y * xh.y);
+    const double dr = rhod - (double)shape[0], dz = fabs(xh.z) - (double)shape[1];
+    const R rho = (R)rhod;
+    if (dr > dz && rhod > 1e-12) { d = (R)dr; const R ir = R(1) / rho; n = mk3<R>(x.x * ir, x.y * ir, R(0)); ncurv = ir; pz = R(0); }
+    else { const R s = xh.z >= 0.0 ? R(1) : R(-1); d = (R)dz; n = mk3<R>(R(0), R(0), s); }
   }
   if (!(d < R(0))) return false;
   const R dd = dot3(n, v);

@@ -29,9 +29,10 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
     for (int i = 1; i <= c.nl; ++i)                  // (contacts couple branches: phase 2 adds to them)
       if (S[rec0 + (i - 1) * TS_LR_SIZE + TS_LR_BRANCH] != mybranch) st6(c.DT + (i * nd + k) * DT_SIZE + DT_FN, zero6<R>());
   }
-  M3<R> pR; V3<R> pp; S6<R> pV, pA, pdV, pdA;        // state of the link this lane processed in the previous step
+  M3<double> pRd; V3<double> ppd;                    // pose of the link this lane processed in the previous step (double)
+  S6<R> pV, pA, pdV, pdA;                            // ... its twist, acceleration and their tangents
   S6<R> Wk = zero6<R>();                             // twist column of this lane's own dof, once its link has been swept
-  pR = ldm(c.LP + LK_R); pp = zero3<R>(); pV = zero6<R>(); pA = zero6<R>(); pdV = zero6<R>(); pdA = zero6<R>();
+  pRd = ldm(c.LPd); ppd = zero3<double>(); pV = zero6<R>(); pA = zero6<R>(); pdV = zero6<R>(); pdA = zero6<R>();
   int prev = 0;
   for (int st = 0; st < nsteps; ++st) {
     __syncthreads();                                 // value records stored by the leaders in the previous step
@@ -43,15 +44,19 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
     const R* lf = c.F + c.foff_link + (i - 1) * TSIM_LF_SIZE;
     const int par = li[TS_LR_PARENT], jt = li[TS_LR_JTYPE], k0 = li[TS_LR_DOF0], ndj = li[TS_LR_NDOF], ancm = li[TS_LR_ANCMASK];
     R* X = c.LP + i * LK_SIZE;
-    M3<R> PR; V3<R> Pp; S6<R> PV, PA, PdV = zero6<R>(), PdA = zero6<R>();
-    if (par == prev && par > 0) { PR = pR; Pp = pp; PV = pV; PA = pA; PdV = pdV; PdA = pdA; }
+    M3<double> PRd; V3<double> Ppd; S6<R> PV, PA, PdV = zero6<R>(), PdA = zero6<R>();
+    if (par == prev && par > 0) { PRd = pRd; Ppd = ppd; PV = pV; PA = pA; PdV = pdV; PdA = pdA; }
     else {
       const R* P = c.LP + par * LK_SIZE;
-      PR = ldm(P + LK_R); Pp = ldv(P + LK_P); PV = ld6(P + LK_W); PA = ld6(P + LK_AW);
+      PRd = ldm(c.LPd + par * 12); Ppd = ldv(c.LPd + par * 12 + 9); PV = ld6(P + LK_W); PA = ld6(P + LK_AW);
       if (act && par > 0) { const R* Dp = c.DT + (par * nd + k) * DT_SIZE; PdV = ld6(Dp + DT_VW); PdA = ld6(Dp + DT_AW); }
     }
-    const M3<R> R0 = mulMM(PR, ldm(lf + TSIM_LF_R));
-    V3<R> Xp = mulMv(PR, ldv(lf + TSIM_LF_P)) + Pp;
+    // pose chain in double (Ctx): R0d = joint frame before the joint motion, (XRd, Xpd) = link frame
+    const M3<double> R0d = mulMM(PRd, ldm_as<double>(lf + TSIM_LF_R));
+    V3<double> Xpd = mulMv(PRd, ldv_as<double>(lf + TSIM_LF_P)) + Ppd;
+    M3<double> XRd = R0d;
+    const M3<R> R0 = cvtm<R>(R0d);
+    V3<R> Xp = cvt3<R>(Xpd);
     M3<R> XR = R0;
     const R* ax = lf + TSIM_LF_AXES;
     S6<R> VJ = zero6<R>(), AJ = zero6<R>();
@@ -77,7 +82,8 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
       M3<R> Em;
 #pragma unroll
       for (int e = 0; e < 9; ++e) Em.m[e] = E[e];
-      XR = mulMM(R0, Em);
+      XRd = mulMM(R0d, cvtm<double>(Em));            // the rotation-vector exponential itself is evaluated in R
+      XR = cvtm<R>(XRd);
       const V3<R> thd = mk3<R>(c.qd[k0], c.qd[k0 + 1], c.qd[k0 + 2]);
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
@@ -116,13 +122,15 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
         }
       }
     } else if (jt == TSIM_J_REVOLUTE) {
-      R s, co; t_sincos(c.q[k0], s, co);
-      const R t = R(1) - co;
-      M3<R> Q;
-      Q.m[0] = t * ax[0] * ax[0] + co;         Q.m[1] = t * ax[0] * ax[1] - s * ax[2];  Q.m[2] = t * ax[0] * ax[2] + s * ax[1];
-      Q.m[3] = t * ax[0] * ax[1] + s * ax[2];  Q.m[4] = t * ax[1] * ax[1] + co;         Q.m[5] = t * ax[1] * ax[2] - s * ax[0];
-      Q.m[6] = t * ax[0] * ax[2] - s * ax[1];  Q.m[7] = t * ax[1] * ax[2] + s * ax[0];  Q.m[8] = t * ax[2] * ax[2] + co;
-      XR = mulMM(R0, Q);
+      double s, co; t_sincos_d(c.qD[k0], s, co);
+      const double t = 1.0 - co;
+      const double a0 = (double)ax[0], a1 = (double)ax[1], a2 = (double)ax[2];
+      M3<double> Q;
+      Q.m[0] = t * a0 * a0 + co;       Q.m[1] = t * a0 * a1 - s * a2;  Q.m[2] = t * a0 * a2 + s * a1;
+      Q.m[3] = t * a0 * a1 + s * a2;   Q.m[4] = t * a1 * a1 + co;      Q.m[5] = t * a1 * a2 - s * a0;
+      Q.m[6] = t * a0 * a2 - s * a1;   Q.m[7] = t * a1 * a2 + s * a0;  Q.m[8] = t * a2 * a2 + co;
+      XRd = mulMM(R0d, Q);
+      XR = cvtm<R>(XRd);
       const V3<R> a = mulMv(R0, ldv(ax));          // the axis is invariant under its own rotation
       Wj[0] = mk6<R>(a, cross3(Xp, a)); Wj[1] = zero6<R>(); Wj[2] = zero6<R>();
       VJ = Wj[0] * c.qd[k0]; AJ = Wj[0] * c.qa[k0];
@@ -133,7 +141,8 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
         if (kk < ndj) {
           const R e[3] = {kk == 0 ? R(1) : R(0), kk == 1 ? R(1) : R(0), kk == 2 ? R(1) : R(0)};
           const V3<R> a = mulMv(R0, ldv(jt == TSIM_J_TRANSLATIONAL ? e : ax + 3 * kk));
-          Xp = Xp + a * c.q[k0 + kk];
+          Xpd = Xpd + mulMv(R0d, ldv_as<double>(jt == TSIM_J_TRANSLATIONAL ? e : ax + 3 * kk)) * c.qD[k0 + kk];
+          Xp = cvt3<R>(Xpd);
           Wj[kk] = mk6<R>(zero3<R>(), a);
           VJ = VJ + Wj[kk] * c.qd[k0 + kk]; AJ = AJ + Wj[kk] * c.qa[k0 + kk];
         }
@@ -161,6 +170,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
     const R mass = lf[TSIM_LF_MASS];
     const S6<R> h = imul(mass, cw, Ic, V), IA = imul(mass, cw, Ic, A);
     if (leader) {
+      stm(c.LPd + i * 12, XRd); stv(c.LPd + i * 12 + 9, Xpd);
       stm(X + LK_R, XR); stv(X + LK_P, Xp); st6(X + LK_W, V); st6(X + LK_AW, A); st6(X + LK_FN, IA + crf(V, h));
       stv(X + LK_C, cw);
 #pragma unroll
@@ -197,7 +207,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
       }
       st6(D + DT_VW, dV); st6(D + DT_AW, dA); st6(D + DT_FN, dF);
     }
-    pR = XR; pp = Xp; pV = V; pA = A; pdV = dV; pdA = dA; prev = i;
+    pRd = XRd; ppd = Xpd; pV = V; pA = A; pdV = dV; pdA = dA; prev = i;
   }
   __syncthreads();
 }
@@ -209,17 +219,22 @@ template <class R>
 __device__ __forceinline__ void pair_stage_value(const Ctx<R>& c, int pk, int slot, bool store) {
   const int* pi = ts_pair_rec(c, pk);
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-  const R* A = c.LP + pi[TSIM_PI_LINKA] * LK_SIZE;
-  const R* B = c.LP + pi[TSIM_PI_LINKB] * LK_SIZE;
-  const M3<R> RB = ldm(B + LK_R);
-  const M3<R> RP = mulMM(RB, ldm(pf + TSIM_PF_R));
-  const V3<R> pP = mulMv(RB, ldv(pf + TSIM_PF_P)) + ldv(B + LK_P);
-  const M3<R> RPA = mulMtM(RP, ldm(A + LK_R));
-  const V3<R> pPA = mulMtv(RP, ldv(A + LK_P) - pP);
+  const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB];
+  const R* A = c.LP + la * LK_SIZE;
+  const R* B = c.LP + lb * LK_SIZE;
+  // relative pose in double: it is what the penetration depths are computed from
+  const M3<double> RBd = ldm(c.LPd + lb * 12);
+  const M3<double> RPd = mulMM(RBd, ldm_as<double>(pf + TSIM_PF_R));
+  const V3<double> pPd = mulMv(RBd, ldv_as<double>(pf + TSIM_PF_P)) + ldv(c.LPd + lb * 12 + 9);
+  const M3<double> RPAd = mulMtM(RPd, ldm(c.LPd + la * 12));
+  const V3<double> pPAd = mulMtv(RPd, ldv(c.LPd + la * 12 + 9) - pPd);
+  const M3<R> RP = cvtm<R>(RPd);
+  const V3<R> pP = cvt3<R>(pPd);
   const S6<R> Vrel = to_frame(RP, pP, ld6(A + LK_W) - ld6(B + LK_W));
   if (store) {
     R* S = c.PP + slot * PP_SIZE;
-    stm(S + PP_RPA, RPA); stv(S + PP_PPA, pPA); st6(S + PP_WREL, Vrel); stm(S + PP_RP, RP); stv(S + PP_PP, pP);
+    stm(c.PPd + slot * 12, RPAd); stv(c.PPd + slot * 12 + 9, pPAd);
+    stm(S + PP_RPA, cvtm<R>(RPAd)); stv(S + PP_PPA, cvt3<R>(pPAd)); st6(S + PP_WREL, Vrel); stm(S + PP_RP, RP); stv(S + PP_PP, pP);
     st6(S + PP_WN, zero6<R>());
   }
 }
@@ -271,8 +286,9 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
   const int prim = pi[TSIM_PI_PRIM];
   const bool sphere_plane = (pi[TSIM_PI_FLAGS] & 2) != 0;
   R* S = c.PP + slot * PP_SIZE;
-  const M3<R> RPA = ldm(S + PP_RPA);
-  const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+  const M3<double> RPAd = ldm(c.PPd + slot * 12);
+  const V3<double> pPAd = ldv(c.PPd + slot * 12 + 9);
+  const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
   R w0[6], M[6][12];               // value wrench (n; F) and d(n; F) / d(dth, drho, dw, dv)
 #pragma unroll
   for (int e = 0; e < 6; ++e) {
@@ -288,10 +304,11 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
     M3<R> Jx, Jv;
     if (pidx < npt) {
       const R* cp = c.CPT + pt0 + pidx;                    // SoA: consecutive lanes -> consecutive addresses
-      cP = mulMv(RPA, mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt])) + pPA;
-      xP = cP;
-      if (sphere_plane) xP.z -= pf[TSIM_PF_SHAPE];         // lowest point of the sphere (plane normal = +z of P)
-      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv);
+      V3<double> xPd = mulMv(RPAd, mk3<double>((double)cp[0], (double)cp[c.ncpt], (double)cp[2 * c.ncpt])) + pPAd;
+      cP = cvt3<R>(xPd);
+      if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
+      xP = cvt3<R>(xPd);
+      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
     }
     if (!__any(hit)) continue;
     any_hit = true;
@@ -378,8 +395,9 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
   const bool sphere_plane = (pi[TSIM_PI_FLAGS] & 2) != 0;
   const int anc = anc_of(c.I, c.off_link, la) | anc_of(c.I, c.off_link, lb);
   R* S = c.PP + slot * PP_SIZE;
-  const M3<R> RPA = ldm(S + PP_RPA);
-  const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+  const M3<double> RPAd = ldm(c.PPd + slot * 12);
+  const V3<double> pPAd = ldv(c.PPd + slot * 12 + 9);
+  const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
   R acc[NRM + 1][6];
 #pragma unroll
   for (int d = 0; d <= NRM; ++d)
@@ -393,10 +411,11 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
     M3<R> Jx, Jv;
     if (pidx < npt) {
       const R* cp = c.CPT + pt0 + pidx;                    // SoA: consecutive lanes -> consecutive addresses
-      cP = mulMv(RPA, mk3<R>(cp[0], cp[c.ncpt], cp[2 * c.ncpt])) + pPA;
-      xP = cP;
-      if (sphere_plane) xP.z -= pf[TSIM_PF_SHAPE];         // lowest point of the sphere (plane normal = +z of P)
-      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv);
+      V3<double> xPd = mulMv(RPAd, mk3<double>((double)cp[0], (double)cp[c.ncpt], (double)cp[2 * c.ncpt])) + pPAd;
+      cP = cvt3<R>(xPd);
+      if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
+      xP = cvt3<R>(xPd);
+      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
     }
     if (!__any(hit)) continue;
     any_hit = true;
@@ -606,6 +625,7 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
     c.qd[lane] = c.qdp[lane] + c.cv * d;
     c.qa[lane] = c.ca * d;
     c.q[lane] = c.qp[lane] + d;
+    c.qD[lane] = c.qpD[lane] + (double)d;
   }
   __syncthreads();
   TS_STAMP(c);

@@ -21,8 +21,15 @@
 #include "tsim_eval.h"
 
 
-// tape record per (sub-step, env): q[nr] qd[nr] H[nr*nr] u[nu]
-__host__ __device__ inline int ts_rec(int nr, int nu) { return 2 * nr + nr * nr + nu; }
+// tape record per (sub-step, env), in reals: q[nr] as DOUBLE (the pose chain is double also in the fp32 kernels),
+// qd[nr], H[nr*nr], u[nu]; padded to an even count so that every record starts 8-byte aligned
+__host__ __device__ inline int ts_qw(int esz) { return 8 / esz; }                      // reals per double
+__host__ __device__ inline int ts_rec(int nr, int nu, int esz) { return (ts_qw(esz) * nr + nr + nr * nr + nu + 1) & ~1; }
+template <class R> __device__ __forceinline__ double* rec_q(R* rec) { return reinterpret_cast<double*>(rec); }
+template <class R> __device__ __forceinline__ const double* rec_q(const R* rec) { return reinterpret_cast<const double*>(rec); }
+template <class R> __device__ __forceinline__ int rec_qd(int nr) { return ts_qw((int)sizeof(R)) * nr; }           // offset of qd
+template <class R> __device__ __forceinline__ int rec_H(int nr) { return ts_qw((int)sizeof(R)) * nr + nr; }
+template <class R> __device__ __forceinline__ int rec_u(int nr) { return ts_qw((int)sizeof(R)) * nr + nr + nr * nr; }
 
 // ================================================================================================ read-out
 // variables: lanes = end-effector points; tactile: lanes = taxels (coalesced SoA loads of position / frame,
@@ -61,9 +68,10 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
           const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
           const R* S = c.PP + (j - j0) * PP_SIZE;
           const M3<R> RPA = ldm(S + PP_RPA);
-          const V3<R> xP = mulMv(RPA, xa) + ldv(S + PP_PPA);
+          const V3<double> xPd = mulMv(ldm(c.PPd + (j - j0) * 12), cvt3<double>(xa)) + ldv(c.PPd + (j - j0) * 12 + 9);
+          const V3<R> xP = cvt3<R>(xPd);
           V3<R> F; M3<R> Jx, Jv;
-          if (contact_law<R, false>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, ldv(S + PP_VREL) + cross3(ldv(S + PP_WREL), xP), F, Jx, Jv))
+          if (contact_law<R, false>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, ldv(S + PP_VREL) + cross3(ldv(S + PP_WREL), xP), F, Jx, Jv, xPd))
             Fl = Fl + mulMtv(RPA, F);
         }
         R* o = tac_out + (size_t)env * 3 * c.ntax + 3 * t;
@@ -85,7 +93,7 @@ template <class R> struct FwdArgs {
   R* tape; const R* u;
   R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
   const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
-  R* prev; int has_prev;  // state before the previous sub-step [B][2 nr] (BDF2 history across launches)
+  double* prev; int has_prev;  // state before the previous sub-step [B][2 nr] doubles (BDF2 history across launches)
 };
 
 template <class R, int NRM, bool EXPJ, int LPE>
@@ -101,11 +109,11 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   const bool valid = eidx < a.B;                                        // a batch that is no multiple of NS: idle slot
   const int env = a.order ? a.order[min(eidx, a.B - 1)] : min(eidx, a.B - 1);
   Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
-  const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
+  const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   init_world(c, lane, LPE);
   {
     const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
-    if (lane < nr) { c.q0[lane] = st[lane]; c.qd0[lane] = st[nr + lane]; }
+    if (lane < nr) { c.q0D[lane] = rec_q(st)[lane]; c.q0[lane] = (R)c.q0D[lane]; c.qd0[lane] = st[rec_qd<R>(nr) + lane]; }
   }
   __syncthreads();
   R* dlbase = c.dq + nr;
@@ -114,7 +122,8 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   const bool bdf2_model = c.I[TSIM_IH_INTEGRATOR] == 2;
   bool has_prev = a.has_prev != 0;
   if (bdf2_model && has_prev && lane < nr) {
-    c.qm1[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qdm1[lane] = a.prev[(size_t)env * 2 * nr + nr + lane];
+    c.qm1D[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qm1[lane] = (R)c.qm1D[lane];
+    c.qdm1[lane] = (R)a.prev[(size_t)env * 2 * nr + nr + lane];
   }
   __syncthreads();
   // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
@@ -127,13 +136,14 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     if (bdf2_model && has_prev) {
       c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h);
       if (lane < nr) {
-        const R qp = R(4.0 / 3) * c.q0[lane] - R(1.0 / 3) * c.qm1[lane] + c.h * (R(8.0 / 9) * c.qd0[lane] - R(2.0 / 9) * c.qdm1[lane]);
-        c.qp[lane] = qp;
-        c.qdp[lane] = (R(3) * qp - R(4) * c.q0[lane] + c.qm1[lane]) / (R(2) * c.h);
+        const double hD = (double)c.h;
+        const double qp = 4.0 / 3 * c.q0D[lane] - 1.0 / 3 * c.qm1D[lane] + hD * (8.0 / 9 * (double)c.qd0[lane] - 2.0 / 9 * (double)c.qdm1[lane]);
+        c.qpD[lane] = qp; c.qp[lane] = (R)qp;
+        c.qdp[lane] = (R)((3.0 * qp - 4.0 * c.q0D[lane] + c.qm1D[lane]) / (2.0 * hD));
       }
     } else {
       c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
-      if (lane < nr) { c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane]; }
+      if (lane < nr) { c.qpD[lane] = c.q0D[lane] + (double)c.h * (double)c.qd0[lane]; c.qp[lane] = (R)c.qpD[lane]; c.qdp[lane] = c.qd0[lane]; }
     }
     const R sq = R(1), sv = c.cv, sa = c.ca;
     if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
@@ -202,12 +212,15 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     // commit the sub-step: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
     if (a.record && valid) {
       R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
-      if (lane < nr) { rec[lane] = c.q[lane]; rec[nr + lane] = c.qd[lane]; }
-      for (int e = lane; e < nr * nr; e += LPE) rec[2 * nr + e] = c.H[e];
-      if (lane < nu) rec[2 * nr + nr * nr + lane] = c.u[lane];
+      if (lane < nr) { rec_q(rec)[lane] = c.qD[lane]; rec[rec_qd<R>(nr) + lane] = c.qd[lane]; }
+      for (int e = lane; e < nr * nr; e += LPE) rec[rec_H<R>(nr) + e] = c.H[e];
+      if (lane < nu) rec[rec_u<R>(nr) + lane] = c.u[lane];
     }
     __syncthreads();
-    if (lane < nr) { c.qm1[lane] = c.q0[lane]; c.qdm1[lane] = c.qd0[lane]; c.q0[lane] = c.q[lane]; c.qd0[lane] = c.qd[lane]; }
+    if (lane < nr) {
+      c.qm1[lane] = c.q0[lane]; c.qm1D[lane] = c.q0D[lane]; c.qdm1[lane] = c.qd0[lane];
+      c.q0[lane] = c.q[lane]; c.q0D[lane] = c.qD[lane]; c.qd0[lane] = c.qd[lane];
+    }
     has_prev = true;
     __syncthreads();
   }
@@ -223,10 +236,10 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   __syncthreads();
   }
   if (valid) {
-    if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = c.qdm1[lane]; }
+    if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1D[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = (double)c.qdm1[lane]; }
     if (!a.record) {
       R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
-      if (lane < nr) { st[lane] = c.q0[lane]; st[nr + lane] = c.qd0[lane]; }
+      if (lane < nr) { rec_q(st)[lane] = c.q0D[lane]; st[rec_qd<R>(nr) + lane] = c.qd0[lane]; }
     }
     if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
     if (a.evals && lane == 0) a.evals[env] = evals;
@@ -265,10 +278,10 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
   Ctx<R> c; ctx_init(c, a.I, a.F, lds, 1, 0, lane, TS_WAVE, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
-  const int nr = c.nr, REC = ts_rec(nr, c.nu);
+  const int nr = c.nr, REC = ts_rec(nr, c.nu, (int)sizeof(R));
   init_world(c, lane, TS_WAVE);
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
-  if (lane < nr) { c.q[lane] = st[lane]; c.qd[lane] = st[nr + lane]; c.qa[lane] = R(0); }
+  if (lane < nr) { c.qD[lane] = rec_q(st)[lane]; c.q[lane] = (R)c.qD[lane]; c.qd[lane] = st[rec_qd<R>(nr) + lane]; c.qa[lane] = R(0); }
   __syncthreads();
   phase1<R, false, true>(c, lane, R(0), R(0), R(0));
   // high-resolution sensors (RollingBall: 40 000 taxels): blockIdx.y selects a slice of the taxels, so one
@@ -294,6 +307,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
     c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane];
     c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane];
     c.dl[lane] = a.q1[(size_t)env * nr + lane] - c.qp[lane];
+    c.qpD[lane] = (double)a.q1[(size_t)env * nr + lane] - (double)c.dl[lane];      // so that qD = qpD + dl is the given q1
   }
   if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
   __syncthreads();
@@ -391,8 +405,9 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
         bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
         V3<R> xP, F; M3<R> Jx, Jv;
         if (live) {
-          xP = mulMv(RPA, mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax])) + pPA;
-          live = contact_law<R, true>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv);
+          const V3<double> xPd = mulMv(ldm(c.PPd), mk3<double>((double)tp[0], (double)tp[c.ntax], (double)tp[2 * c.ntax])) + ldv(c.PPd + 9);
+          xP = cvt3<R>(xPd);
+          live = contact_law<R, true>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
         }
         if (!__any(live)) continue;
         any_live = true;
@@ -444,7 +459,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
   const bool valid = (int)blockIdx.x * NS + slot < a.B;
   const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
   Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
-  const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu);
+  const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
   R* H2 = c.H2;    // taped Newton matrix of the sub-step
   init_world(c, lane, LPE);
@@ -456,12 +471,13 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
     const R* r1 = a.tape + ((size_t)t * a.B + env) * REC;
     const R* r0 = a.tape + ((size_t)(t - 1) * a.B + env) * REC;
     if (lane < nr) {
-      c.q[lane] = r1[lane]; c.q0[lane] = r0[lane]; c.qd0[lane] = r0[nr + lane];
-      c.qd[lane] = r1[nr + lane];                               // taped (q1 - q0)/h
-      c.qa[lane] = (r1[nr + lane] - r0[nr + lane]) / c.h;       // discrete acceleration, no position cancellation
+      const int oqd = rec_qd<R>(nr);
+      c.qD[lane] = rec_q(r1)[lane]; c.q[lane] = (R)c.qD[lane]; c.q0[lane] = (R)rec_q(r0)[lane]; c.qd0[lane] = r0[oqd + lane];
+      c.qd[lane] = r1[oqd + lane];                              // taped (q1 - q0)/h
+      c.qa[lane] = (r1[oqd + lane] - r0[oqd + lane]) / c.h;     // discrete acceleration, no position cancellation
     }
-    if (lane < nu) c.u[lane] = r1[2 * nr + nr * nr + lane];
-    for (int e = lane; e < nr * nr; e += LPE) H2[e] = r1[2 * nr + e];
+    if (lane < nu) c.u[lane] = r1[rec_u<R>(nr) + lane];
+    for (int e = lane; e < nr * nr; e += LPE) H2[e] = r1[rec_H<R>(nr) + e];
     __syncthreads();
     phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
     // direct partials of the loss w.r.t. this sub-step's outputs
@@ -597,25 +613,25 @@ template <class R> __global__ void k_set_state(R* tape, const R* q, const R* qd,
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nr) return;
   int env = i / nr, k = i % nr;
-  tape[(size_t)env * rec + k] = q[i];
-  tape[(size_t)env * rec + nr + k] = qd ? qd[i] : R(0);
+  rec_q(tape + (size_t)env * rec)[k] = (double)q[i];
+  tape[(size_t)env * rec + rec_qd<R>(nr) + k] = qd ? qd[i] : R(0);
 }
 // masked variant: only environments with mask[env] != 0 get the new state (record t of the tape)
-template <class R> __global__ void k_set_state_masked(R* tape_rec, const R* q, const R* qd, const int32_t* mask, R* prev, R h, int B, int nr, int rec) {
+template <class R> __global__ void k_set_state_masked(R* tape_rec, const R* q, const R* qd, const int32_t* mask, double* prev, R h, int B, int nr, int rec) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nr) return;
   int env = i / nr, k = i % nr;
   if (!mask[env]) return;
-  tape_rec[(size_t)env * rec + k] = q[i];
-  tape_rec[(size_t)env * rec + nr + k] = qd ? qd[i] : R(0);
-  if (prev) { const R v = qd ? qd[i] : R(0); prev[(size_t)env * 2 * nr + k] = q[i] - h * v; prev[(size_t)env * 2 * nr + nr + k] = v; }
+  rec_q(tape_rec + (size_t)env * rec)[k] = (double)q[i];
+  tape_rec[(size_t)env * rec + rec_qd<R>(nr) + k] = qd ? qd[i] : R(0);
+  if (prev) { const double v = qd ? (double)qd[i] : 0.0; prev[(size_t)env * 2 * nr + k] = (double)q[i] - (double)h * v; prev[(size_t)env * 2 * nr + nr + k] = v; }
 }
 template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, int B, int nr, int rec) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nr) return;
   int env = i / nr, k = i % nr;
-  if (q) q[i] = tape_rec[(size_t)env * rec + k];
-  if (qd) qd[i] = tape_rec[(size_t)env * rec + nr + k];
+  if (q) q[i] = (R)rec_q(tape_rec + (size_t)env * rec)[k];
+  if (qd) qd[i] = tape_rec[(size_t)env * rec + rec_qd<R>(nr) + k];
 }
 
 // dynamic LDS of a block of nslot environments
@@ -677,7 +693,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = tac_slot;
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
-  a.prev = (R*)b->prev; a.has_prev = b->has_prev;
+  a.prev = (double*)b->prev; a.has_prev = b->has_prev;
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
   if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
@@ -726,8 +742,8 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->B = B; b->dtype = dtype; b->device = device; b->cap = tape_capacity;
   b->I.assign(I, I + I[TSIM_IH_NI]); b->F.assign(F, F + I[TSIM_IH_NF]);
   b->nl = nl; b->nr = nr; b->nu = nu; b->nvar = I[TSIM_IH_NVAR]; b->ntax = I[TSIM_IH_NTAXEL];
-  b->rec = ts_rec(nr, nu);
   b->esz = dtype == TSIM_F32 ? 4 : 8;
+  b->rec = ts_rec(nr, nu, (int)b->esz);
   b->t_cur = 0; b->record = 0; b->has_exp = n_exp > 0;
   b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT];
   b->lpe_forced = 0;
@@ -748,7 +764,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * b->esz) != hipSuccess) {
+      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
   }
@@ -846,7 +862,7 @@ int tsim_reset_masked(tsim_batch* b, const void* q0, const void* qd0, const int3
   size_t off = (size_t)b->t_cur * b->B * b->rec;
   // BDF2 models: the environment restarts with a constant-velocity history (q_-1 = q0 - h qd0, qd_-1 = qd0) [CHOICE]
   void* prev = (b->I[TSIM_IH_INTEGRATOR] == 2 && b->has_prev) ? b->prev : nullptr;
-  if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_set_state_masked<float>, dim3(grd), dim3(blk), 0, st, (float*)b->tape + off, (const float*)q0, (const float*)qd0, mask, (float*)prev, (float)b->F[TSIM_FH_H], b->B, b->nr, b->rec);
+  if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_set_state_masked<float>, dim3(grd), dim3(blk), 0, st, (float*)b->tape + off, (const float*)q0, (const float*)qd0, mask, (double*)prev, (float)b->F[TSIM_FH_H], b->B, b->nr, b->rec);
   else hipLaunchKernelGGL(k_set_state_masked<double>, dim3(grd), dim3(blk), 0, st, (double*)b->tape + off, (const double*)q0, (const double*)qd0, mask, (double*)prev, b->F[TSIM_FH_H], b->B, b->nr, b->rec);
   HIPCHK(hipGetLastError());
   return 0;
