@@ -34,9 +34,11 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 
 
 def algorithmic_bytes(nr, nu, nvar, ntac, S, esz):
-    """per env-step, state on chip across the S sub-steps, model constants batch-shared."""
-    fwd = esz * (nu + nr + nvar + ntac + 2 * nr * S)
-    bwd = esz * (2 * nr * S + nr + nvar + ntac + nu * S)
+    """per env-step, state on chip across the S sub-steps, model constants batch-shared.  The taped state is
+    (q as double, qd) per sub-step: the pose chain is double also in the fp32 kernels."""
+    tape = S * nr * (8 + esz)
+    fwd = esz * (nu + nr + nvar + ntac) + tape
+    bwd = tape + esz * (nr + nvar + ntac + nu * S)
     return fwd, bwd
 
 

@@ -8,6 +8,8 @@
  * One `tsim_batch` = B independent environments of one model, resident on one GPU.  The reference's
  * one-environment `Simulation` object is B = 1.  All array arguments are DEVICE pointers of the batch's
  * real type (float for TSIM_F32, double for TSIM_F64), env-major ([B][dim], C order) unless noted.
+ * TSIM_F32 batches are mixed precision inside: positions, link poses and penetration depths are double, everything
+ * else float; the interface stays float.
  * `stream` is a hipStream_t (NULL = default stream).  Functions return 0 on success, non-zero on error
  * (message via tsim_last_error()).  Calls on one batch must be serialised by the caller (the reference's
  * Simulation is single-threaded as well: algorithms/gd.py:30 torch.set_num_threads(1)).
