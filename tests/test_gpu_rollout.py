@@ -1,5 +1,7 @@
 """tsim_rollout / tsim_backward_episode (the open-loop episode of EpisodicSimFunction, envs/redmax_torch_functions.py:
 46-57, 77-92, as one launch each): bit-identical to the per-step entry points, and checked against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -242,3 +244,47 @@ def test_launch_shapes_agree(pusher_model, dtype, tol, monkeypatch):
         for k, ref in res[64].items():
             err = float((res[lpe][k] - ref).abs().max())
             assert err <= tol * max(float(ref.abs().max()), 1e-3), (lpe, k, err)
+
+
+@pytest.mark.parametrize("dtype,tq,tt,tg", [(torch.float64, 1e-10, 1e-9, 1e-9), (torch.float32, 5e-6, 2e-4, 1e-4)])
+def test_full_episodes_against_the_oracle(pusher_model, dtype, tq, tt, tg):
+    """64 environments x 100 env-steps (the bench's episode length) through tsim_rollout / tsim_backward_episode against the
+    oracle, with the XML's own Newton tolerance: trajectories, tactile fields and the 100-step episode gradients.  The fp32
+    bound on the gradients is the BASELINE.md target (1e-4)."""
+    import threading
+    from tactilesimulation_amd.host.batch import BatchSim
+    from oracle.oracle import OracleSim
+    B, T, S = 64, 100, 5
+    q0, u, _ = push_workload(B, T, seed=23)
+    rng = np.random.default_rng(4)
+    wq, wv, wt = rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0
+    Q, TAC, G = np.zeros((T, B, 7)), np.zeros((T, B, 390)), np.zeros((T, B, 6))
+    nthr = min(len(os.sched_getaffinity(0)), 16)
+
+    def work(i):                                              # one oracle instance per thread (ctypes releases the GIL)
+        o = OracleSim(pusher_model)
+        for e in range(i, B, nthr):
+            o.reset(q0[e], record=True)
+            for t in range(T):
+                assert o.forward(u[e, t], S) == 0
+                Q[t, e], _ = o.state()
+                _, TAC[t, e] = o.outputs()
+            for t in reversed(range(T)):
+                dq = np.zeros((S, 7)); dq[-1] = wq[t]
+                dv = np.zeros((S, 6)); dv[-1] = wv[t]
+                dt_ = np.zeros((S, 390)); dt_[-1] = wt[t]
+                G[t, e] = o.backward_steps(S, dq, dv, dt_).sum(0)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dev = "cuda:0"
+    sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+    sim.reset(torch.tensor(q0, device=dev, dtype=dtype), None, backward_flag=True)
+    ro = sim.rollout(torch.tensor(u, device=dev, dtype=dtype).transpose(0, 1).contiguous(), S)
+    assert int((ro["status"] != 0).sum()) == 0
+    tile = lambda w: torch.tensor(np.broadcast_to(w[:, None, :], (T, B, w.shape[1])).copy(), device=dev, dtype=dtype)
+    du = sim.backward_episode(T, S, tile(wq), tile(wv), tile(wt)).double().cpu().numpy()
+    assert np.abs(ro["q"].double().cpu().numpy() - Q).max() < tq
+    assert np.abs(ro["tactile"].double().cpu().numpy() - TAC).max() < tt * np.abs(TAC).max()
+    eg = np.abs(du - G).max(axis=(0, 2)) / np.abs(G).max(axis=(0, 2))
+    assert eg.max() < tg, eg.max()
