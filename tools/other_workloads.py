@@ -38,7 +38,20 @@ def run(name, B, T, S, dtype=torch.float32, reps=3):
         ro = sim.rollout(ud, S)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         best_ep = dt if best_ep is None else min(best_ep, dt)
+    # forward + adjoint, one launch each way (seeds on q / variables / tactile of every frame)
+    simr = BatchSim(m, B, dtype=dtype, tape_capacity=T * S)
+    ones = lambda d: torch.ones(T, B, d, device="cuda", dtype=dtype)
+    wq, wv, wt = ones(simr.ndof_r), (ones(simr.ndof_var) if simr.ndof_var else None), ones(simr.ndof_tactile)
+    best_fb = None
+    for r in range(reps):
+        simr.reset(q0d, None, True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        simr.rollout(ud, S)
+        simr.backward_episode(T, S, wq, wv, wt)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best_fb = dt if best_fb is None else min(best_fb, dt)
     return {"model": name, "B": B, "env_steps": T, "substeps_per_env_step": S, "dtype": str(dtype),
+            "episode_fwd_adjoint_env_steps_per_s": B * T / best_fb,
             "env_steps_per_s": B * T / best, "substeps_per_s": B * T * S / best, "nonconverged_last": int((out["status"] != 0).sum()),
             "episode_launch_env_steps_per_s": B * T / best_ep, "episode_nonconverged": int((ro["status"] != 0).sum()),
             "launch_shape": sim.launch_info()}
