@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Batched analytic-gradient training of the TactilePush policy — the MI355X counterpart of the reference's
+examples/TactilePushExp/train_tactile_push_gd.py + algorithms/gd.py (cfg/gd_tactile.yaml: 393 -> 64 -> 64 -> 3 actor,
+Adam, gradient-norm clip, 100-step episodes).  There, `num_episodes` episodes run one after the other through one
+Simulation; here they are one batch per GPU.
+
+    python examples/train_tactile_push_gd_batched.py --batch 4096 --epochs 20                      # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+           examples/train_tactile_push_gd_batched.py --batch 4096 --epochs 20                      # 8 GPUs, RCCL over xGMI
+
+Per epoch and rank: one episode of `--batch` environments (policy -> env-step -> ... -> BPTT through the simulator),
+replayed from ONE HIP graph (`--eager` for the plain loop); the ranks exchange only the flat policy gradient (118 KB), once
+per epoch.  Every epoch draws new goals / box offsets / disturbances per environment (envs/tactile_push_env.py:133-190) and
+writes them into the graph's static inputs.  The model path defaults to the compiled TactilePush model of the test fixtures;
+pass the reference's envs/assets/pusher/pusher.xml to compile it afresh.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv                      # noqa: E402
+from tactilesimulation_amd.algorithms.batched_gd import Actor, GraphedRollout, train_epoch, train_epoch_graphed   # noqa: E402
+
+
+def draw_episode(rng, B, T, device, dtype):
+    """q0 [B, 7], goal [B, 3], disturbances [T, B, 2] as in tactile_push_env.py:133-190 (new force every 10 steps, on with p = 0.5)."""
+    q0 = np.zeros((B, 7)); q0[:, 1] = -0.001; q0[:, 4] = rng.uniform(-0.02, 0.02, size=B)
+    goal = np.zeros((B, 3))
+    goal[:, 0:2] = rng.uniform([0.15, -0.2], [0.25, 0.2], size=(B, 2))
+    goal[:, 2] = rng.uniform(goal[:, 1] * math.pi - math.pi / 16.0, goal[:, 1] * math.pi + math.pi / 16.0)
+    d = np.zeros((T, B, 2))
+    for t0 in range(0, T, 10):
+        d[t0:t0 + 10] = (rng.uniform(size=(B, 1)) < 0.5) * rng.uniform(-1.0, 1.0, size=(B, 2))
+    t = lambda a: torch.tensor(a, device=device, dtype=dtype)
+    return t(q0), t(goal), t(d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default=os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    ap.add_argument("--batch", type=int, default=4096, help="environments (= episodes per epoch) per GPU")
+    ap.add_argument("--epochs", type=int, default=20)
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--grad-clip", type=float, default=1.0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per episode")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev, dtype = "cuda:%d" % local, (torch.float32 if args.dtype == "f32" else torch.float64)
+    B, T = args.batch, args.horizon
+    env = BatchedTactilePushEnv(args.model, B, device=dev, dtype=dtype, gradient=True, seed=args.seed + rank, tape_steps=T)
+    torch.manual_seed(args.seed)                                   # identical initial policy on every rank
+    actor = Actor(dtype=dtype).to(dev)
+    opt = torch.optim.Adam(actor.parameters(), lr=args.lr)
+    rng = np.random.default_rng(args.seed + 1000 * rank)
+    q0, goal, dist_ = draw_episode(rng, B, T, dev, dtype)
+    gr = None if args.eager else GraphedRollout(env, actor, T, q0, goal, dist_)
+    for epoch in range(args.epochs):
+        nq0, ngoal, ndist = draw_episode(rng, B, T, dev, dtype)
+        q0.copy_(nq0); goal.copy_(ngoal); dist_.copy_(ndist)       # static inputs of the graph
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if gr is None:
+            loss = train_epoch(env, actor, opt, T, B * world, grad_clip=args.grad_clip, q0=q0, goal=goal, disturbances=dist_)
+        else:
+            loss = float(train_epoch_graphed(gr, opt, B * world, grad_clip=args.grad_clip).detach()) / B
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if rank == 0:
+            print("epoch %3d  loss/episode (rank 0) %10.3f  %6.1f ms  %.2f M env-steps/s (all ranks)" % (epoch, loss, dt * 1e3, B * T * world / dt / 1e6), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
