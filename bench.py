@@ -9,17 +9,30 @@ algorithms/gd.py:239-259).  Default launch granularity: one launch per episode e
 tsim_backward_episode — the open-loop episode of EpisodicSimFunction, envs/redmax_torch_functions.py:46-57,77-92, with the
 synthetic actions resident in HBM); `--launch step` times one launch per env-step (StepSimFunction granularity) and
 its rate is reported in the same JSON line either way (`launch.other_mode_value`).  Every frame's q / variables /
-tactile outputs are written in both modes.  Inputs are resident in HBM before the timed region.  Environments shard across ranks with
-no data-path exchange (weak scaling); the only collective is the GD outer loop's policy-gradient all-reduce
-(29 574 fp32 = 118 296 B), issued once per episode.
+tactile outputs are written in both modes.  Inputs are resident in HBM before the timed region.  Environments shard
+across ranks with no data-path exchange (weak scaling); the only collective is the GD outer loop's policy-gradient
+all-reduce (29 574 fp32 = 118 296 B), issued once per episode.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and `cpu_baseline`
-(the fp64 CPU oracle — this build's restatement, NOT DiffRedMax — on a bounded sample, 1 thread and all host cores).
+Prints ONE JSON line (rank 0).  Besides the contract's fields:
+  roofline      dominant kernel, HIP-event timed in this run; HBM fraction from SURVEY.md §8d's algorithmic bytes, plus
+                `valu`: what actually bounds the path (instruction issue of one wavefront per SIMD), from hardware counters
+                collected IN THIS RUN by short `rocprofv3 --pmc` passes of this same script (separate passes, counters only);
+                `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of those passes (gfx950 correction of MI355X_MICROARCH.md §HBM)
+  closed_loop   BASELINE config 3 as cfg/gd_tactile.yaml runs it: policy between env-steps, BPTT, all-reduce, clip, Adam —
+                one HIP graph replay per episode (algorithms/batched_gd.GraphedRollout), timed here, not by a side script
+  readout_hbm   the one HBM-relevant kernel of this path: 200 x 200-taxel read-out of RollingBall, GB/s
+  cpu_baseline  the fp64 CPU oracle (this build's restatement, NOT DiffRedMax), built -O3 -march=native on this host,
+                one instance per usable core
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,16 +43,45 @@ sys.path.insert(0, ROOT)
 
 POLICY_GRAD_FLOATS = 29574      # DiagGaussianActor(393 -> 64 -> 64 -> 3), SURVEY.md §2.2
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
-FP32_VALU_PEAK_TFLOPS = 157.3
+FP32_VALU_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 lanes x 2 flop per 2 cycles at 2.4 GHz (packed / two wavefronts per SIMD)
+N_SIMD, CLOCK_GHZ = 1024, 2.4
+PMC_PASSES = [
+    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
+    ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+     "SQ_INSTS_VALU_FMA_F64", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY"],
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+]
 
 
 def algorithmic_bytes(nr, nu, nvar, ntac, S, esz):
-    """per env-step, state on chip across the S sub-steps, model constants batch-shared.  The taped state is
-    (q as double, qd) per sub-step: the pose chain is double also in the fp32 kernels."""
-    tape = S * nr * (8 + esz)
-    fwd = esz * (nu + nr + nvar + ntac) + tape
-    bwd = tape + esz * (nr + nvar + ntac + nu * S)
+    """per env-step, state on chip across the S sub-steps, model constants batch-shared:
+    fwd = esz (nu + nr + nvar + ntac + 2 nr S), bwd = esz (2 nr S + nr + nvar + ntac + nu S)   (1 916 / 2 012 B for fp32
+    TactilePush).  As built, the tape holds q as double and the Newton matrix: that is implementation traffic
+    and shows in `traffic`, not here."""
+    fwd = esz * (nu + nr + nvar + ntac + 2 * nr * S)
+    bwd = esz * (2 * nr * S + nr + nvar + ntac + nu * S)
     return fwd, bwd
+
+
+def usable_cores():
+    """Cores this process may actually keep busy: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def main():
@@ -52,13 +94,17 @@ def main():
     ap.add_argument("--frame-skip", type=int, default=5)
     ap.add_argument("--episode", type=int, default=100, help="env-steps per episode (tape length / frame_skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic / roofline.valu then "
+                    "come from the committed profile of this command, with the source stated)")
+    ap.add_argument("--no-closed-loop", action="store_true")
+    ap.add_argument("--pmc-dump", default=None, help="write the counters of the in-run --pmc passes to this JSON file (profiles/)")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] style run (not the headline)")
     ap.add_argument("--launch", default="episode", choices=["episode", "step"],
                     help="episode: tsim_rollout + tsim_backward_episode, one launch each way per episode (the open-loop "
                          "episode of EpisodicSimFunction); step: one tsim_step / tsim_backward_steps launch per env-step "
                          "(StepSimFunction granularity, what a closed-loop policy needs)")
     ap.add_argument("--timed-only", action="store_true",
-                    help="skip the legs after the timed region (other launch mode, evaluation statistics): profiler runs")
+                    help="skip every leg after the timed region: profiler runs (and the in-run --pmc passes)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the real multi-GPU path) or gloo (plumbing test: with TSIM_BENCH_SHARE_GPU=1 "
                          "all ranks share cuda:0 and the collectives go through host copies)")
@@ -85,9 +131,9 @@ def main():
 
     from tactilesimulation_amd.model.compiler import load_model
     from tactilesimulation_amd.host.batch import BatchSim
-    from tests.workloads import push_workload
+    from tactilesimulation_amd.workloads import push_workload, PUSHER_BLOB
 
-    model = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    model = load_model(PUSHER_BLOB)
     B, S, T = args.batch, args.frame_skip, args.episode
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     esz = 4 if args.dtype == "f32" else 8
@@ -190,55 +236,44 @@ def main():
         return float(np.mean(ms)), float(sum(ms) / sum(fr)), int(round(np.mean(fr)))
     fwd_ms, fwd_ms_step, fwd_frames = ev_stats(ev["fwd"])
     bwd_ms, bwd_ms_step, bwd_frames = ev_stats(ev["bwd"])
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"timed_only": True, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                              "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms}}), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # second leg, reported next to the headline: the other launch granularity on the same workload (short, after the
     # timed region)
     other = "step" if args.launch == "episode" else "episode"
     ev_main, ev = ev, {"fwd": [], "bwd": []}
     k_other = min(args.steps, 40)
-    other_value = None
-    if not args.timed_only:
-        run_steps(min(k_other, 5), False, other)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(k_other, False, other)
-        torch.cuda.synchronize()
-        other_value = B * k_other / (time.perf_counter() - t1)
+    run_steps(min(k_other, 5), False, other)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run_steps(k_other, False, other)
+    torch.cuda.synchronize()
+    other_value = B * k_other / (time.perf_counter() - t1)
     ev = ev_main
 
     # untimed: Newton work statistics (residual evaluations per env-step) of the same workload
     sim.reset(q0, None, backward_flag=False)
     evs = []
-    for t in range(min(T, 30) if not args.timed_only else 0):
+    for t in range(min(T, 30)):
         sim.step(u[t], S, out=out)
         evs.append(sim.last_evals())
-    evs = np.array(evs) if evs else np.zeros((1, 1))
-    if args.timed_only:
-        out["status"] = torch.zeros(1, dtype=torch.int32)
+    evs = np.array(evs)
     status_bad = int((out["status"] != 0).sum().item())
+    launch_shape = sim.launch_info()
 
     if rank == 0:
         fb, bb = algorithmic_bytes(nr, nu, nvar, ntac, S, esz)
         dom, dom_ms, dom_bytes, dom_frames = ("k_forward", fwd_ms, fb, fwd_frames) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb, bwd_frames)
         achieved = dom_bytes * B * dom_frames / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         value = B * world * args.steps / dt
-        traffic, traffic_src, issue = None, None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % args.dtype)
-        if os.path.exists(pmc_file) and B == 4096:       # separate rocprofv3 --pmc run of this same command (tools/gpu_pmc.sh)
-            try:
-                pj = json.load(open(pmc_file))
-                pk = [v for k, v in pj["per_kernel"].items() if dom in k][0]
-                # gfx950: FETCH_SIZE counts 1/2 (MI355X_MICROARCH.md §HBM); scaled from the profiled launch (pmc frames) to this one
-                traffic = (2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024.0 * dom_frames / pj.get("frames_per_launch", 1)
-                traffic_src = ("profiles/" + os.path.basename(pmc_file) + " (2*FETCH_SIZE + WRITE_SIZE KiB per launch of %d env-steps, "
-                               "scaled to %d)" % (pj.get("frames_per_launch", 1), dom_frames))
-                # what actually bounds the kernel: instruction issue of the one wavefront each SIMD holds (same PMC file)
-                issue = {"valu_insts_per_env_step": pk["SQ_INSTS_VALU"] / (4096.0 * pj.get("frames_per_launch", 1)),
-                         "wave_issuing_frac": pk["SQ_ACTIVE_INST_ANY"] / pk["SQ_WAVE_CYCLES"],
-                         "wave_valu_frac": pk["SQ_ACTIVE_INST_VALU"] / pk["SQ_WAVE_CYCLES"],
-                         "wavefronts": pk["SQ_WAVES"], "source": "profiles/" + os.path.basename(pmc_file)}
-            except Exception:
-                pass
         res = {
             "metric": ("env-steps/sec (fwd+bwd) TactilePush batch=%d" % B) if not args.forward_only else ("env-steps/sec (fwd only) TactilePush batch=%d" % B),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,25 +282,52 @@ def main():
             "config": {"workload": "TactilePush (pusher.xml, 13x10 taxels, ndof_r 7) gd_tactile fwd+adjoint, frame_skip %d, "
                                    "batch %d envs/GPU, episodes of %d env-steps" % (S, B, T),
                        "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "valu-issue latency (one wavefront per SIMD; not HBM: SURVEY.md §0.6) — the HBM figures below are reported as the task asks",
+                         "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "algorithmic_bytes_per_launch": dom_bytes * B * dom_frames, "env_steps_per_launch": dom_frames,
-                         "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb},
+                         "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb, "source": "SURVEY.md §8d"},
                          "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms},
                          "kernel_ms_per_env_step": {"k_forward": fwd_ms_step, "k_backward": bwd_ms_step},
-                         "issue": issue,
-                         "note": "state stays in LDS across sub-steps, so this path is latency/VALU-bound, not HBM-bound (SURVEY.md §0.6)"},
+                         "valu": None},
             "launch": {"mode": args.launch,
                        "episode": "tsim_rollout + tsim_backward_episode: one launch each way per episode (EpisodicSimFunction's open-loop episode)",
                        "step": "tsim_step + tsim_backward_steps: one launch per env-step each way (StepSimFunction granularity)",
                        "other_mode": other, "other_mode_value": other_value, "other_mode_env_steps": k_other},
             "nonconverged_envs_last_step": status_bad, "nonconverged_warmup": bad_warm,
-            "launch_shape": sim.launch_info(),      # LDS bytes / block, blocks, lanes per environment, wavefronts per SIMD
+            "launch_shape": launch_shape,      # LDS bytes / block, blocks, lanes per environment
             "residual_evals_per_env_step": {"mean": float(evs.mean()), "p99": float(np.percentile(evs, 99)),
                                             "mean_of_per_step_max": float(evs.max(axis=1).mean()), "max": int(evs.max())},
         }
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(model, S, not args.forward_only)
+        # free the batch before the other legs (tape: 0.6 GB) — and so that the profiled child runs see an idle GPU
+        del sim
+        torch.cuda.empty_cache()
+        if world == 1:
+            pmc = None
+            if not args.no_pmc:
+                pmc = pmc_passes(args)
+            src = "measured in this run: rocprofv3 --pmc passes of `bench.py --timed-only` with this run's --steps / --batch / --dtype"
+            if pmc is None or dom not in pmc:
+                pmc, src = pmc_from_profile(args), "profiles/r02_pmc_%s.json (committed rocprofv3 --pmc run of this command; the in-run passes were skipped or failed)" % args.dtype
+            if pmc is not None and dom in pmc:
+                fill_roofline_counters(res["roofline"], pmc[dom], src, B, dom_frames, dom_ms)
+                res["roofline"]["counters_per_launch"] = pmc
+                if args.pmc_dump:
+                    json.dump({"note": "rocprofv3 --pmc, separate passes " + " | ".join(" ".join(p_) for p_ in PMC_PASSES) + "; mean per dispatch of `python bench.py "
+                               "--steps %d --warmup %d --timed-only` %s B=%d; FETCH_SIZE / WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE under-reports "
+                               "wide reads by 2x); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles" % (args.steps, args.steps, args.dtype, B),
+                               "frames_per_launch": dom_frames, "per_kernel": pmc}, open(args.pmc_dump, "w"), indent=1)
+            if not args.no_closed_loop and not args.forward_only:
+                try:
+                    res["closed_loop"] = closed_loop_leg(model, B, T, tdt, dev)
+                except Exception as e:      # the headline must not die with an optional leg
+                    res["closed_loop"] = {"error": repr(e)}
+            try:
+                res["readout_hbm"] = readout_leg(tdt, dev)
+            except Exception as e:
+                res["readout_hbm"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(model, S, not args.forward_only)
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -273,26 +335,175 @@ def main():
         dist.destroy_process_group()
 
 
+# ---------------------------------------------------------------------------------------------------- hardware counters
+def pmc_passes(args, kernels=("k_forward", "k_backward")):
+    """Counters of the bench kernels, collected by re-running this script's timed region under `rocprofv3 --pmc` (counters
+    only, one pass per counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md §rocprofv3 PMC slots).
+    Returns {kernel: {counter: mean per dispatch}} or None."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="tsim_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {k: {} for k in kernels}
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, "p%d" % i)
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(args.steps), "--warmup", str(args.steps), "--batch", str(args.batch), "--dtype", args.dtype,
+                   "--episode", str(args.episode), "--frame-skip", str(args.frame_skip), "--launch", args.launch, "--timed-only", "--no-pmc",
+                   "--no-cpu-baseline"] + (["--forward-only"] if args.forward_only else [])
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            per = {k: {} for k in kernels}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    for k in kernels:
+                        if k in r.get("Kernel_Name", ""):
+                            per[k].setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+                            per[k][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            for k in kernels:
+                for c in counters:
+                    if c in per[k]:
+                        vals[k][c] = float(np.mean(list(per[k][c].values())))
+        need = [c for p_ in PMC_PASSES for c in p_]
+        return {k: v for k, v in vals.items() if all(c in v for c in need)} or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_from_profile(args):
+    f = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.dtype)
+    if not (os.path.exists(f) and args.batch == 4096):
+        return None
+    try:
+        pj = json.load(open(f))
+        if pj.get("frames_per_launch") != min(args.steps, args.episode):
+            return None
+        return pj["per_kernel"]
+    except Exception:
+        return None
+
+
+def fill_roofline_counters(rl, c, src, B, frames, kernel_ms):
+    """HBM traffic and the VALU side of the roofline from the counters of one launch of the dominant kernel."""
+    # gfx950: FETCH_SIZE reports half of the bytes of wide reads, WRITE_SIZE as is; both in KiB (MI355X_MICROARCH.md §HBM)
+    rl["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    rl["traffic_source"] = src + "; 2 * FETCH_SIZE + WRITE_SIZE (KiB) per launch of %d env-steps" % frames
+    t = kernel_ms * 1e-3
+    valu = c["SQ_INSTS_VALU"]                                   # wave-level VALU instructions of the launch
+    f32 = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + 2.0 * c["SQ_INSTS_VALU_FMA_F32"]
+    f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2.0 * c["SQ_INSTS_VALU_FMA_F64"]
+    lanes = c["SQ_THREAD_CYCLES_VALU"] / max(4.0 * c["SQ_ACTIVE_INST_VALU"], 1.0) / 64.0     # mean fraction of the 64 lanes active in a VALU instruction
+    flops = 64.0 * lanes * (f32 + f64)                          # lane-level flops (FMA = 2), idle lanes not counted
+    rl["valu"] = {
+        "source": src,
+        "valu_wave_insts_per_env_step": valu / (B * frames),
+        # issue roofline: a SIMD issues at most one VALU instruction per 4 cycles from ONE wavefront (2 cycles with >= 2)
+        "achieved_wave_insts_per_s": valu / t, "peak_wave_insts_per_s_one_wave_per_simd": N_SIMD * CLOCK_GHZ * 1e9 / 4.0,
+        "frac_of_one_wave_issue_rate": (valu / t) / (N_SIMD * CLOCK_GHZ * 1e9 / 4.0),
+        "frac_of_chip_issue_rate": (valu / t) / (N_SIMD * CLOCK_GHZ * 1e9 / 2.0),
+        "wavefronts": c["SQ_WAVES"], "wavefronts_per_simd": c["SQ_WAVES"] / N_SIMD,
+        "wave_issuing_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+        "wave_valu_frac": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+        "wave_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+        "active_lane_frac": lanes,
+        "fp_flops_per_env_step": flops / (B * frames), "fp64_share_of_flops": f64 / max(f32 + f64, 1.0),
+        "achieved_tflops": flops / t / 1e12, "peak_tflops": FP32_VALU_PEAK_TFLOPS, "frac": flops / t / 1e12 / FP32_VALU_PEAK_TFLOPS,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------- closed GD loop
+def closed_loop_leg(model, B, T, tdt, dev, epochs=3):
+    """BASELINE config 3 as algorithms/gd.py:224-259 runs it — observation -> policy -> env-step, 100 env-steps, BPTT, one
+    gradient all-reduce + clip + Adam per epoch — with every environment of the batch as one episode and the episode + its
+    backward replayed from one HIP graph (algorithms/batched_gd.GraphedRollout)."""
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.algorithms.batched_gd import Actor, GraphedRollout, train_epoch_graphed
+    env = BatchedTactilePushEnv(model, B, device=str(dev), dtype=tdt, gradient=True, seed=0, tape_steps=T)
+    env.reset()
+    q0, goal = env.q0.clone(), env.goal.clone()
+    rng = np.random.default_rng(1)
+    dist_ = torch.tensor(rng.uniform(-1, 1, size=(T, B, 2)) * (rng.uniform(size=(T, B, 1)) < 0.5), device=dev, dtype=tdt)
+    torch.manual_seed(0)
+    actor = Actor(dtype=tdt).to(dev)
+    opt = torch.optim.Adam(actor.parameters(), lr=5e-3, betas=(0.7, 0.95))          # cfg/gd_tactile.yaml
+    gr = GraphedRollout(env, actor, T, q0, goal, dist_, warmup=1)
+    train_epoch_graphed(gr, opt, B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = [train_epoch_graphed(gr, opt, B).detach().clone() for _ in range(epochs)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"value": B * T * epochs / dt, "unit": "env-steps/s", "s_per_epoch": dt / epochs, "epochs": epochs, "horizon": T, "batch": B,
+           "what": "closed GD epoch: policy MLP (29 574 parameters) between env-steps, per-env-step launches of the simulator, BPTT, "
+                   "gradient normalise + clip + Adam; one HIP graph replay per episode",
+           "loss_per_episode": [float(l) / B for l in losses]}
+    del gr, env
+    torch.cuda.empty_cache()
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------- HBM-relevant read-out
+def readout_leg(tdt, dev, B=256, reps=5):
+    """k_readout on RollingBall's 200 x 200 taxels (assets/tactile_pad/tactile_pad.xml:29): 480 KB written per
+    environment and read-out, taxel constants (12 planes) re-read per environment from L2 — the one kernel of this path
+    whose time is set by memory traffic."""
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.workloads import asset
+    m = load_model(asset("tactile_pad"))
+    sim = BatchSim(m, B, device=str(dev), dtype=tdt, tape_capacity=0)
+    sim.reset(torch.zeros(B, sim.ndof_r, device=dev, dtype=tdt), None, backward_flag=False)
+    u = torch.zeros(B, sim.ndof_u, device=dev, dtype=tdt)
+    u[:, 2] = 0.2                                               # the first 100 steps of examples/RollingBallExp/test_sim_speed.py:43-48:
+    for _ in range(100):                                        # the pad comes down on the ball
+        sim.step(u, 1, want_var=False, want_tactile=False)
+    sim.readout()
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    e[0].record()
+    for i in range(reps):
+        _, tac = sim.readout(want_var=False)
+        e[i + 1].record()
+    torch.cuda.synchronize()
+    ms = min(e[i].elapsed_time(e[i + 1]) for i in range(reps))
+    esz = 4 if tdt == torch.float32 else 8
+    written = B * sim.ndof_tactile * esz
+    return {"kernel": "k_readout", "workload": "RollingBall tactile_pad.xml, 200 x 200 taxels, %d environments" % B, "ms": ms,
+            "bytes_written": written, "achieved": written / (ms * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "frac": written / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "taxels_in_contact_max": int((tac.reshape(B, -1, 3)[:, :, 2] != 0).sum(1).max().item())}
+
+
+# ---------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(model, S, with_backward):
-    """fp64 CPU oracle (oracle/tsim_oracle.cpp — the build's own restatement) on a bounded sample of the same workload:
-    one thread, and all host cores (environments are independent: one oracle instance per thread, ctypes releases the GIL)."""
+    """fp64 CPU oracle (oracle/tsim_oracle.cpp — the build's own restatement, kind "port") on a bounded sample of the same
+    workload, rebuilt here with -O3 -march=native: one thread, and one oracle instance per USABLE core (affinity mask capped
+    by the cgroup CPU quota; environments are independent, ctypes releases the GIL)."""
     import threading
     from oracle.oracle import OracleSim
-    from tests.workloads import push_workload
+    from tactilesimulation_amd.workloads import push_workload
     nenv, nstep = 8, 100
     q0, u, _ = push_workload(nenv, nstep, seed=0)
-    o = OracleSim(model)
+    try:
+        o = OracleSim(model, native=True)
+        flags = "g++ -O3 -march=native (built on this host)"
+        native = True
+    except Exception:
+        o = OracleSim(model)
+        flags = "g++ -O3 (portable build; the native rebuild failed)"
+        native = False
     o.bench_rollout(q0[:1], u[:1, :5], S, with_backward)       # warm
     t0 = time.perf_counter()
     n, _ = o.bench_rollout(q0, u, S, with_backward)
     dt1 = time.perf_counter() - t0
     st = o.stats()
     single = n / dt1
-    # all cores: 2 environments x 100 env-steps per thread
-    nthr = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    per = 2
+    nthr = usable_cores()
+    per = max(2, int(round(12.0 * single / nstep)))            # ~12 s of CPU work per thread
     q0m, um, _ = push_workload(per * nthr, nstep, seed=1)
-    sims = [OracleSim(model) for _ in range(nthr)]
+    sims = [OracleSim(model, native=native) for _ in range(nthr)]
     done = [0] * nthr
 
     def work(i):
@@ -306,12 +517,12 @@ def cpu_baseline(model, S, with_backward):
         t.join()
     dtm = time.perf_counter() - t0
     c1 = os.times()
-    busy = ((c1.user - c0.user) + (c1.system - c0.system)) / dtm      # cores actually kept busy (cgroup limits show here)
+    busy = ((c1.user - c0.user) + (c1.system - c0.system)) / dtm      # cores actually kept busy
     what = "fwd+adjoint" if with_backward else "fwd only"
     return {"value": sum(done) / dtm, "unit": "env-steps/s", "cores": nthr, "kind": "port",
-            "sample": "%d threads x %d envs x %d env-steps of the same TactilePush workload, %s, fp64, g++ -O3 (one oracle instance "
-                      "per thread); single thread: %d envs x %d env-steps; mean Newton iterations/sub-step %.2f"
-                      % (nthr, per, nstep, what, nenv, nstep, st["newton_iters"] / max(st["substeps"], 1)),
+            "sample": "%d threads (usable cores) x %d envs x %d env-steps of the same TactilePush workload, %s, fp64, %s, one oracle "
+                      "instance per thread; single thread: %d envs x %d env-steps; mean Newton iterations/sub-step %.2f"
+                      % (nthr, per, nstep, what, flags, nenv, nstep, st["newton_iters"] / max(st["substeps"], 1)),
             "single_thread_value": single, "host_cpus": os.cpu_count(), "cores_busy": busy}
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Batched analytic-gradient training of the TactilePush policy — the MI355X counterpart of the reference's
 examples/TactilePushExp/train_tactile_push_gd.py + algorithms/gd.py (cfg/gd_tactile.yaml: 393 -> 64 -> 64 -> 3 actor,
-Adam, gradient-norm clip, 100-step episodes).  There, `num_episodes` episodes run one after the other through one
+Adam lr 0.005 betas (0.7, 0.95) with the linear decay of gd.py:146-149, gradient-norm clip 1.0, 100-step episodes).  There, `num_episodes` episodes run one after the other through one
 Simulation; here they are one batch per GPU.
 
     python examples/train_tactile_push_gd_batched.py --batch 4096 --epochs 20                      # one GPU
@@ -44,12 +44,16 @@ def draw_episode(rng, B, T, device, dtype):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default=os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    ap.add_argument("--model", default=os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
     ap.add_argument("--batch", type=int, default=4096, help="environments (= episodes per epoch) per GPU")
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--horizon", type=int, default=100)
-    ap.add_argument("--lr", type=float, default=1e-3)
+    # optimiser of cfg/gd_tactile.yaml (algorithms/gd.py:146-151): Adam lr 0.005, betas (0.7, 0.95), linear decay to 1e-5
+    ap.add_argument("--lr", type=float, default=5e-3)
+    ap.add_argument("--betas", type=float, nargs=2, default=(0.7, 0.95))
+    ap.add_argument("--lr-schedule", default="linear", choices=["linear", "constant"])
     ap.add_argument("--grad-clip", type=float, default=1.0)
+    ap.add_argument("--log", default=None, help="write the loss curve (JSON) here")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per episode")
     ap.add_argument("--seed", type=int, default=0)
@@ -66,11 +70,15 @@ def main():
     env = BatchedTactilePushEnv(args.model, B, device=dev, dtype=dtype, gradient=True, seed=args.seed + rank, tape_steps=T)
     torch.manual_seed(args.seed)                                   # identical initial policy on every rank
     actor = Actor(dtype=dtype).to(dev)
-    opt = torch.optim.Adam(actor.parameters(), lr=args.lr)
+    opt = torch.optim.Adam(actor.parameters(), lr=args.lr, betas=tuple(args.betas))
+    curve = []
     rng = np.random.default_rng(args.seed + 1000 * rank)
     q0, goal, dist_ = draw_episode(rng, B, T, dev, dtype)
     gr = None if args.eager else GraphedRollout(env, actor, T, q0, goal, dist_)
     for epoch in range(args.epochs):
+        if args.lr_schedule == "linear":                           # gd.py:146-149
+            for g in opt.param_groups:
+                g["lr"] = (1e-5 - args.lr) * float(epoch / args.epochs) + args.lr
         nq0, ngoal, ndist = draw_episode(rng, B, T, dev, dtype)
         q0.copy_(nq0); goal.copy_(ngoal); dist_.copy_(ndist)       # static inputs of the graph
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -79,8 +87,14 @@ def main():
         else:
             loss = float(train_epoch_graphed(gr, opt, B * world, grad_clip=args.grad_clip).detach()) / B
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        curve.append({"epoch": epoch, "loss_per_episode": loss, "ms": dt * 1e3, "lr": opt.param_groups[0]["lr"]})
         if rank == 0:
             print("epoch %3d  loss/episode (rank 0) %10.3f  %6.1f ms  %.2f M env-steps/s (all ranks)" % (epoch, loss, dt * 1e3, B * T * world / dt / 1e6), flush=True)
+    if rank == 0 and args.log:
+        import json
+        json.dump({"args": vars(args), "world": world, "curve": curve,
+                   "note": "loss = -sum of rewards / episodes of rank 0's batch; every epoch draws new goals, offsets and disturbances"},
+                  open(args.log, "w"), indent=1)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 

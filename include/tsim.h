@@ -122,16 +122,32 @@ int tsim_get_adjoint(tsim_batch* b, void* df_dq0, void* df_dqd0, void* stream);
 
 /* sim.saveBackwardCache() / popBackwardCache() / clearBackwardCache()
  *                                     envs/redmax_torch_functions.py:65,81; envs/tactile_insertion_env.py:226
- * LIFO of tapes so that several episodes can be forwarded before their backwards. */
+ * LIFO of tapes so that several episodes can be forwarded before their backwards.  The tapes are swapped by pointer:
+ * save parks the live tape buffer on the stack and continues on a spare one (the current state is carried over), pop
+ * makes the newest saved tape the live one again (its length and recording flag with it; the carried adjoint restarts at
+ * zero) and returns the buffer it replaces to the pool.  No tape copy, no synchronisation; the only allocation is the first
+ * use of a stack depth, which tsim_cache_reserve(depth) moves out of the hot path.  clear drops the saved tapes (their
+ * buffers go back to the pool; two spares are kept).  All calls of one batch on ONE stream. */
 int tsim_cache_save(tsim_batch* b, void* stream);
 int tsim_cache_pop(tsim_batch* b, void* stream);
 int tsim_cache_clear(tsim_batch* b);
+int tsim_cache_reserve(tsim_batch* b, int depth);     /* no reference counterpart: pre-allocate `depth` tape buffers */
+int tsim_cache_depth(const tsim_batch* b);            /* saved tapes on the stack */
 
 /* Diagnostics (no reference counterpart): one residual evaluation g(q1; q0, qd0, u) and its Newton matrix
  * H = dg/dq1 for env 0..B-1; g_out [B][nr], H_out [B][nr][nr] (row-major). Used by the parity tests.
  * cycles (device int64 [B][32], may be NULL): shader-clock stamps taken inside the evaluation (models with ndof_r <= 8). */
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u,
                     void* g_out, void* H_out, long long* cycles, void* stream);
+
+/* Diagnostics (no reference counterpart; SURVEY.md §7 "Non-smoothness"): branch signature of the taped sub-steps
+ * t_first+1 .. t_first+n (1 = the first sub-step after reset) of every environment: which contact points and taxels
+ * penetrate and on which smooth piece of the penalty law each of them is (stick / slip, face of the primitive), recomputed
+ * from the taped state exactly as the adjoint re-evaluates it.  out: DEVICE uint32 [n][B][2] = (number of penetrating
+ * items, sum over them of mix(item, branch) mod 2^32; the oracle states the same two numbers).  Two runs with equal
+ * signatures went through the same smooth pieces of the dynamics — the fp32 / fp64 gradient comparison is made on those
+ * environments, and the fraction that differs is reported (tests/test_gpu_configs.py).  Needs reset(backward_flag=True). */
+int tsim_debug_signature(tsim_batch* b, int t_first, int n, uint32_t* out, void* stream);
 
 /* launch statistics of the most recent kernels (HIP events are the caller's business; this only reports
  * static launch geometry of the forward / backward kernels): out[0] = LDS bytes per block, out[1] = threads per block,
@@ -141,7 +157,7 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
 int tsim_launch_info(const tsim_batch* b, int32_t* out);
 /* Force 16 / 32 / 64 lanes per environment (0 = automatic again).  For callers that split a batch into groups on several
  * streams: each group is then small, but the groups together should still fill the device. */
-int tsim_set_lanes_per_env(tsim_batch* b, int lanes);
+int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes effect with the next launch */
 
 /* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */
 int tsim_last_evals(tsim_batch* b, int32_t* host_out);

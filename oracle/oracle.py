@@ -11,29 +11,42 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "libtsim_oracle.so")
-_lib = None
+_SO_NATIVE = os.path.join(_DIR, "libtsim_oracle_native.so")
+_libs = {}
 _dp = C.POINTER(C.c_double)
 
 
 def build(force=False):
     src = os.path.join(_DIR, "tsim_oracle.cpp")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _DIR, "-s", "-B"])
+        subprocess.check_call(["make", "-C", _DIR, "-s", "-B", "libtsim_oracle.so"])
     return _SO
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_SO):
+def build_native():
+    """-march=native build on the machine that will time it (bench.py cpu_baseline); always rebuilt: a copy made on
+    another host must not be trusted."""
+    subprocess.check_call(["make", "-C", _DIR, "-s", "-B", "libtsim_oracle_native.so"])
+    return _SO_NATIVE
+
+
+def lib(native=False):
+    key = "native" if native else "portable"
+    if key not in _libs:
+        so = _SO_NATIVE if native else _SO
+        if native:
+            build_native()
+        elif not os.path.exists(so):
             build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(so)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.POINTER(C.c_int), _dp]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_reset.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.orc_forward.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_forward.restype = C.c_int
+        L.orc_forward_sig.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_forward_sig.restype = C.c_int
         L.orc_get_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_outputs.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_tape_len.argtypes = [C.c_void_p]
@@ -46,8 +59,8 @@ def lib():
         L.orc_inverse_dynamics.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
         L.orc_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
         L.orc_bench_rollout.restype = C.c_long
-        _lib = L
-    return _lib
+        _libs[key] = L
+    return _libs[key]
 
 
 def _p(a):
@@ -64,11 +77,12 @@ def _f(a, n=None):
 class OracleSim:
     """One environment, fp64, CPU. Mirrors the stepping/adjoint part of redmax_py.Simulation."""
 
-    def __init__(self, model):
+    def __init__(self, model, native=False):
         self.model = model
+        self._L = lib(native)
         self._I = np.ascontiguousarray(model.I, dtype=np.int32)
         self._F = np.ascontiguousarray(model.F, dtype=np.float64)
-        self._h = lib().orc_create(self._I.ctypes.data_as(C.POINTER(C.c_int)), _p(self._F))
+        self._h = self._L.orc_create(self._I.ctypes.data_as(C.POINTER(C.c_int)), _p(self._F))
         if not self._h:
             raise RuntimeError("oracle rejected the model blob")
         self.nr, self.nu = model.ndof_r, model.ndof_u
@@ -77,27 +91,34 @@ class OracleSim:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+            self._L.orc_destroy(self._h)
             self._h = None
 
     def reset(self, q, qd=None, record=False):
         q = _f(q, self.nr)
         qd = np.zeros(self.nr) if qd is None else _f(qd, self.nr)
-        lib().orc_reset(self._h, _p(q), _p(qd), int(record))
+        self._L.orc_reset(self._h, _p(q), _p(qd), int(record))
 
     def forward(self, u, nsub=1):
         u = _f(u, self.nu)
-        return lib().orc_forward(self._h, _p(u), int(nsub))
+        return self._L.orc_forward(self._h, _p(u), int(nsub))
+
+    def forward_sig(self, u, nsub=1):
+        """forward(u, nsub) + the branch signature (count, hash) after each sub-step: (bad, int64 [nsub, 2])."""
+        u = _f(u, self.nu)
+        sig = np.zeros((nsub, 2), dtype=np.uint32)
+        bad = self._L.orc_forward_sig(self._h, _p(u), int(nsub), sig.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return bad, sig.astype(np.int64)
 
     def state(self):
         q, qd = np.zeros(self.nr), np.zeros(self.nr)
-        lib().orc_get_state(self._h, _p(q), _p(qd))
+        self._L.orc_get_state(self._h, _p(q), _p(qd))
         return q, qd
 
     def outputs(self, tactile=True):
         var = np.zeros(max(self.nvar, 1))
         tac = np.zeros(max(self.ntac, 1)) if tactile else None
-        lib().orc_outputs(self._h, _p(var), _p(tac))
+        self._L.orc_outputs(self._h, _p(var), _p(tac))
         return var[:self.nvar], (tac[:self.ntac] if tactile else None)
 
     def backward_steps(self, n, df_dq=None, df_dvar=None, df_dtac=None):
@@ -105,38 +126,38 @@ class OracleSim:
         b = _f(df_dvar, n * self.nvar) if (df_dvar is not None and self.nvar) else None
         c = _f(df_dtac, n * self.ntac) if (df_dtac is not None and self.ntac) else None
         du = np.zeros(max(n * self.nu, 1))
-        rc = lib().orc_backward_steps(self._h, int(n), _p(a), _p(b), _p(c), _p(du))
+        rc = self._L.orc_backward_steps(self._h, int(n), _p(a), _p(b), _p(c), _p(du))
         if rc != 0:
             raise RuntimeError("oracle backward failed (%d)" % rc)
         return du[:n * self.nu].reshape(n, self.nu)
 
     def adjoint(self):
         a, b = np.zeros(self.nr), np.zeros(self.nr)
-        lib().orc_get_adjoint(self._h, _p(a), _p(b))
+        self._L.orc_get_adjoint(self._h, _p(a), _p(b))
         return a, b
 
     def clear_adjoint(self):
-        lib().orc_clear_adjoint(self._h)
+        self._L.orc_clear_adjoint(self._h)
 
     def tape_len(self):
-        return lib().orc_tape_len(self._h)
+        return self._L.orc_tape_len(self._h)
 
     def stats(self):
         out = (C.c_long * 3)()
-        lib().orc_stats(self._h, out)
+        self._L.orc_stats(self._h, out)
         return {"newton_iters": out[0], "substeps": out[1], "nonconverged": out[2]}
 
     def residual(self, q1, q0, qd0, u, which=-1):
         g = np.zeros(self.nr)
         ncol = self.nu if which == 3 else self.nr
         J = np.zeros((self.nr, max(ncol, 1)))
-        lib().orc_residual(self._h, _p(_f(q1)), _p(_f(q0)), _p(_f(qd0)), _p(_f(u, self.nu)), int(which), _p(g), _p(J))
+        self._L.orc_residual(self._h, _p(_f(q1)), _p(_f(q0)), _p(_f(qd0)), _p(_f(u, self.nu)), int(which), _p(g), _p(J))
         return (g, J[:, :ncol]) if which >= 0 else g
 
     def inverse_dynamics(self, q, qd, qdd, u=None):
         r = np.zeros(self.nr)
         u = np.zeros(max(self.nu, 1)) if u is None else _f(u)
-        lib().orc_inverse_dynamics(self._h, _p(_f(q)), _p(_f(qd)), _p(_f(qdd)), _p(u), _p(r))
+        self._L.orc_inverse_dynamics(self._h, _p(_f(q)), _p(_f(qd)), _p(_f(qdd)), _p(u), _p(r))
         return r
 
     def bench_rollout(self, q0, u_tab, nsub, with_backward):
@@ -144,5 +165,5 @@ class OracleSim:
         u_tab = np.ascontiguousarray(u_tab, dtype=np.float64)
         nenv, nstep = u_tab.shape[0], u_tab.shape[1]
         cs = C.c_double(0)
-        n = lib().orc_bench_rollout(self._h, nenv, nstep, int(nsub), _p(q0), _p(u_tab), int(with_backward), C.byref(cs))
+        n = self._L.orc_bench_rollout(self._h, nenv, nstep, int(nsub), _p(q0), _p(u_tab), int(with_backward), C.byref(cs))
         return n, cs.value

@@ -140,17 +140,20 @@ template <class T> struct Link {
 // ------------------------------------------------------------------------------------------ contact law
 // DiffHand penalty model: d<0: fn = (-kn + kd ddot) d ; ft = -min(kt|vt|, mu|fn|) vt/|vt|.
 // Returns the world-frame force on the point fixed to link A at x_w (and -F on link B).
+// branch (optional): the smooth piece of the law the point is on: bit 0 = sticking, bits 1.. = face of the primitive
+// (cuboid: 2 axis + (negative side); cylinder: 0 side, 1 / 2 caps; plane, sphere: 0) — see orc_signature.
 template <class T>
 static bool contact_force(int prim, const double* shape, const double* k, const M3<T>& RP, const V3<T>& pP,
-                          const V3<T>& xw, const V3<T>& vrel_w, V3<T>& Fw) {
+                          const V3<T>& xw, const V3<T>& vrel_w, V3<T>& Fw, int* branch = nullptr) {
   V3<T> x = mulT(RP, xw - pP);
   T d; V3<T> n;
+  int face = 0;
   if (prim == TSIM_P_PLANE) { d = x.z; n = mk<T>(T(0.0), T(0.0), T(1.0)); }
   else if (prim == TSIM_P_CUBOID) {
     double ex = std::fabs(val(x.x)) - shape[0], ey = std::fabs(val(x.y)) - shape[1], ez = std::fabs(val(x.z)) - shape[2];
-    if (ex >= ey && ex >= ez) { double s = val(x.x) >= 0 ? 1.0 : -1.0; d = x.x * T(s) - T(shape[0]); n = mk<T>(T(s), T(0.0), T(0.0)); }
-    else if (ey >= ez)        { double s = val(x.y) >= 0 ? 1.0 : -1.0; d = x.y * T(s) - T(shape[1]); n = mk<T>(T(0.0), T(s), T(0.0)); }
-    else                      { double s = val(x.z) >= 0 ? 1.0 : -1.0; d = x.z * T(s) - T(shape[2]); n = mk<T>(T(0.0), T(0.0), T(s)); }
+    if (ex >= ey && ex >= ez) { double s = val(x.x) >= 0 ? 1.0 : -1.0; d = x.x * T(s) - T(shape[0]); n = mk<T>(T(s), T(0.0), T(0.0)); face = s > 0 ? 0 : 1; }
+    else if (ey >= ez)        { double s = val(x.y) >= 0 ? 1.0 : -1.0; d = x.y * T(s) - T(shape[1]); n = mk<T>(T(0.0), T(s), T(0.0)); face = s > 0 ? 2 : 3; }
+    else                      { double s = val(x.z) >= 0 ? 1.0 : -1.0; d = x.z * T(s) - T(shape[2]); n = mk<T>(T(0.0), T(0.0), T(s)); face = s > 0 ? 4 : 5; }
   } else if (prim == TSIM_P_SPHERE) {
     T r2 = dot(x, x);
     if (val(r2) < 1e-24) return false;
@@ -160,7 +163,7 @@ static bool contact_force(int prim, const double* shape, const double* k, const 
     double rho = std::sqrt(val(rho2));
     double dr = rho - shape[0], dz = std::fabs(val(x.z)) - shape[1];
     if (dr > dz && rho > 1e-12) { T rr = sqrt(rho2); d = rr - T(shape[0]); T ir = T(1.0) / rr; n = mk<T>(x.x * ir, x.y * ir, T(0.0)); }
-    else { double s = val(x.z) >= 0 ? 1.0 : -1.0; d = x.z * T(s) - T(shape[1]); n = mk<T>(T(0.0), T(0.0), T(s)); }
+    else { double s = val(x.z) >= 0 ? 1.0 : -1.0; d = x.z * T(s) - T(shape[1]); n = mk<T>(T(0.0), T(0.0), T(s)); face = s > 0 ? 1 : 2; }
   }
   if (!(val(d) < 0.0)) return false;
   V3<T> xd = mulT(RP, vrel_w);
@@ -171,7 +174,9 @@ static bool contact_force(int prim, const double* shape, const double* k, const 
   V3<T> F = n * fn;
   double vtn = std::sqrt(val(vt2));
   double fnabs = std::fabs(val(fn));
-  if (k[1] * vtn <= k[2] * fnabs || vtn < 1e-14) {
+  const bool stick = k[1] * vtn <= k[2] * fnabs || vtn < 1e-14;
+  if (branch) *branch = (stick ? 1 : 0) | (face << 1);
+  if (stick) {
     F = F - vt * T(k[1]);                                  // "sticking": viscous
   } else {
     T s = (val(fn) >= 0 ? fn : -fn) * T(k[2]) / sqrt(vt2);  // sliding: Coulomb
@@ -354,6 +359,51 @@ static void outputs(const Model& m, const T* q, const T* qd, T* var, T* tac, boo
       tac[3 * t + 2] = Fl.x * T(m.tax(9, t)) + Fl.y * T(m.tax(10, t)) + Fl.z * T(m.tax(11, t));
     }
   }
+}
+
+// Branch signature of the state (q, qd) (test diagnostics; the HIP library states the same two numbers in
+// tsim_debug_signature): over the dynamics-active contact points and the (taxel, paired primitive) items, count those that
+// penetrate and add up mix(group, index, 1 + branch) mod 2^32.
+static inline unsigned sig_mix(unsigned group, unsigned index, unsigned code) {
+  unsigned x = (group * 0x9E3779B1u) ^ (index * 0x85EBCA77u) ^ (code * 0xC2B2AE3Du);
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+static void signature(const Model& m, const double* q, const double* qd, unsigned* out) {
+  Link<double> L[MAXL]; V3<double> Ww[MAXR], Wv[MAXR];
+  double zero[MAXR]; for (int k = 0; k < m.nr; ++k) zero[k] = 0.0;
+  kinematics<double>(m, q, qd, zero, L, Ww, Wv, false);
+  unsigned cnt = 0, sum = 0;
+  for (int pk = 0; pk < m.npair; ++pk) {
+    const int* pi = m.pi(pk); const double* pf = m.pf(pk);
+    if (!(pi[TSIM_PI_FLAGS] & 1)) continue;
+    M3<double> RP; V3<double> pP; prim_pose(m, pk, L, RP, pP);
+    const Link<double>& A = L[pi[TSIM_PI_LINKA]]; const Link<double>& Bk = L[pi[TSIM_PI_LINKB]];
+    for (int i = 0; i < pi[TSIM_PI_NPT]; ++i) {
+      int c = pi[TSIM_PI_PT0] + i;
+      V3<double> xw = mul(A.R, mk<double>(m.cpt(0, c), m.cpt(1, c), m.cpt(2, c))) + A.p;
+      if (pi[TSIM_PI_FLAGS] & 2) xw = xw - mk<double>(RP.m[2], RP.m[5], RP.m[8]) * pf[TSIM_PF_SHAPE];
+      V3<double> vrel = (A.v + cross(A.w, xw)) - (Bk.v + cross(Bk.w, xw)), Fw; int br = 0;
+      if (contact_force<double>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, RP, pP, xw, vrel, Fw, &br)) { ++cnt; sum += sig_mix((unsigned)pk, (unsigned)i, (unsigned)(1 + br)); }
+    }
+  }
+  for (int s = 0; s < m.nsensor; ++s) {
+    const int* si = m.si(s); const double* sf = m.sf(s);
+    const Link<double>& A = L[si[TSIM_SI_LINK]];
+    for (int j = 0; j < si[TSIM_SI_NSPRIM]; ++j) {
+      int pk = m.sprim(si[TSIM_SI_SPRIM0] + j);
+      const int* pi = m.pi(pk); const double* pf = m.pf(pk);
+      M3<double> RP; V3<double> pP; prim_pose(m, pk, L, RP, pP);
+      const Link<double>& Bk = L[pi[TSIM_PI_LINKB]];
+      for (int i = 0; i < si[TSIM_SI_NTAX]; ++i) {
+        int t = si[TSIM_SI_TAX0] + i;
+        V3<double> xw = mul(A.R, mk<double>(m.tax(0, t), m.tax(1, t), m.tax(2, t))) + A.p;
+        V3<double> vrel = (A.v + cross(A.w, xw)) - (Bk.v + cross(Bk.w, xw)), Fw; int br = 0;
+        if (contact_force<double>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, RP, pP, xw, vrel, Fw, &br)) { ++cnt; sum += sig_mix(0x10000u + (unsigned)(si[TSIM_SI_SPRIM0] + j), (unsigned)i, (unsigned)(1 + br)); }
+      }
+    }
+  }
+  out[0] = cnt; out[1] = sum;
 }
 
 // ------------------------------------------------------------------------------------------ dense LU
@@ -562,6 +612,12 @@ void orc_reset(void* h, const double* q, const double* qd, int record) {
 int orc_forward(void* h, const double* u, int nsub) {
   Sim& S = *(Sim*)h; int bad = 0;
   for (int s = 0; s < nsub; ++s) if (substep(S, u) < 0) ++bad;
+  return bad;
+}
+// the same, recording the branch signature (count, hash) after every sub-step: sig [nsub][2]
+int orc_forward_sig(void* h, const double* u, int nsub, unsigned* sig) {
+  Sim& S = *(Sim*)h; int bad = 0;
+  for (int s = 0; s < nsub; ++s) { if (substep(S, u) < 0) ++bad; signature(S.m, S.q.data(), S.qd.data(), sig + 2 * s); }
   return bad;
 }
 void orc_get_state(void* h, double* q, double* qd) { Sim& S = *(Sim*)h; for (int k = 0; k < S.m.nr; ++k) { q[k] = S.q[k]; qd[k] = S.qd[k]; } }

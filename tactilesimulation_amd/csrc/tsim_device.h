@@ -304,7 +304,7 @@ __host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu, int esz)
 // LDS reals of a block of nslot environments. nfrec: leading reals of the model blob that are staged in LDS (everything
 // except the per-point SoA arrays); one copy per block, or one per slot with per-environment tables.
 // The contact-point SoA arrays (3 ncpt reals right behind the tables in the blob) are staged with the shared tables when
-// the host says so (S[TS_SCHED_STAGE_CPT]: they are small and do not cost the launch its lanes-per-environment shape):
+// the host says so (kernel argument stage_cpt, decided per launch: they are small and do not cost the launch its lanes-per-environment shape):
 // every residual evaluation reads all of them, and a lone wavefront cannot hide ~600-cycle L2 latencies.
 #define TS_CPT_LDS_BYTES 8192
 __host__ __device__ inline int ts_cpt_staged(int ncpt, bool env_tables, bool stage) {
@@ -324,7 +324,7 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, i
 // lane k < nr walks only the links of the branch of its own dof k — all branches advance together, and the sweep takes
 // max(branch size) steps instead of nl.
 //   S[0] = number of ints, S[1] = steps, S[2 + l] = branch of lane l (l < 16; -1: lane has no dof),
-//   S[18 + b] = leader lane of branch b, S[34] = number of branches, S[35] = stage the contact-point arrays in LDS,
+//   S[18 + b] = leader lane of branch b, S[34] = number of branches, S[35] = unused,
 //   S[TS_SCHED_ENT + step * 16 + l] = link visited by lane l at that step | leader << 8 (0: none; the leader lane of a
 //   branch stores the link's value record), then per link 8 ints: parent, joint type, dof0, ndof, ancestor mask, branch.
 // The leaf->root projection (phase 3) uses the same lists backwards, one lane per (direction, branch).
@@ -337,7 +337,7 @@ template <class C> __device__ __forceinline__ const int* ts_pair_rec(const C& c,
 
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
-template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, const R* Fenv = nullptr) {
+template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, bool stage_cpt, const R* Fenv = nullptr) {
   // Stage the model's FLOAT tables in LDS (link / dof / motor / pair / sensor records): later reads are ds_read
   // broadcasts instead of ~500-cycle global loads.  The INT tables stay in global memory on purpose: they are
   // wave-uniform, so they travel through the scalar cache and all indexing / control flow stays on the SALU.
@@ -348,10 +348,10 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
       mf += slot * (nfrec + 2);
       for (int i = lane; i < nfrec; i += lpe) mf[i] = Fenv[i];
     } else {
-      const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, I[I[TSIM_IH_NI] + TS_SCHED_STAGE_CPT] != 0);   // tables (+ contact points)
+      const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, stage_cpt);   // tables (+ contact points)
       for (int i = threadIdx.x; i < nst; i += TS_WAVE) mf[i] = F[i];
     }
-    lds += ts_tab_reals(nfrec, I[TSIM_IH_NCPT], nslot, Fenv != nullptr, I[I[TSIM_IH_NI] + TS_SCHED_STAGE_CPT] != 0);
+    lds += ts_tab_reals(nfrec, I[TSIM_IH_NCPT], nslot, Fenv != nullptr, stage_cpt);
     {                                            // sweep schedule + link int records (one copy per block)
       const int* S = I + I[TSIM_IH_NI];
       const int ns = S[0];
@@ -362,7 +362,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     }
     __syncthreads();
     c.Fg = F; c.F = mf; c.I = I;
-    c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, I[I[TSIM_IH_NI] + TS_SCHED_STAGE_CPT] != 0) ? mf : F) + I[TSIM_IH_FOFF_CPT];
+    c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt) ? mf : F) + I[TSIM_IH_FOFF_CPT];
     F = mf;
   }
   c.stamps = nullptr; c.nstamp = 0;
@@ -419,23 +419,37 @@ __device__ __forceinline__ int anc_of(const int* I, int off_link, int link) {
   return link > 0 ? I[off_link + (link - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK] : 0;
 }
 
+// ------------------------------------------------------------------------------------------------ branch signature
+// Per (environment, sub-step): which contact points / taxels penetrate and on which smooth piece of the penalty law each
+// of them is (tsim_debug_signature in include/tsim.h; the oracle computes the same two numbers).  Item id = (pair or
+// sensor-primitive list index, point index); term = mix(id, code), code = 1 + branch of contact_law; the signature is
+// (number of penetrating items, sum of terms mod 2^32) — commutative, so lanes can add in any order.
+__host__ __device__ inline unsigned ts_sig_mix(unsigned group, unsigned index, unsigned code) {
+  unsigned x = (group * 0x9E3779B1u) ^ (index * 0x85EBCA77u) ^ (code * 0xC2B2AE3Du);
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
 // ------------------------------------------------------------------------------------------------ contact law
 // DiffHand penalty model in the primitive's frame: d < 0:  fn = (-kn + kd ddot) d,  ft = -min(kt |vt|, mu |fn|) vt/|vt|.
 // x = point in the primitive frame, v = its velocity relative to the primitive (same frame).
 // Returns the force on the point; with JAC also Jx = dF/dx and Jv = dF/dv (exact: the law is piecewise smooth).
 // xh: the same point in double — the signed distance (a small difference of large numbers) is taken from it.
+// branch (diagnostics, tsim_debug_signature): which smooth piece of the law the point is on — bit 0 = sticking, bits 1.. =
+// face of the primitive (cuboid: 2 axis + (negative side); cylinder: 0 side, 1 / 2 caps; plane, sphere: 0).
 template <class R, bool JAC>
-__device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv, V3<double> xh) {
+__device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv, V3<double> xh, int* branch = nullptr) {
   const R kn = kp[0], kt = kp[1], mu = kp[2], kd = kp[3];
   R d; V3<R> n;
   R ncurv = R(0);          // N = dn/dx = ncurv * (Pm - n n^T), Pm = diag(1, 1, pz)
   R pz = R(1);
+  int face = 0;
   if (prim == TSIM_P_PLANE) { d = (R)xh.z; n = mk3<R>(R(0), R(0), R(1)); }
   else if (prim == TSIM_P_CUBOID) {
     const double ex = fabs(xh.x) - (double)shape[0], ey = fabs(xh.y) - (double)shape[1], ez = fabs(xh.z) - (double)shape[2];
-    if (ex >= ey && ex >= ez) { const R s = xh.x >= 0.0 ? R(1) : R(-1); d = (R)ex; n = mk3<R>(s, R(0), R(0)); }
-    else if (ey >= ez)        { const R s = xh.y >= 0.0 ? R(1) : R(-1); d = (R)ey; n = mk3<R>(R(0), s, R(0)); }
-    else                      { const R s = xh.z >= 0.0 ? R(1) : R(-1); d = (R)ez; n = mk3<R>(R(0), R(0), s); }
+    if (ex >= ey && ex >= ez) { const R s = xh.x >= 0.0 ? R(1) : R(-1); d = (R)ex; n = mk3<R>(s, R(0), R(0)); face = xh.x >= 0.0 ? 0 : 1; }
+    else if (ey >= ez)        { const R s = xh.y >= 0.0 ? R(1) : R(-1); d = (R)ey; n = mk3<R>(R(0), s, R(0)); face = xh.y >= 0.0 ? 2 : 3; }
+    else                      { const R s = xh.z >= 0.0 ? R(1) : R(-1); d = (R)ez; n = mk3<R>(R(0), R(0), s); face = xh.z >= 0.0 ? 4 : 5; }
   } else if (prim == TSIM_P_SPHERE) {
     const double r2 = xh.x * xh.x + xh.y * xh.y + xh.z * xh.z;
     if (r2 < 1e-24) return false;
@@ -446,7 +460,7 @@ __device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* k
     const double dr = rhod - (double)shape[0], dz = fabs(xh.z) - (double)shape[1];
     const R rho = (R)rhod;
     if (dr > dz && rhod > 1e-12) { d = (R)dr; const R ir = R(1) / rho; n = mk3<R>(x.x * ir, x.y * ir, R(0)); ncurv = ir; pz = R(0); }
-    else { const R s = xh.z >= 0.0 ? R(1) : R(-1); d = (R)dz; n = mk3<R>(R(0), R(0), s); }
+    else { const R s = xh.z >= 0.0 ? R(1) : R(-1); d = (R)dz; n = mk3<R>(R(0), R(0), s); face = xh.z >= 0.0 ? 1 : 2; }
   }
   if (!(d < R(0))) return false;
   const R dd = dot3(n, v);
@@ -455,6 +469,7 @@ __device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* k
   const V3<R> vt = v - n * dd;
   const R vtn = t_sqrt(dot3(vt, vt));
   const bool stick = kt * vtn <= mu * t_abs(fn) || vtn < R(1e-14);
+  if (branch) *branch = (stick ? 1 : 0) | (face << 1);
   R s = kt;
   const R sg = fn >= R(0) ? R(1) : R(-1);
   if (!stick) s = mu * sg * fn / vtn;

@@ -94,6 +94,7 @@ template <class R> struct FwdArgs {
   R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
   const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
   double* prev; int has_prev;  // state before the previous sub-step [B][2 nr] doubles (BDF2 history across launches)
+  int stage_cpt;               // contact-point arrays staged in LDS with the shared tables (sized into the launch's LDS)
 };
 
 template <class R, int NRM, bool EXPJ, int LPE>
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   const int eidx = blockIdx.x * NS + slot;
   const bool valid = eidx < a.B;                                        // a batch that is no multiple of NS: idle slot
   const int env = a.order ? a.order[min(eidx, a.B - 1)] : min(eidx, a.B - 1);
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   init_world(c, lane, LPE);
   {
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   }
   if (lane < nr && valid) {
     const size_t o = ((size_t)f * a.B + env) * nr + lane;
-    if (a.q_out) a.q_out[o] = c.q0[lane];
+    if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
     if (a.qd_out) a.qd_out[o] = c.qd0[lane];
   }
   // link poses / velocities in LDS are those of the accepted state (last evaluation)
@@ -270,14 +271,14 @@ __global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* 
 }
 
 // ================================================================================================ read-out kernel
-template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R *var_out, *tac_out; int slice; };
+template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R *var_out, *tac_out; int slice; int stage_cpt; };
 
 template <class R>
 __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   const int env = blockIdx.x, lane = threadIdx.x;
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, 1, 0, lane, TS_WAVE, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, 1, 0, lane, TS_WAVE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
   const int nr = c.nr, REC = ts_rec(nr, c.nu, (int)sizeof(R));
   init_world(c, lane, TS_WAVE);
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
@@ -289,8 +290,85 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   readout<TS_WAVE>(c, lane, env, true, blockIdx.y == 0 ? a.var_out : nullptr, a.tac_out, (int)blockIdx.y * a.slice, ((int)blockIdx.y + 1) * a.slice);
 }
 
+// ================================================================================================ branch signature
+// Diagnostics (tsim_debug_signature): for the taped sub-steps t_first+1 .. t_first+n of every environment, which contact
+// points / taxels penetrate and on which smooth piece of the penalty law (stick / slip, face of the primitive) each one is,
+// recomputed from the taped state (q as double, qd) exactly as the backward kernel re-evaluates it.  Two trajectories with
+// equal signatures went through the same smooth pieces, so their gradients are comparable; where they differ, one of them
+// crossed a contact / friction kink.  One environment per 64-lane block; lanes = points.
+template <class R> struct SigArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t_first, n; const R* tape; unsigned* out; int stage_cpt; };
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned x) {
+  for (int off = 32; off > 0; off >>= 1) x += (unsigned)lane_gather((int)x, (int)threadIdx.x ^ off);
+  return x;
+}
+
+template <class R>
+__global__ void __launch_bounds__(TS_WAVE) k_signature(SigArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R* lds = reinterpret_cast<R*>(smem_raw);
+  const int env = blockIdx.x, lane = threadIdx.x;
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, 1, 0, lane, TS_WAVE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)blockIdx.x * a.fstride : nullptr);
+  const int nr = c.nr, REC = ts_rec(nr, c.nu, (int)sizeof(R));
+  init_world(c, lane, TS_WAVE);
+  for (int j = 0; j < a.n; ++j) {
+    const R* st = a.tape + ((size_t)(a.t_first + 1 + j) * a.B + env) * REC;
+    __syncthreads();
+    if (lane < nr) { c.qD[lane] = rec_q(st)[lane]; c.q[lane] = (R)c.qD[lane]; c.qd[lane] = st[rec_qd<R>(nr) + lane]; c.qa[lane] = R(0); }
+    __syncthreads();
+    phase1<R, false, true>(c, lane, R(0), R(0), R(0));
+    unsigned cnt = 0, sum = 0;
+    for (int pk = 0; pk < c.npair; ++pk) {                     // dynamics-active contact pairs
+      const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+      if (!(pi[TSIM_PI_FLAGS] & 1)) continue;
+      const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+      __syncthreads();
+      pair_stage_value(c, pk, 0, lane == 0);
+      __syncthreads();
+      const R* S = c.PP;
+      const M3<double> RPAd = ldm(c.PPd); const V3<double> pPAd = ldv(c.PPd + 9);
+      const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+      for (int i = lane; i < pi[TSIM_PI_NPT]; i += TS_WAVE) {
+        const R* cp = c.CPT + pi[TSIM_PI_PT0] + i;
+        V3<double> xPd = mulMv(RPAd, mk3<double>((double)cp[0], (double)cp[c.ncpt], (double)cp[2 * c.ncpt])) + pPAd;
+        if (pi[TSIM_PI_FLAGS] & 2) xPd.z -= (double)pf[TSIM_PF_SHAPE];
+        const V3<R> xP = cvt3<R>(xPd);
+        V3<R> F; M3<R> Jx, Jv; int br = 0;
+        if (contact_law<R, false>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd, &br)) {
+          ++cnt; sum += ts_sig_mix((unsigned)pk, (unsigned)i, (unsigned)(1 + br));
+        }
+      }
+    }
+    for (int s = 0; s < c.nsensor; ++s) {                      // taxels against the primitives paired with their sensor
+      const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
+      const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
+      for (int jp = 0; jp < si[TSIM_SI_NSPRIM]; ++jp) {
+        const int pk = c.I[c.off_sprim + si[TSIM_SI_SPRIM0] + jp];
+        const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+        const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+        __syncthreads();
+        pair_stage_value(c, pk, 0, lane == 0);
+        __syncthreads();
+        const R* S = c.PP;
+        const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+        for (int i = lane; i < si[TSIM_SI_NTAX]; i += TS_WAVE) {
+          const R* tp = c.Fg + c.foff_tax + si[TSIM_SI_TAX0] + i;
+          const V3<double> xPd = mulMv(ldm(c.PPd), mk3<double>((double)tp[0], (double)tp[c.ntax], (double)tp[2 * c.ntax])) + ldv(c.PPd + 9);
+          const V3<R> xP = cvt3<R>(xPd);
+          V3<R> F; M3<R> Jx, Jv; int br = 0;
+          if (contact_law<R, false>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd, &br)) {
+            ++cnt; sum += ts_sig_mix(0x10000u + (unsigned)(si[TSIM_SI_SPRIM0] + jp), (unsigned)i, (unsigned)(1 + br));
+          }
+        }
+      }
+    }
+    cnt = wave_sum_u32(cnt); sum = wave_sum_u32(sum);
+    if (lane == 0) { unsigned* o = a.out + ((size_t)j * a.B + env) * 2; o[0] = cnt; o[1] = sum; }
+  }
+}
+
 // ================================================================================================ debug evaluation
-template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; };
+template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; int stage_cpt; };
 
 template <class R, int LPE>
 __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
@@ -300,7 +378,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
   const bool valid = (int)blockIdx.x * NS + slot < a.B;
   const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu;
   init_world(c, lane, LPE);
   if (lane < nr) {
@@ -338,6 +416,7 @@ template <class R> struct BwdArgs {
   const R* tape;
   const R *df_dq, *df_dvar, *df_dtac;
   R *lamq, *lamv, *df_du;
+  int stage_cpt;
 };
 
 // (M z)_j for lane j: direct sums over the links below dof j (no recursion, no scratch)
@@ -458,7 +537,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
   const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
   const bool valid = (int)blockIdx.x * NS + slot < a.B;
   const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
   R* H2 = c.H2;    // taped Newton matrix of the sub-step
@@ -527,6 +606,18 @@ static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
+// Every entry point runs on the batch's device and leaves the calling thread's current device as it found it (a process
+// may drive several GPUs, and torch's current device / current_stream() follow the thread's HIP device).
+struct DeviceGuard {
+  int prev = -1; bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define TS_DEVICE(b) DeviceGuard guard_((b)->device); if (!guard_.ok) return fail("hipSetDevice(" + std::to_string((b)->device) + ") failed")
+
 struct CacheEntry { void* buf; int len; int record; };
 struct tsim_batch {
   int B, dtype, device, cap;
@@ -546,7 +637,8 @@ struct tsim_batch {
   int stage_cpt;                 // the contact-point arrays are staged in LDS with the shared tables
   int n_simd;                    // SIMDs of the device (CUs x 4)
   size_t esz;
-  std::vector<CacheEntry> cache;
+  std::vector<CacheEntry> cache;   // saved tapes, newest last
+  std::vector<void*> pool;          // spare tape buffers
 };
 
 // sweep schedule of the link tree (layout: ts_sched in tsim_device.h)
@@ -593,7 +685,6 @@ static int upload_model(tsim_batch* b, hipStream_t st) {
   {
     std::vector<int32_t> S = build_sched(b->I);              // appended to the device copy at I[TSIM_IH_NI]
     if ((int)S.size() != b->nsched) return fail("sweep schedule size changed");
-    S[TS_SCHED_STAGE_CPT] = b->stage_cpt;
     HIPCHK(hipMemcpyAsync(b->dI + b->I.size(), S.data(), S.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -693,7 +784,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = tac_slot;
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
-  a.prev = (double*)b->prev; a.has_prev = b->has_prev;
+  a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
   if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
@@ -710,7 +801,7 @@ static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, co
   BwdArgs<R> a;
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames; a.tac_slot = tac_slot;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
-  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du;
+  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt;
   TS_LAUNCH(k_backward, R, b, st, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -737,7 +828,8 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   }
   for (int s = 0; s < I[TSIM_IH_NSENSOR]; ++s)
     if (I[I[TSIM_IH_OFF_SENSOR] + s * TSIM_SI_SIZE + TSIM_SI_NSPRIM] > 16) return fail("too many primitives per sensor");
-  HIPCHK(hipSetDevice(device));
+  DeviceGuard guard_(device);
+  if (!guard_.ok) return fail("hipSetDevice(" + std::to_string(device) + ") failed");
   tsim_batch* b = new tsim_batch();
   b->B = B; b->dtype = dtype; b->device = device; b->cap = tape_capacity;
   b->I.assign(I, I + I[TSIM_IH_NI]); b->F.assign(F, F + I[TSIM_IH_NF]);
@@ -777,8 +869,9 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
 
 void tsim_batch_destroy(tsim_batch* b) {
   if (!b) return;
-  (void)hipSetDevice(b->device);
+  DeviceGuard guard_(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
+  for (void* p : b->pool) (void)hipFree(p);
   (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->order); (void)hipFree(b->prev);
   delete b;
 }
@@ -808,29 +901,26 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
     b->stage_cpt = 1;
     if (launch_shape(b).lpe != lpe0) b->stage_cpt = 0;
   }
-  if (b->stage_cpt != old) {
-    HIPCHK(hipSetDevice(b->device));
-    const int32_t v = b->stage_cpt;
-    HIPCHK(hipMemcpy(b->dI + b->I.size() + TS_SCHED_STAGE_CPT, &v, sizeof(v), hipMemcpyHostToDevice));
-  }
+  (void)old;      // the flag travels with every launch as a kernel argument: nothing on the device to update
   return 0;
 }
 int tsim_last_evals(tsim_batch* b, int32_t* host_out) {
-  if (hipSetDevice(b->device) != hipSuccess || hipMemcpy(host_out, b->evals, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_evals: copy failed");
+  TS_DEVICE(b);
+  if (hipMemcpy(host_out, b->evals, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_evals: copy failed");
   return 0;
 }
 
 int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* stream) {
   if (I[TSIM_IH_NI] != (int)b->I.size() || I[TSIM_IH_NF] != (int)b->F.size()) return fail("update_model: blob size changed");
   for (int i = 0; i < TSIM_IH_SIZE; ++i) if (I[i] != b->I[i]) return fail("update_model: topology changed");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   b->I.assign(I, I + I[TSIM_IH_NI]); b->F.assign(F, F + I[TSIM_IH_NF]);
   if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; }     // per-environment tables refer to the old model
   return upload_model(b, (hipStream_t)stream);
 }
 
 int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream) {
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   if (!tables) { if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; } return 0; }
   size_t bytes = (size_t)b->B * b->nfrec * b->esz;
   if (!b->dFenv) HIPCHK(hipMalloc(&b->dFenv, bytes));
@@ -841,7 +931,7 @@ int tsim_table_size(const tsim_batch* b) { return b->nfrec; }
 
 int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag, void* stream) {
   if (!q0) return fail("reset: q0 is null");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   hipStream_t st = (hipStream_t)stream;
   int n = b->B * b->nr, blk = 256, grd = (n + blk - 1) / blk;
   if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_set_state<float>, dim3(grd), dim3(blk), 0, st, (float*)b->tape, (const float*)q0, (const float*)qd0, b->B, b->nr, b->rec);
@@ -856,7 +946,7 @@ int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag
 int tsim_reset_masked(tsim_batch* b, const void* q0, const void* qd0, const int32_t* mask, void* stream) {
   if (!q0 || !mask) return fail("reset_masked: q0 / mask is null");
   if (b->record) return fail("reset_masked: not while recording (the tape is shared by the batch): use reset");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   hipStream_t st = (hipStream_t)stream;
   int n = b->B * b->nr, blk = 256, grd = (n + blk - 1) / blk;
   size_t off = (size_t)b->t_cur * b->B * b->rec;
@@ -872,7 +962,7 @@ int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd
   if (num_steps <= 0) return fail("step: num_steps must be positive");
   if (!u && b->nu > 0) return fail("step: u is null");
   if (b->record && b->t_cur + num_steps > b->cap) return fail("step: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, 1, nullptr, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
                                 : launch_forward<double>(b, u, 1, nullptr, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
   if (rc) return rc;
@@ -882,7 +972,7 @@ int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd
 }
 
 int tsim_get_state(tsim_batch* b, void* q_out, void* qd_out, void* stream) {
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   int n = b->B * b->nr, blk = 256, grd = (n + blk - 1) / blk;
   size_t off = (size_t)b->t_cur * b->B * b->rec;
   if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_get_state<float>, dim3(grd), dim3(blk), 0, (hipStream_t)stream, (const float*)b->tape + off, (float*)q_out, (float*)qd_out, b->B, b->nr, b->rec);
@@ -892,15 +982,15 @@ int tsim_get_state(tsim_batch* b, void* q_out, void* qd_out, void* stream) {
 }
 
 int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   const int slice = 1024;                                   // taxels per block
   const int ny = tac_out ? (b->ntax + slice - 1) / slice : 1;
   dim3 grid(b->B, ny > 0 ? ny : 1);
   if (b->dtype == TSIM_F32) {
-    ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out, slice};
+    ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out, slice, b->stage_cpt};
     hipLaunchKernelGGL(k_readout<float>, grid, dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
   } else {
-    ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out, slice};
+    ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out, slice, b->stage_cpt};
     hipLaunchKernelGGL(k_readout<double>, grid, dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
   }
   HIPCHK(hipGetLastError());
@@ -913,7 +1003,7 @@ int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, 
   if (n <= 0 || n > b->t_cur) return fail("backward_steps: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
   if (!df_du && b->nu > 0) return fail("backward_steps: df_du is null");
   if (seed_mode != 0 && seed_mode != 1) return fail("backward_steps: bad seed_mode");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   const int stride = seed_mode == 1 ? 1 : n;
   int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, n, stride, 0, nullptr, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
                                 : launch_backward<double>(b, n, stride, 0, nullptr, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
@@ -926,7 +1016,7 @@ int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, co
   if (num_frames <= 0 || num_steps <= 0) return fail("rollout: num_frames and num_steps must be positive");
   if (!u && b->nu > 0) return fail("rollout: u is null");
   if (b->record && b->t_cur + (long long)num_frames * num_steps > b->cap) return fail("rollout: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   int rc = b->dtype == TSIM_F32 ? launch_forward<float>(b, u, num_frames, tactile_slot, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream)
                                 : launch_forward<double>(b, u, num_frames, tactile_slot, num_steps, q_out, qd_out, var_out, tac_out, status, (hipStream_t)stream);
   if (rc) return rc;
@@ -942,7 +1032,7 @@ int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const in
   const long long n = (long long)num_frames * num_steps;
   if (n > b->t_cur) return fail("backward_episode: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
   if (!df_du && b->nu > 0) return fail("backward_episode: df_du is null");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   int rc = b->dtype == TSIM_F32 ? launch_backward<float>(b, (int)n, num_steps, 1, tactile_slot, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream)
                                 : launch_backward<double>(b, (int)n, num_steps, 1, tactile_slot, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
   if (rc) return rc;
@@ -951,56 +1041,88 @@ int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const in
 }
 
 int tsim_get_adjoint(tsim_batch* b, void* df_dq0, void* df_dqd0, void* stream) {
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   size_t bytes = (size_t)b->B * b->nr * b->esz;
   if (df_dq0) HIPCHK(hipMemcpyAsync(df_dq0, b->lamq, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (df_dqd0) HIPCHK(hipMemcpyAsync(df_dqd0, b->lamv, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 
+// Backward cache = LIFO of tape BUFFERS swapped by pointer (no tape copy): save parks the live tape on the stack and takes a
+// spare buffer from the pool (allocated on first use, or ahead of time by tsim_cache_reserve), pop swaps back.  After
+// warm-up neither allocates nor synchronises, so both can sit inside a captured HIP graph region's host code path.
+static size_t tape_bytes_of(const tsim_batch* b) { return (size_t)(b->cap + 1) * b->B * b->rec * b->esz; }
+int tsim_cache_reserve(tsim_batch* b, int depth) {
+  TS_DEVICE(b);
+  while ((int)(b->pool.size() + b->cache.size()) < depth) {
+    void* p = nullptr;
+    if (hipMalloc(&p, tape_bytes_of(b)) != hipSuccess) return fail("cache_reserve: hipMalloc of a " + std::to_string(tape_bytes_of(b)) + " byte tape failed");
+    b->pool.push_back(p);
+  }
+  return 0;
+}
 int tsim_cache_save(tsim_batch* b, void* stream) {
-  HIPCHK(hipSetDevice(b->device));
-  CacheEntry e; e.len = b->t_cur; e.record = b->record; e.buf = nullptr;
-  size_t bytes = (size_t)(b->t_cur + 1) * b->B * b->rec * b->esz;
-  HIPCHK(hipMalloc(&e.buf, bytes));
-  HIPCHK(hipMemcpyAsync(e.buf, b->tape, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  TS_DEVICE(b);
+  if (b->pool.empty()) { int rc = tsim_cache_reserve(b, (int)b->cache.size() + 1); if (rc) return rc; }
+  void* spare = b->pool.back(); b->pool.pop_back();
+  // the simulation goes on from its current state: carry the newest record (q, qd of all environments) over
+  const size_t rec_bytes = (size_t)b->B * b->rec * b->esz, off = (size_t)b->t_cur * rec_bytes;
+  HIPCHK(hipMemcpyAsync((char*)spare + off, (char*)b->tape + off, rec_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  CacheEntry e; e.buf = b->tape; e.len = b->t_cur; e.record = b->record;
   b->cache.push_back(e);
+  b->tape = spare;
   return 0;
 }
 int tsim_cache_pop(tsim_batch* b, void* stream) {
   if (b->cache.empty()) return fail("popBackwardCache: cache is empty");
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   CacheEntry e = b->cache.back(); b->cache.pop_back();
-  size_t bytes = (size_t)(e.len + 1) * b->B * b->rec * b->esz;
-  HIPCHK(hipMemcpyAsync(b->tape, e.buf, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  HIPCHK(hipFree(e.buf));
-  b->t_cur = e.len; b->record = e.record; b->has_prev = 0;
+  b->pool.push_back(b->tape);                 // stream order keeps earlier kernels on the old buffer safe: it is only
+  b->tape = e.buf;                            // handed out again by a later save on the same stream
+  b->t_cur = e.len; b->record = e.record; b->has_prev = 0; b->order_valid = 0;
   HIPCHK(hipMemsetAsync(b->lamq, 0, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream));
   HIPCHK(hipMemsetAsync(b->lamv, 0, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream));
   return 0;
 }
 int tsim_cache_clear(tsim_batch* b) {
-  (void)hipSetDevice(b->device);
-  for (auto& e : b->cache) (void)hipFree(e.buf);
+  DeviceGuard guard_(b->device);
+  for (auto& e : b->cache) b->pool.push_back(e.buf);
   b->cache.clear();
+  while (b->pool.size() > 2) { (void)hipFree(b->pool.back()); b->pool.pop_back(); }     // keep two spares warm
+  return 0;
+}
+int tsim_cache_depth(const tsim_batch* b) { return (int)b->cache.size(); }
+
+int tsim_debug_signature(tsim_batch* b, int t_first, int n, uint32_t* out, void* stream) {
+  if (!b->record) return fail("debug_signature: reset(backward_flag=True) was not called (the signature is taken from the tape)");
+  if (t_first < 0 || n <= 0 || t_first + n > b->t_cur) return fail("debug_signature: sub-steps " + std::to_string(t_first) + "+" + std::to_string(n) + " are not on the tape (" + std::to_string(b->t_cur) + ")");
+  if (!out) return fail("debug_signature: out is null");
+  TS_DEVICE(b);
+  if (b->dtype == TSIM_F32) {
+    SigArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, t_first, n, (const float*)b->tape, out, b->stage_cpt};
+    hipLaunchKernelGGL(k_signature<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
+  } else {
+    SigArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, t_first, n, (const double*)b->tape, out, b->stage_cpt};
+    hipLaunchKernelGGL(k_signature<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
+  }
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u, void* g_out, void* H_out, long long* cycles, void* stream) {
-  HIPCHK(hipSetDevice(b->device));
+  TS_DEVICE(b);
   // one environment per wavefront, unless TSIM_LPE forces a packed shape (nr <= 8 models: the stamped variant is NRM 8)
   const int lpe = (b->lpe_forced && !b->has_exp && (!cycles || b->nr <= 8)) ? b->lpe_forced : TS_WAVE;
   const int ns = TS_WAVE / lpe;
   const dim3 grid((b->B + ns - 1) / ns), blk(TS_WAVE);
   const size_t lds = lds_bytes_for(b, ns);
   if (b->dtype == TSIM_F32) {
-    DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles};
+    DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles, b->stage_cpt};
     if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<float, 16>), grid, blk, lds, (hipStream_t)stream, a);
     else if (lpe == 32) hipLaunchKernelGGL((k_debug_eval<float, 32>), grid, blk, lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_debug_eval<float, 64>), grid, blk, lds, (hipStream_t)stream, a);
   } else {
-    DbgArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles};
+    DbgArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles, b->stage_cpt};
     if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<double, 16>), grid, blk, lds, (hipStream_t)stream, a);
     else if (lpe == 32) hipLaunchKernelGGL((k_debug_eval<double, 32>), grid, blk, lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_debug_eval<double, 64>), grid, blk, lds, (hipStream_t)stream, a);

@@ -63,8 +63,10 @@ class BatchSim:
         if t.device != self.device or t.dtype != self.dtype:
             t = t.to(device=self.device, dtype=self.dtype)
         t = t.contiguous()
-        if t.numel() != self.B * dim:
-            raise ValueError("%s: expected %d x %d values, got shape %s" % (name, self.B, dim, tuple(t.shape)))
+        # env-major [B, dim] (or [B, n, d] with n * d == dim for per-sub-step seeds): a transposed or otherwise mis-shaped
+        # tensor must not be reinterpreted silently
+        if t.dim() < 2 or t.shape[0] != self.B or t.numel() != self.B * dim:
+            raise ValueError("%s: expected shape [%d, %d], got %s" % (name, self.B, dim, tuple(t.shape)))
         return t
 
     def empty(self, *dims):
@@ -218,6 +220,13 @@ class BatchSim:
     def cache_clear(self):
         capi.check(capi.lib().tsim_cache_clear(self._h))
 
+    def cache_reserve(self, depth):
+        """Pre-allocate tape buffers for `depth` saved episodes, so that cache_save / cache_pop never allocate."""
+        capi.check(capi.lib().tsim_cache_reserve(self._h, int(depth)))
+
+    def cache_depth(self):
+        return capi.lib().tsim_cache_depth(self._h)
+
     # ------------------------------------------------------------------ diagnostics
     def debug_eval(self, q1, q0, qd0, u, cycles=False):
         q1, q0, qd0 = (self._chk(x, self.ndof_r, "q") for x in (q1, q0, qd0))
@@ -227,6 +236,14 @@ class BatchSim:
         capi.check(capi.lib().tsim_debug_eval(self._h, _ptr(q1), _ptr(q0), _ptr(qd0), _ptr(u), _ptr(g), _ptr(H), _ptr(cyc),
                                               self._stream()))
         return (g, H, cyc) if cycles else (g, H)
+
+    def branch_signature(self, t_first=0, n=None):
+        """[n, B, 2] int64 (count, hash) of the contact / friction branches of the taped sub-steps t_first+1 .. t_first+n
+        (include/tsim.h tsim_debug_signature); needs reset(backward_flag=True)."""
+        n = self.tape_len() - t_first if n is None else int(n)
+        out = torch.empty((n, self.B, 2), device=self.device, dtype=torch.int32)
+        capi.check(capi.lib().tsim_debug_signature(self._h, int(t_first), n, _ptr(out), self._stream()))
+        return out.to(torch.int64) & 0xFFFFFFFF
 
     def last_evals(self):
         out = np.zeros(self.B, dtype=np.int32)

@@ -30,6 +30,8 @@ _SIGS = {
     "tsim_backward_episode": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tsim_get_adjoint": (C.c_int, [_vp, _vp, _vp, _vp]),
     "tsim_cache_save": (C.c_int, [_vp, _vp]), "tsim_cache_pop": (C.c_int, [_vp, _vp]), "tsim_cache_clear": (C.c_int, [_vp]),
+    "tsim_cache_reserve": (C.c_int, [_vp, C.c_int]), "tsim_cache_depth": (C.c_int, [_vp]),
+    "tsim_debug_signature": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "tsim_debug_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tsim_launch_info": (C.c_int, [_vp, _ip]),
     "tsim_set_lanes_per_env": (C.c_int, [_vp, C.c_int]),

@@ -289,8 +289,11 @@ class CompiledModel:
         z = np.load(path)
         spec = json.loads(bytes(z["spec"]).decode())
         cm = compile_spec(spec)
-        if not (np.array_equal(cm.I, z["I"]) and np.allclose(cm.F, z["F"], rtol=0, atol=0)):
+        # The stored arrays ARE the model (one ulp of numpy / BLAS drift in a recompile must not change what the kernels and the
+        # oracle simulate); the recompile only guards against compiler-version skew.
+        if not (np.array_equal(cm.I, z["I"]) and cm.F.shape == z["F"].shape and np.allclose(cm.F, z["F"], rtol=1e-12, atol=1e-300)):
             raise RuntimeError("model blob %s does not match its embedded spec (compiler version skew)" % path)
+        cm.I, cm.F = z["I"].copy(), z["F"].copy()
         return cm
 
 

@@ -12,7 +12,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-MODELS = os.path.join(ROOT, "tests", "golden", "models")
+MODELS = os.path.join(ROOT, "tactilesimulation_amd", "assets")
 
 
 @pytest.fixture(scope="session")

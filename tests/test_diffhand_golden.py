@@ -1,0 +1,88 @@
+"""Reference-pinned parity slot (last bullet).  `tests/golden/diffhand_pusher.npz` is what
+tools/capture_diffhand_golden.py records from a REAL DiffRedMax build (the reference's un-vendored simulator).  While the
+file is absent — it cannot be produced in this container: no DiffHand source, no network — these tests SKIP and the
+repository's parity stays "unpinned" (oracle pinned by closed-form mechanics + finite differences only).  Once it is
+committed, they compare the fp64 oracle (CPU) and the fp64 HIP kernels (GPU) with it.
+
+Tolerances: the XML's Newton tolerance (1e-8 on ||g||) is all two correct solvers share, and a 500-sub-step contact roll-out
+amplifies it (measured fp64 tol 1e-8 vs 1e-12 on this path: q median 7e-6, profiles/r02_branch_signature.json), hence
+1e-4 on q / variables over the first 20 env-steps, 5 % of the peak on tactile, and gradients by the reference's own
+criterion (algorithms/gd.py:459-465: relative error and cosine)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "diffhand_pusher.npz")
+needs_golden = pytest.mark.skipif(not os.path.exists(GOLDEN), reason="PARITY UNPINNED: tests/golden/diffhand_pusher.npz absent "
+                                  "(run tools/capture_diffhand_golden.py against a DiffRedMax build)")
+
+
+def _check(g, q, var, tac, du, label, n_strict=20):
+    sc_t = np.abs(g["tactile"]).max()
+    assert np.abs(q[:n_strict] - g["q"][:n_strict]).max() < 1e-4, label
+    assert np.abs(var[:n_strict] - g["var"][:n_strict]).max() < 1e-4, label
+    assert np.abs(tac[:n_strict] - g["tactile"][:n_strict]).max() < 5e-2 * sc_t, label
+    a, b = du.reshape(-1), g["df_du"].reshape(-1)
+    rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+    assert rel < 5e-2 and cos > 0.99, (label, rel, cos)
+
+
+def _run_oracle(g, model):
+    from oracle.oracle import OracleSim
+    T, S = g["u"].shape[0], int(g["frame_skip"])
+    o = OracleSim(model)
+    o.reset(g["q0"], record=True)
+    q, var, tac = np.zeros_like(g["q"]), np.zeros_like(g["var"]), np.zeros_like(g["tactile"])
+    for t in range(T):
+        o.forward(g["u"][t], S)
+        q[t] = o.state()[0]
+        var[t], tac[t] = o.outputs()
+    n = T * S
+    dq = np.zeros((n, q.shape[1])); dq[S - 1::S, 3] = 1.0; dq[S - 1::S, 4] = 1.0
+    du = o.backward_steps(n, dq, None, None)
+    return q, var, tac, du
+
+
+@needs_golden
+def test_oracle_matches_diffredmax_golden(pusher_model):
+    g = np.load(GOLDEN)
+    assert "SHIM" not in str(g["source"]), "the committed file is a shim self-test, not a DiffRedMax capture"
+    assert list(g["dims"]) == [pusher_model.ndof_r, pusher_model.ndof_u, pusher_model.ndof_var, pusher_model.ndof_tactile]
+    assert abs(float(g["h"]) - pusher_model.h) < 1e-15
+    _check(g, *_run_oracle(g, pusher_model), label="oracle vs DiffRedMax")
+
+
+@needs_golden
+@pytest.mark.gpu
+def test_fp64_kernels_match_diffredmax_golden(pusher_model):
+    import torch
+    from tactilesimulation_amd.host.batch import BatchSim
+    g = np.load(GOLDEN)
+    T, S = g["u"].shape[0], int(g["frame_skip"])
+    sim = BatchSim(pusher_model, 1, dtype=torch.float64, tape_capacity=T * S)
+    sim.reset(torch.tensor(g["q0"][None]), None, backward_flag=True)
+    ro = sim.rollout(torch.tensor(g["u"][:, None, :], device="cuda"), S)
+    dq = torch.zeros(T, 1, 7, dtype=torch.float64, device="cuda"); dq[:, :, 3:5] = 1.0
+    du = sim.backward_episode(T, S, dq, None, None).cpu().numpy()[:, 0]          # summed per env-step
+    gd = dict(g); gd["df_du"] = g["df_du"].reshape(T, S, -1).sum(1)
+    _check(gd, ro["q"][:, 0].cpu().numpy(), ro["var"][:, 0].cpu().numpy(), ro["tactile"][:, 0].cpu().numpy(), du, label="HIP fp64 vs DiffRedMax")
+
+
+@pytest.mark.gpu
+def test_capture_hook_runs_against_the_shim_and_the_consumer_reads_it(tmp_path, pusher_model):
+    """Self-test of the hook (NOT parity): the capture script runs unmodified against this repository's `redmax_py` shim,
+    writes the §8c record (< 400 KB), and the consumer above accepts it against the oracle."""
+    out = str(tmp_path / "shim_capture.npz")
+    xml = os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "capture_diffhand_golden.py"), "--shim", "--xml", xml, "--out", out])
+    assert os.path.getsize(out) < 400 * 1024
+    g = np.load(out)
+    assert "SHIM" in str(g["source"])
+    assert g["q"].shape == (100, 7) and g["var"].shape == (100, 6) and g["tactile"].shape == (100, 390) and g["df_du"].shape == (500, 6)
+    assert np.abs(g["tactile"]).max() > 1e-3 and np.abs(g["df_du"]).max() > 0
+    _check(g, *_run_oracle(g, pusher_model), label="oracle vs shim capture")

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tactilesimulation_amd", "compat"))
 def _model(tol=None):
     import tactilesimulation_amd.model.blob as B
     from tactilesimulation_amd.model.compiler import load_model
-    m = load_model(os.path.join(ROOT, "tests", "golden", "models", "tactile_pad.npz"))
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "tactile_pad.npz"))
     if tol is not None:
         m.F[B.TSIM_FH_TOL] = tol
         m.spec["options"]["tol"] = tol

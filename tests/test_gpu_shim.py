@@ -8,12 +8,12 @@ import numpy as np
 import pytest
 import torch
 
-from tests.workloads import push_workload
+from tactilesimulation_amd.workloads import push_workload
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(ROOT, "tactilesimulation_amd", "compat"))
-PUSHER = os.path.join(ROOT, "tests", "golden", "models", "pusher.npz")
+PUSHER = os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz")
 
 
 def _tight(model, tol=1e-13):
@@ -146,3 +146,88 @@ def test_update_parameters_and_flow_images(pusher_model):
     assert len(img) == 1 and img[0].shape == (13, 10, 3) and np.allclose(img[0].reshape(-1), sim.get_tactile_force_vector())
     pos = sim.get_tactile_image_pos("tactile_pad_left")
     assert len(pos) == 130 and pos[12] == (1, 2)
+
+
+def test_backward_cache_is_a_lifo_of_tapes_depth_3_and_clear(pusher_model):
+    """saveBackwardCache / popBackwardCache / clearBackwardCache (envs/redmax_torch_functions.py:65,81;
+    envs/tactile_insertion_env.py:226; envs/stable_grasp_env.py:133): three episodes are forwarded and saved before any
+    backward; the pops return them newest first, each adjoint equals the oracle's for THAT episode; the tapes are swapped by
+    pointer (no allocation once the pool is warm); clear empties the stack."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    from oracle.oracle import OracleSim
+    m = _tight(pusher_model)
+    B, T, S, E = 3, 4, 5, 3
+    sim = BatchSim(m, B, dtype=torch.float64, tape_capacity=T * S)
+    sim.cache_reserve(E)                                   # the only allocations: before the episodes
+    eps = [push_workload(B, T, seed=60 + k) for k in range(E)]
+    wq = [np.random.default_rng(70 + k).normal(size=(T, 7)) for k in range(E)]
+    tile = lambda w: torch.tensor(np.broadcast_to(w[:, None, :], (T, B, w.shape[1])).copy(), device="cuda")
+    finals = []
+    for k, (q0, u, _) in enumerate(eps):
+        sim.reset(torch.tensor(q0), None, backward_flag=True)
+        ro = sim.rollout(torch.tensor(u, device="cuda").transpose(0, 1).contiguous(), S)
+        finals.append(ro["q"][-1].clone())
+        assert sim.tape_len() == T * S
+        sim.cache_save()
+        assert sim.cache_depth() == k + 1
+        q_now, _ = sim.get_state()                         # the simulation goes on from its current state after a save
+        assert torch.equal(q_now, finals[-1])
+    with pytest.raises(RuntimeError):                      # a fourth save needs a fourth buffer: allocated on demand, so it works...
+        sim.cache_pop(); sim.cache_pop(); sim.cache_pop(); sim.cache_pop()      # ...but a fourth pop has nothing to return
+    assert sim.cache_depth() == 0
+    # forward again (the pops above consumed the stack), save all three, then backward newest first
+    for k, (q0, u, _) in enumerate(eps):
+        sim.reset(torch.tensor(q0), None, backward_flag=True)
+        sim.rollout(torch.tensor(u, device="cuda").transpose(0, 1).contiguous(), S)
+        sim.cache_save()
+    o = OracleSim(m)
+    for k in reversed(range(E)):
+        sim.cache_pop()
+        assert sim.tape_len() == T * S and sim.cache_depth() == k
+        q_now, _ = sim.get_state()
+        assert torch.equal(q_now, finals[k])               # the newest record of episode k is the live state again
+        du = sim.backward_episode(T, S, tile(wq[k]), None, None).cpu().numpy()
+        lq, lv = (x.cpu().numpy() for x in sim.get_adjoint())
+        q0, u, _ = eps[k]
+        for e in range(B):
+            o.reset(q0[e], record=True)
+            for t in range(T):
+                o.forward(u[e, t], S)
+            n = T * S
+            sq = np.zeros((n, 7)); sq[S - 1::S] = wq[k]
+            g = o.backward_steps(n, sq, None, None).reshape(T, S, 6).sum(1)
+            alq, alv = o.adjoint()
+            assert np.abs(du[:, e] - g).max() < 1e-7 * np.abs(g).max(), (k, e)
+            assert np.abs(lq[e] - alq).max() < 1e-7 * max(np.abs(alq).max(), 1e-12)
+            assert np.abs(lv[e] - alv).max() < 1e-7 * max(np.abs(alv).max(), 1e-12)
+    # clear: saved tapes are dropped, pop then fails, the batch keeps working
+    sim.reset(torch.tensor(eps[0][0]), None, backward_flag=True)
+    sim.rollout(torch.tensor(eps[0][1], device="cuda").transpose(0, 1).contiguous(), S)
+    sim.cache_save(); sim.cache_save()
+    assert sim.cache_depth() == 2
+    sim.cache_clear()
+    assert sim.cache_depth() == 0
+    with pytest.raises(RuntimeError):
+        sim.cache_pop()
+    sim.reset(torch.tensor(eps[1][0]), None, backward_flag=True)
+    ro = sim.rollout(torch.tensor(eps[1][1], device="cuda").transpose(0, 1).contiguous(), S)
+    assert torch.equal(ro["q"][-1], finals[1])
+
+
+def test_mis_shaped_inputs_are_rejected(pusher_model):
+    """[dim, B] (or flat) tensors must not be reinterpreted as [B, dim]."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    B = 6
+    sim = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=8)
+    q0, u, _ = push_workload(B, 1, seed=2)
+    with pytest.raises(ValueError):
+        sim.reset(torch.tensor(q0).t().contiguous(), None)
+    sim.reset(torch.tensor(q0), None, backward_flag=True)
+    with pytest.raises(ValueError):
+        sim.step(torch.tensor(u[:, 0]).t().contiguous(), 5)
+    with pytest.raises(ValueError):
+        sim.step(torch.tensor(u[:, 0]).reshape(-1), 5)
+    sim.step(torch.tensor(u[:, 0]), 5)
+    with pytest.raises(ValueError):
+        sim.backward_steps(5, torch.zeros(7, B, dtype=torch.float64))
+    sim.backward_steps(5, torch.zeros(B, 7, dtype=torch.float64))

@@ -7,6 +7,7 @@ import pytest
 import tactilesimulation_amd.model.blob as B
 from tactilesimulation_amd.model import compiler as mc
 from tactilesimulation_amd.model.geometry import mesh_props, cuboid_surface_lattice, cylinder_cap_points, quat_to_R
+from tactilesimulation_amd.workloads import asset
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
@@ -28,7 +29,7 @@ def test_pusher_blob_dimensions(pusher_model):
 def test_blob_roundtrip_and_all_reference_models_load():
     for name, dims in {"pusher": (7, 6, 6, 390), "tactile_pad": (9, 3, 0, 120000), "tactile_insertion": (12, 6, 0, 780),
                        "dclaw_position_control": (10, 9, 12, 2718), "stable_grasp": (12, 6, 0, 780)}.items():
-        m = mc.load_model(os.path.join(HERE, "golden", "models", name + ".npz"))
+        m = mc.load_model(asset(name))
         assert (m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile) == dims
         assert m.I[B.TSIM_IH_MAGIC] == B.TSIM_MAGIC and len(m.I) == m.I[B.TSIM_IH_NI] and len(m.F) == m.I[B.TSIM_IH_NF]
 
@@ -69,9 +70,9 @@ def test_reference_mesh_volumes_known_answers():
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
 def test_fixture_blobs_are_current():
-    """tests/golden/models/*.npz equal a fresh compile of the reference XMLs (tools/make_model_fixtures.py)."""
+    """tactilesimulation_amd/assets/*.npz equal a fresh compile of the reference XMLs (tools/make_model_fixtures.py)."""
     fresh = mc.load_model(os.path.join(REF, "envs/assets/pusher/pusher.xml"))
-    stored = mc.load_model(os.path.join(HERE, "golden", "models", "pusher.npz"))
+    stored = mc.load_model(asset("pusher"))
     assert np.array_equal(fresh.I, stored.I) and np.allclose(fresh.F, stored.F, rtol=0, atol=1e-15)
 
 

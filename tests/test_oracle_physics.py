@@ -11,6 +11,7 @@ import pytest
 
 import tactilesimulation_amd.model.blob as B
 from tactilesimulation_amd.model.compiler import load_model
+from tactilesimulation_amd.workloads import asset
 from oracle.oracle import OracleSim
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -156,7 +157,7 @@ def test_adjoint_matches_finite_differences(name, q0, nu):
 
 def test_newton_matrix_is_exact(pusher_model):
     """Dual-number H = dg/dq1 vs central differences at contact states of the TactilePush model."""
-    from tests.workloads import push_workload
+    from tactilesimulation_amd.workloads import push_workload, asset
     o = OracleSim(pusher_model)
     q0s, us, _ = push_workload(4, 12, seed=3)
     for e in range(4):
@@ -192,7 +193,7 @@ def _rolling_ball_actions():
 def test_rolling_ball_kinematic_known_answer():
     """RollingBall (tactile_pad.xml: BDF2, free3d-exp sphere between ground and pad): a ball rolling without slipping
     between a fixed plane and a moving plate travels HALF the plate's displacement and turns by x / r."""
-    m = load_model(os.path.join(HERE, "golden", "models", "tactile_pad.npz"))
+    m = load_model(asset("tactile_pad"))
     assert (m.ndof_r, m.ndof_u, m.ndof_tactile) == (9, 3, 120000)         # test_sim_speed.py:53-54, 200 x 200 taxels
     o = OracleSim(m)
     o.reset(np.zeros(9))
@@ -207,7 +208,7 @@ def test_rolling_ball_kinematic_known_answer():
 
 
 def test_exponential_joint_newton_matrix_is_exact():
-    m = load_model(os.path.join(HERE, "golden", "models", "tactile_pad.npz"))
+    m = load_model(asset("tactile_pad"))
     o = OracleSim(m)
     o.reset(np.zeros(9))
     A = _rolling_ball_actions()

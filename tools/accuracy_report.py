@@ -11,11 +11,11 @@ sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model  # noqa: E402
 from tactilesimulation_amd.host.batch import BatchSim  # noqa: E402
 from oracle.oracle import OracleSim  # noqa: E402
-from tests.workloads import push_workload  # noqa: E402
+from tactilesimulation_amd.workloads import push_workload  # noqa: E402
 
 
 def report(dtype, B=32, T=40, S=5):
-    m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
     q0, u, _ = push_workload(B, T, seed=2)
     rng = np.random.default_rng(9)
     wq, wv, wt = rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0
@@ -61,7 +61,7 @@ def report(dtype, B=32, T=40, S=5):
 
 
 def phase_cycles(dtype, B=4096):
-    m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
     o = OracleSim(m)
     q0s, us, _ = push_workload(64, 10, seed=4)
     st = []

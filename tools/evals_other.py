@@ -5,7 +5,7 @@ from tactilesimulation_amd.model import blob as B
 from tactilesimulation_amd.host.batch import BatchSim
 from tests.test_gpu_models import _inputs
 for name,S in (("tactile_insertion",5),("dclaw_position_control",5)):
-    m = load_model(os.path.join(ROOT, "tests", "golden", "models", name + ".npz"))
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", name + ".npz"))
     I=m.I
     print(name, {k:int(I[getattr(B,'TSIM_IH_'+k)]) for k in ['NL','NR','NU','NPAIR','NCPT','NSENSOR','NTAXEL']})
     T=14 if 'ins' in name else 10

@@ -10,7 +10,7 @@ from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
 from tactilesimulation_amd.algorithms.batched_gd import Actor, train_epoch, GraphedRollout, train_epoch_graphed
 
 def run(B=4096, T=100, dtype=torch.float32, epochs=3):
-    m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
     env = BatchedTactilePushEnv(m, B, dtype=dtype, gradient=True, seed=0, tape_steps=T)
     torch.manual_seed(0)
     actor = Actor(dtype=dtype).cuda()
@@ -26,7 +26,7 @@ def run(B=4096, T=100, dtype=torch.float32, epochs=3):
 
 def run_graphed(B=4096, T=100, dtype=torch.float32, epochs=3):
     import numpy as np
-    m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
     env = BatchedTactilePushEnv(m, B, dtype=dtype, gradient=True, seed=0, tape_steps=T)
     env.reset()                                               # draws q0 / goal like the eager run (same seed)
     q0, goal = env.q0.clone(), env.goal.clone()

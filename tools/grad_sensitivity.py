@@ -5,9 +5,9 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
-from tests.workloads import push_workload
+from tactilesimulation_amd.workloads import push_workload
 B, T, S = 4096, 100, 5
-m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
 q0, u, _ = push_workload(B, T, seed=0)
 dt = torch.float64
 def grad(q0_, u_):

@@ -1,4 +1,4 @@
-"""Compile the reference's model XMLs into self-contained blobs (tests/golden/models/*.npz).
+"""Compile the reference's model XMLs into self-contained blobs (tactilesimulation_amd/assets/*.npz).
 
 Run in the dev container only (needs /root/reference). The blobs are DATA: flat int/float arrays + a JSON spec in
 which every mesh is reduced to its unit-density mass properties; no reference source text is stored. The GPU box
@@ -21,7 +21,7 @@ MODELS = {
 }
 
 if __name__ == "__main__":
-    out = os.path.join(ROOT, "tests", "golden", "models")
+    out = os.path.join(ROOT, "tactilesimulation_amd", "assets")
     os.makedirs(out, exist_ok=True)
     for name, rel in MODELS.items():
         m = load_model(os.path.join(REF, rel))

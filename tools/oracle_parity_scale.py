@@ -7,11 +7,11 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..")); sys.path.
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
 from oracle.oracle import OracleSim
-from tests.workloads import push_workload
+from tactilesimulation_amd.workloads import push_workload
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T, S = 100, 5
-m = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
 q0, u, _ = push_workload(B, T, seed=17)
 rng = np.random.default_rng(3)
 wq, wv, wt = rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0

@@ -17,7 +17,7 @@ from tests.test_gpu_models import _inputs  # noqa: E402
 
 
 def run(name, B, T, S, dtype=torch.float32, reps=3):
-    m = load_model(os.path.join(ROOT, "tests", "golden", "models", name + ".npz"))
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", name + ".npz"))
     q0, u = _inputs(name, m, 64, T)
     q0 = np.tile(q0, (B // 64, 1)); u = np.tile(u, (B // 64, 1, 1))
     sim = BatchSim(m, B, dtype=dtype, tape_capacity=0)

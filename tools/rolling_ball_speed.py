@@ -17,7 +17,7 @@ from tactilesimulation_amd.model.compiler import load_model  # noqa: E402
 from oracle.oracle import OracleSim  # noqa: E402
 
 acts = np.asarray([[0, 0, .2]] * 100 + [[.1, 0, .2]] * 50 + [[-.2, 0, .2]] * 50 + [[0, .1, .2]] * 50 + [[0, -.2, .2]] * 100, dtype=np.float64)
-m = load_model(os.path.join(ROOT, "tests", "golden", "models", "tactile_pad.npz"))
+m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "tactile_pad.npz"))
 res = {}
 for name, dt in (("gpu_shim_f32", torch.float32), ("gpu_shim_f64", torch.float64)):
     sim = redmax.Simulation(m, dtype=dt)

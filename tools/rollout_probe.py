@@ -5,11 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
-from tests.workloads import push_workload
+from tactilesimulation_amd.workloads import push_workload
 
 def run(B=4096, T=100, S=5, dtype=torch.float32, reps=3):
     dev = torch.device("cuda", 0)
-    model = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+    model = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
     q0_np, u_np, _ = push_workload(B, T, seed=0)
     sim = BatchSim(model, B, device="cuda:0", dtype=dtype, tape_capacity=T * S)
     q0 = torch.tensor(q0_np, device=dev, dtype=dtype)

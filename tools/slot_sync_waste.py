@@ -5,9 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
-from tests.workloads import push_workload
+from tactilesimulation_amd.workloads import push_workload
 B, T, S = 4096, 40, 5
-model = load_model(os.path.join(ROOT, "tests", "golden", "models", "pusher.npz"))
+model = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "pusher.npz"))
 q0_np, u_np, _ = push_workload(B, T, seed=0)
 sim = BatchSim(model, B, dtype=torch.float32, tape_capacity=1)
 sim.reset(torch.tensor(q0_np, device="cuda", dtype=torch.float32), None, backward_flag=False)
