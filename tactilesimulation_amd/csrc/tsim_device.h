@@ -258,7 +258,7 @@ template <int LPE, class R> __device__ __forceinline__ R seg_bcast(R x, int src)
 
 // ------------------------------------------------------------------------------------------------ per-block context
 template <class R> struct Ctx {
-  const int* I; const R* F;               // model records (link / dof / motor / pair / sensor tables): staged in LDS
+  const int* I; const R* F;               // model records (int blob; link / dof / motor / pair / sensor float tables): staged in LDS
   const R* Fg;                            // whole float blob in global memory (taxel SoA arrays; large contact-point arrays)
   const R* CPT;                           // contact-point SoA arrays x[] y[] z[]: LDS copy when small, else global
   int nl, nr, nu, nvar, npair, ncpt, nsensor, ntax, nd;
@@ -283,6 +283,11 @@ template <class R> struct Ctx {
   long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
   mutable int nstamp;
 };
+#ifdef TS_FINE_STAMPS      // A/B builds only (tools/gpu_fine_stamps.sh): extra stamps inside the phases
+#define TS_STAMP2(c) TS_STAMP(c)
+#else
+#define TS_STAMP2(c) do { } while (0)
+#endif
 #define TS_STAMP(c) do { if ((c).stamps) { if (threadIdx.x == 0 && (c).nstamp < 32) (c).stamps[(c).nstamp] = clock64(); (c).nstamp++; } } while (0)
 
 // LDS reals of one environment's state (host and device must agree)
@@ -334,6 +339,13 @@ __device__ __forceinline__ int ts_sched_rec(const int* S) { return TS_SCHED_ENT 
 template <class C> __device__ __forceinline__ const int* ts_pair_rec(const C& c, int pk) {
   return c.LI + ts_sched_rec(c.LI) + c.nl * TS_LR_SIZE + pk * TSIM_PI_SIZE;
 }
+// ... then 16 ints: the motor acting on dof j (-1: none, -2: several — walk the records), and a copy of the motor int
+// records (TSIM_MI_*): the joint-space part of phase 3 and the adjoint's dL/du read them per lane, and a lone wavefront
+// cannot hide the latency of dependent global loads
+template <class C> __device__ __forceinline__ const int* ts_dof_motor(const C& c) {
+  return c.LI + ts_sched_rec(c.LI) + c.nl * TS_LR_SIZE + c.npair * TSIM_PI_SIZE;
+}
+template <class C> __device__ __forceinline__ const int* ts_motor_rec(const C& c, int m) { return ts_dof_motor(c) + 16 + m * TSIM_MI_SIZE; }
 
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
@@ -352,16 +364,21 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
       for (int i = threadIdx.x; i < nst; i += TS_WAVE) mf[i] = F[i];
     }
     lds += ts_tab_reals(nfrec, I[TSIM_IH_NCPT], nslot, Fenv != nullptr, stage_cpt);
-    {                                            // sweep schedule + link int records (one copy per block)
+    {                                            // sweep schedule + the whole int blob (one copy per block)
+      // The int tables are wave-uniform, but loads through a plain global pointer are not scalar loads here (the kernel
+      // also writes global memory, so the compiler issues global_load_dword + s_waitcnt vmcnt(0) + v_readfirstlane): ~400
+      // cycles of exposed latency each for a lone wavefront, a dozen times per evaluation.  From LDS they cost a ds_read.
       const int* S = I + I[TSIM_IH_NI];
-      const int ns = S[0];
+      const int ns = S[0], ni = I[TSIM_IH_NI];
       int* li = reinterpret_cast<int*>(lds);
       for (int i = threadIdx.x; i < ns; i += TS_WAVE) li[i] = S[i];
+      for (int i = threadIdx.x; i < ni; i += TS_WAVE) li[ns + i] = I[i];
       c.LI = li;
-      lds += ((ns * 4 + (int)sizeof(R) - 1) / (int)sizeof(R) + 3) / 4 * 4;
+      c.I = li + ns;
+      lds += (((ns + ni) * 4 + (int)sizeof(R) - 1) / (int)sizeof(R) + 3) / 4 * 4;
     }
     __syncthreads();
-    c.Fg = F; c.F = mf; c.I = I;
+    c.Fg = F; c.F = mf;
     c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt) ? mf : F) + I[TSIM_IH_FOFF_CPT];
     F = mf;
   }

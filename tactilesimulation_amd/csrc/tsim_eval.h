@@ -51,6 +51,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
       PRd = ldm(c.LPd + par * 12); Ppd = ldv(c.LPd + par * 12 + 9); PV = ld6(P + LK_W); PA = ld6(P + LK_AW);
       if (act && par > 0) { const R* Dp = c.DT + (par * nd + k) * DT_SIZE; PdV = ld6(Dp + DT_VW); PdA = ld6(Dp + DT_AW); }
     }
+    TS_STAMP2(c);
     // pose chain in double (Ctx): R0d = joint frame before the joint motion, (XRd, Xpd) = link frame
     const M3<double> R0d = mulMM(PRd, ldm_as<double>(lf + TSIM_LF_R));
     V3<double> Xpd = mulMv(PRd, ldv_as<double>(lf + TSIM_LF_P)) + Ppd;
@@ -148,6 +149,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
         }
       }
     }
+    TS_STAMP2(c);
     const S6<R> V = PV + VJ;
     const S6<R> A = PA + AJ + crm(V, VJ) + Bvec;
     const V3<R> cw = mulMv(XR, ldv(lf + TSIM_LF_COM)) + Xp;
@@ -169,6 +171,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
     Ic[5] = T.m[3] * XR.m[6] + T.m[4] * XR.m[7] + T.m[5] * XR.m[8];
     const R mass = lf[TSIM_LF_MASS];
     const S6<R> h = imul(mass, cw, Ic, V), IA = imul(mass, cw, Ic, A);
+    TS_STAMP2(c);
     if (leader) {
       stm(c.LPd + i * 12, XRd); stv(c.LPd + i * 12 + 9, Xpd);
       stm(X + LK_R, XR); stv(X + LK_P, Xp); st6(X + LK_W, V); st6(X + LK_AW, A); st6(X + LK_FN, IA + crf(V, h));
@@ -178,6 +181,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) if (kk < ndj) st6(c.WP + (k0 + kk) * 6, Wj[kk]);
     }
+    TS_STAMP2(c);
     S6<R> dV = zero6<R>(), dA = zero6<R>();
     if (act) {
       R* D = c.DT + (i * nd + k) * DT_SIZE;
@@ -208,6 +212,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
       st6(D + DT_VW, dV); st6(D + DT_AW, dA); st6(D + DT_FN, dF);
     }
     pRd = XRd; ppd = Xpd; pV = V; pA = A; pdV = dV; pdA = dA; prev = i;
+    TS_STAMP2(c);
   }
   __syncthreads();
 }
@@ -356,6 +361,7 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
       M[0][5] -= F.y; M[1][5] += F.x;
     }
   }
+  TS_STAMP2(c);
   if (!any_hit) return;
 #pragma unroll
   for (int e = 0; e < 6; ++e) {
@@ -363,6 +369,7 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
 #pragma unroll
     for (int j = 0; j < 12; ++j) M[e][j] = seg_sum<LPE>(M[e][j]);
   }
+  TS_STAMP2(c);
   if (lane == 0) {
 #pragma unroll
     for (int e = 0; e < 6; ++e) S[PP_WN + e] = w0[e];
@@ -569,7 +576,7 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
           const S6<R> dW = same_exp ? ld6(c.expw + ((j - k0) * 3 + (k - k0)) * 6) : crm(Wk, Wj);
           dtau += sq * dot6(dW, F);
         }
-        c.H[j * nr + k] = dtau;
+        c.H[j * nr + k] = dtau * h2;                  // columns are stored scaled by 1 / ca (g = r / ca)
         if (k == 0) c.g[j] = dot6(Wj, F);
       }
       if (par > 0) {
@@ -583,33 +590,35 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
     }
   }
   __syncthreads();
-  // joint-space forces: damping, limits (lanes = dofs), then motors
+  TS_STAMP2(c);
+  // joint-space forces: damping, limits, motor (lanes = dofs; the motor of a dof comes from the schedule in LDS), and the
+  // 1 / ca scaling of g and H (each lane scales its own column)
   if (act) {
     const int j = lane;
     const R* df = c.F + c.foff_dof + j * TSIM_DF_SIZE;
-    R gj = c.g[j], hjj = c.H[j * nr + j];
+    R gj = c.g[j], hjj = R(0);                       // hjj: joint-space part of H[j][j], added (scaled) at the end
     gj += df[TSIM_DF_DAMPING] * c.qd[j]; hjj += df[TSIM_DF_DAMPING] * sv;
     if (df[TSIM_DF_LIM_K] > R(0)) {
       if (c.q[j] < df[TSIM_DF_LIM_LO]) { gj -= df[TSIM_DF_LIM_K] * (df[TSIM_DF_LIM_LO] - c.q[j]); hjj += df[TSIM_DF_LIM_K] * sq; }
       else if (c.q[j] > df[TSIM_DF_LIM_HI]) { gj += df[TSIM_DF_LIM_K] * (c.q[j] - df[TSIM_DF_LIM_HI]); hjj += df[TSIM_DF_LIM_K] * sq; }
     }
-    for (int m = 0; m < c.nu; ++m) {
-      const int* mi = c.I + c.off_motor + m * TSIM_MI_SIZE;
-      if (mi[TSIM_MI_DOF] != j) continue;
-      const R* mf = c.F + c.foff_motor + m * TSIM_MF_SIZE;
-      if (mi[TSIM_MI_CTRL] == 0) {
-        R uc = fmin(fmax(c.u[m], R(-1)), R(1));
-        gj -= mf[TSIM_MF_LO] + (uc + R(1)) * (R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]));
-      } else {
-        gj -= mf[TSIM_MF_P] * (c.u[m] - c.q[j]) - mf[TSIM_MF_D] * c.qd[j];
-        hjj += mf[TSIM_MF_P] * sq + mf[TSIM_MF_D] * sv;
+    const int dm = ts_dof_motor(c)[j];
+    for (int m = (dm == -2 ? 0 : dm); m >= 0 && m < c.nu; ++m) {
+      const int* mi = ts_motor_rec(c, m);
+      if (mi[TSIM_MI_DOF] == j) {
+        const R* mf = c.F + c.foff_motor + m * TSIM_MF_SIZE;
+        if (mi[TSIM_MI_CTRL] == 0) {
+          R uc = fmin(fmax(c.u[m], R(-1)), R(1));
+          gj -= mf[TSIM_MF_LO] + (uc + R(1)) * (R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]));
+        } else {
+          gj -= mf[TSIM_MF_P] * (c.u[m] - c.q[j]) - mf[TSIM_MF_D] * c.qd[j];
+          hjj += mf[TSIM_MF_P] * sq + mf[TSIM_MF_D] * sv;
+        }
       }
+      if (dm != -2) break;             // the usual case: exactly one motor on this dof
     }
-    c.g[j] = gj; c.H[j * nr + j] = hjj;
+    c.g[j] = gj * h2; c.H[j * nr + j] += hjj * h2;
   }
-  __syncthreads();
-  for (int e = lane; e < nr * nr; e += LPE) c.H[e] *= h2;
-  if (act) c.g[lane] *= h2;
   __syncthreads();
 }
 
@@ -643,38 +652,58 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
 // Pivot search: 4 DPP steps inside the slot's first 16-lane row; pivot row broadcast: v_readlane (one slot per
 // wavefront) or the LDS crossbar (several).  No LDS memory traffic.
 // Solves A x = b (or A^T x = b), n <= NRM <= 16; x is written only where `write` holds (a per-slot predicate).
+__device__ __forceinline__ double fast_rcp(double x) {          // full double accuracy but for the last bit or two
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 template <class R, int NRM, int LPE, class S = double>
 __device__ __forceinline__ void solve_lanes(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
-  S a[NRM], rb = S(0);
+  // branch-free set-up: every lane loads a valid element (row min(lane, n - 1)) and lanes / columns beyond n are turned into
+  // identity rows by selects
+  // broadcasts inside the slot go through the LDS crossbar in every shape (per-lane source = slot base + row): the
+  // v_readlane form of the one-environment-per-wavefront shape keeps the pivot row in SGPRs, which this kernel has none to spare
+  const int sbase = (int)threadIdx.x & ~(LPE - 1);
+  auto sbc = [sbase](auto v, int src) { return lane_gather(v, sbase + src); };
+  S a[NRM], rb;
+  const bool row = lane < n;
+  const int r = min(lane, n - 1);
 #pragma unroll
   for (int j = 0; j < NRM; ++j) {
-    S v = (j == lane) ? S(1) : S(0);
-    if (lane < n && j < n) v = (S)(transpose ? A[j * n + lane] : A[lane * n + j]);
-    a[j] = v;
+    const int jj = min(j, n - 1);
+    const S v = (S)(transpose ? A[jj * n + r] : A[r * n + jj]);
+    a[j] = (row && j < n) ? v : ((j == lane) ? S(1) : S(0));
   }
-  if (lane < n) rb = (S)b[lane];
-  bool done = false; int mycol = -1; S mypiv = S(1);
+  rb = row ? (S)b[r] : S(0);
+  // Pivot search: one unsigned key per lane = the bit pattern of |a[col]| (monotonic for non-negative floats) with its low four
+  // bits replaced by 15 - lane, so that a 4-step DPP maximum over the slot's first row yields the largest magnitude and, among
+  // magnitudes equal to within 16 ulp, the lowest lane.  Rows already used as pivots (and lanes >= n) carry key 0.
+  bool done = !row; int mycol = -1; S mypiv = S(1);
 #pragma unroll
   for (int col = 0; col < NRM; ++col) {
     if (col < n) {
-      float mag = (!done && lane < n) ? fabsf((float)a[col]) : -1.0f;
-      int idx = lane;
-#define TS_ARGMAX_STEP(CTRL) { float om = dpp_r<CTRL, 0xf>(mag); int oi = dpp_i<CTRL, 0xf>(idx); \
-        if (om > mag || (om == mag && oi < idx)) { mag = om; idx = oi; } }
-      TS_ARGMAX_STEP(0xB1) TS_ARGMAX_STEP(0x4E) TS_ARGMAX_STEP(0x141) TS_ARGMAX_STEP(0x140)
-#undef TS_ARGMAX_STEP
-      const int p = seg_bcast<LPE>(idx, 0);            // the slot's first row holds the matrix rows
-      const S piv = seg_bcast<LPE>(a[col], p);
-      const S f = (lane != p) ? a[col] / piv : S(0);
+      unsigned key = done ? 0u : ((__builtin_bit_cast(unsigned, fabsf((float)a[col])) & ~0xFu) | (unsigned)(15 - (lane & 15)) | 0x10u);
+      key = max(key, (unsigned)dpp_i<0xB1, 0xf>((int)key));
+      key = max(key, (unsigned)dpp_i<0x4E, 0xf>((int)key));
+      key = max(key, (unsigned)dpp_i<0x141, 0xf>((int)key));
+      key = max(key, (unsigned)dpp_i<0x140, 0xf>((int)key));
+      const int p = 15 - (int)(sbc((int)key, 0) & 0xFu);      // the slot's first row holds the matrix rows
+      // the pivot row (entries col.., rhs) travels in ONE batch of broadcasts; the multiplier comes from a reciprocal
+      S prow[NRM];
 #pragma unroll
-      for (int j = 0; j < NRM; ++j) {
-        if (j >= col) { const S pj = seg_bcast<LPE>(a[j], p); a[j] -= f * pj; }
-      }
-      const S pb = seg_bcast<LPE>(rb, p); rb -= f * pb;
-      if (lane == p) { done = true; mycol = col; mypiv = piv; }
+      for (int j = 0; j < NRM; ++j) if (j >= col) prow[j] = sbc(a[j], p);
+      const S pb = sbc(rb, p);
+      const S piv = prow[col];
+      const bool isp = lane == p;
+      const S f = isp ? S(0) : a[col] * fast_rcp(piv);
+#pragma unroll
+      for (int j = 0; j < NRM; ++j) if (j >= col) a[j] -= f * prow[j];
+      rb -= f * pb;
+      done = done || isp; mycol = isp ? col : mycol; mypiv = isp ? piv : mypiv;
     }
   }
-  if (write && lane < n && mycol >= 0) x[mycol] = (R)(rb / mypiv);
+  if (write && row && mycol >= 0) x[mycol] = (R)(rb * fast_rcp(mypiv));
   __syncthreads();
 }
 

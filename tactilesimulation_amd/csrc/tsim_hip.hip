@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
       c.lamv[lane] = c.h * ym;
     }
     if (lane < nu && valid) {
-      const int* mi = c.I + c.off_motor + lane * TSIM_MI_SIZE;
+      const int* mi = ts_motor_rec(c, lane);
       const R* mf = c.F + c.foff_motor + lane * TSIM_MF_SIZE;
       R dtu;
       if (mi[TSIM_MI_CTRL] == 0) dtu = (c.u[lane] >= R(-1) && c.u[lane] <= R(1)) ? R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]) : R(0);
@@ -659,7 +659,8 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
   std::vector<int> leader(links.size(), -1);                 // lowest dof lane of each branch
   for (int k = nr - 1; k >= 0; --k) leader[branch[dof_link[k]]] = k;
   const int npair = I[TSIM_IH_NPAIR], op = I[TSIM_IH_OFF_PAIR];
-  std::vector<int32_t> S(TS_SCHED_ENT + nsteps * 16 + nl * TS_LR_SIZE + npair * TSIM_PI_SIZE, 0);
+  const int nu = I[TSIM_IH_NU], om = I[TSIM_IH_OFF_MOTOR];
+  std::vector<int32_t> S(TS_SCHED_ENT + nsteps * 16 + nl * TS_LR_SIZE + npair * TSIM_PI_SIZE + 16 + nu * TSIM_MI_SIZE, 0);
   S[0] = (int32_t)S.size(); S[1] = nsteps;
   for (int l = 0; l < 16; ++l) S[TS_SCHED_BRANCH + l] = l < nr ? branch[dof_link[l]] : -1;
   for (size_t b = 0; b < links.size() && b < 16; ++b) S[TS_SCHED_LEADER + b] = leader[b];
@@ -677,6 +678,13 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
     r[TS_LR_NDOF] = li[TSIM_LI_NDOF]; r[TS_LR_ANCMASK] = li[TSIM_LI_ANCMASK]; r[TS_LR_BRANCH] = branch[i];
   }
   for (int e = 0; e < npair * TSIM_PI_SIZE; ++e) S[rec0 + nl * TS_LR_SIZE + e] = I[op + e];      // pair int records
+  const int dm0 = rec0 + nl * TS_LR_SIZE + npair * TSIM_PI_SIZE;                                 // dof -> motor, motor int records
+  for (int j = 0; j < 16; ++j) S[dm0 + j] = -1;
+  for (int m = 0; m < nu; ++m) {
+    const int j = I[om + m * TSIM_MI_SIZE + TSIM_MI_DOF];
+    if (j >= 0 && j < 16) S[dm0 + j] = S[dm0 + j] == -1 ? m : -2;
+    for (int e = 0; e < TSIM_MI_SIZE; ++e) S[dm0 + 16 + m * TSIM_MI_SIZE + e] = I[om + m * TSIM_MI_SIZE + e];
+  }
   return S;
 }
 
@@ -727,7 +735,7 @@ template <class R> __global__ void k_get_state(const R* tape_rec, R* q, R* qd, i
 
 // dynamic LDS of a block of nslot environments
 static size_t lds_bytes_for(const tsim_batch* b, int nslot) {
-  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, b->I[TSIM_IH_NCPT], b->stage_cpt != 0, nslot, b->dFenv != nullptr, b->nsched, (int)b->esz);
+  const int reals = ts_lds_reals(b->nl, b->nr, b->nu, b->nfrec, b->I[TSIM_IH_NCPT], b->stage_cpt != 0, nslot, b->dFenv != nullptr, b->nsched + (int)b->I.size(), (int)b->esz);
   return ((size_t)reals * b->esz + 15) / 16 * 16;
 }
 // Launch shape of the forward / backward kernels.

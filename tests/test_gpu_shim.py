@@ -217,7 +217,7 @@ def test_backward_cache_is_a_lifo_of_tapes_depth_3_and_clear(pusher_model):
 def test_mis_shaped_inputs_are_rejected(pusher_model):
     """[dim, B] (or flat) tensors must not be reinterpreted as [B, dim]."""
     from tactilesimulation_amd.host.batch import BatchSim
-    B = 6
+    B = 5                                                  # != ndof_u = 6, ndof_r = 7: a transpose cannot pass by accident
     sim = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=8)
     q0, u, _ = push_workload(B, 1, seed=2)
     with pytest.raises(ValueError):
