@@ -35,8 +35,10 @@ template <class R> __device__ __forceinline__ int rec_u(int nr) { return ts_qw((
 // variables: lanes = end-effector points; tactile: lanes = taxels (coalesced SoA loads of position / frame,
 // 12 B per lane contiguous stores).  Each taxel is evaluated in the frame of the primitive it is tested against.
 template <int LPE, class R>
-__device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool wr, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
-  if (var_out && wr) {
+__device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool wr_var, bool wr, bool has_var, bool has_tac, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
+  // has_var / has_tac are wave-uniform (the loops below contain fences); wr_var / wr are per slot: in k_forward the slots of a
+  // wavefront reach the end of a frame in different rounds, and only those that did write
+  if (has_var && wr_var) {
     for (int e = lane; e < c.nvar; e += LPE) {
       const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
       const V3<R> x = mulMv(ldm(c.LP + l * LK_SIZE + LK_R), ldv(c.F + c.foff_var + e * TSIM_VF_SIZE)) + ldv(c.LP + l * LK_SIZE + LK_P);
@@ -44,7 +46,7 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
       o[0] = x.x; o[1] = x.y; o[2] = x.z;
     }
   }
-  if (!tac_out) return;
+  if (!has_tac) return;
   for (int s = 0; s < c.nsensor; ++s) {
     const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
     const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
@@ -127,6 +129,139 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     c.qdm1[lane] = (R)a.prev[(size_t)env * 2 * nr + nr + lane];
   }
   __syncthreads();
+#ifndef TS_SYNC_SLOTS
+  // A launch covers nframes env-steps (1 for tsim_step).  The slots of a wavefront progress INDEPENDENTLY through their
+  // frames and sub-steps: every round of the loop below is one residual evaluation for every slot at that slot's own
+  // (frame, sub-step, Newton state); a slot whose sub-step has converged commits it and starts the next one in the same
+  // round instead of idling until the other slots of the wavefront have converged too.  (Sub-step-synchronous slots cost a
+  // wavefront the sum over sub-steps of the per-sub-step maximum over its slots: +18 % rounds on the bench workload, and the
+  // slowest wavefront — which is what an episode launch lasts — 378 instead of 335 rounds per 20 env-steps;
+  // profiles/r02_async_slots.md.)  Model-dependent control flow stays wave-uniform; everything per slot is a predicate.
+  int f = 0, s = 0;                              // this slot's frame and sub-step
+  bool alive = a.nframes > 0;                    // this slot still has sub-steps to do
+  R gn = R(0), alpha = R(1);
+  int iter = 0, ls = -1, kicks = 0;              // ls < 0: the evaluation just done is not a line-search trial
+  bool conv = false, forced = false, giving_up = false, deep = false;
+  // start of a sub-step: force-free predictor of the implicit step, the coefficients of qd1, qdd1 in the increment, dl = 0
+  auto begin_substep = [&](bool who) {
+    if (bdf2_model && has_prev) {
+      if (who) { c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h); }
+      if (who && lane < nr) {
+        const double hD = (double)c.h;
+        const double qp = 4.0 / 3 * c.q0D[lane] - 1.0 / 3 * c.qm1D[lane] + hD * (8.0 / 9 * (double)c.qd0[lane] - 2.0 / 9 * (double)c.qdm1[lane]);
+        c.qpD[lane] = qp; c.qp[lane] = (R)qp;
+        c.qdp[lane] = (R)((3.0 * qp - 4.0 * c.q0D[lane] + c.qm1D[lane]) / (2.0 * hD));
+      }
+    } else {
+      if (who) { c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h); }
+      if (who && lane < nr) { c.qpD[lane] = c.q0D[lane] + (double)c.h * (double)c.qd0[lane]; c.qp[lane] = (R)c.qpD[lane]; c.qdp[lane] = c.qd0[lane]; }
+    }
+    if (who && lane < nr) c.dl[lane] = R(0);     // initial guess: the predictor
+    if (who) { gn = R(0); alpha = R(1); iter = 0; ls = -1; kicks = 0; conv = false; forced = false; giving_up = false; deep = false; }
+  };
+  if (alive && lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];       // frame 0
+  begin_substep(alive);
+  __syncthreads();
+  // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
+  // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).  The state is per slot
+  // (identical in all lanes of a slot).
+  // Globalisation: backtracking on ||g||.  ||g|| has non-smooth local minima next to contact /
+  // friction kinks where no short step along the Newton direction reduces it; there the full Newton step is taken
+  // anyway (it lands across the kink, from where the iteration normally converges in two or three steps).  A
+  // sub-step that needs more than TSIM_KICK_MAX such steps (a cycle) is restarted from the predictor with plain
+  // monotone backtracking down to 2^-max_ls, which returns to the last accepted iterate when even that finds no
+  // decrease.
+  while (true) {
+    const R sq = R(1), sv = c.cv, sa = c.ca;
+    evaluate<R, NRM, EXPJ, LPE>(c, lane, sq, sv, sa);
+    const R gnew = block_norm2<LPE>(c.g, nr, lane);
+    bool solve = false, fin = false;
+    if (alive) {
+      ++evals;
+      if (giving_up) { gn = gnew; conv = gn < R(100) * c.tol; fin = true; }      // back at the last accepted iterate
+      else if (ls >= 0 && !forced && !(gnew < gn)) {                             // a rejected line-search trial
+        if (!deep && ls >= min(c.max_ls, TSIM_LS_SHORT)) {
+          if (kicks < TSIM_KICK_MAX) {
+            ++kicks; forced = true;
+            if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+          } else {                           // restart the sub-step, monotone from here on
+            deep = true; iter = 0; ls = -1;
+            if (lane < nr) c.dl[lane] = R(0);
+          }
+        } else if (ls >= c.max_ls) {
+          giving_up = true;
+          if (lane < nr) c.dl[lane] = dlbase[lane];
+        } else {
+          alpha *= R(0.5); ++ls;
+          if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
+        }
+      } else {
+        if (ls >= 0) ++iter;
+        forced = false;
+        gn = gnew;
+        if (!(gn == gn)) { nonfinite = true; fin = true; }
+        else if (gn < c.tol) { conv = true; fin = true; }
+        else if (iter >= c.max_iter) fin = true;
+        else {
+          solve = true;
+          if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
+        }
+      }
+    }
+    __syncthreads();
+    if (__any(solve)) {
+      solve_lanes<R, NRM, LPE, double>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+      if (solve) {
+        alpha = R(1); ls = 0;
+        if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+      }
+      __syncthreads();
+    }
+    // ---- slots whose sub-step is finished commit it: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
+    if (__any(fin)) {
+      if (fin && !conv) ++bad;
+      if (fin && a.record && valid) {
+        R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
+        if (lane < nr) { rec_q(rec)[lane] = c.qD[lane]; rec[rec_qd<R>(nr) + lane] = c.qd[lane]; }
+        for (int e = lane; e < nr * nr; e += LPE) rec[rec_H<R>(nr) + e] = c.H[e];
+        if (lane < nu) rec[rec_u<R>(nr) + lane] = c.u[lane];
+      }
+      __syncthreads();
+      if (fin && lane < nr) {
+        c.qm1[lane] = c.q0[lane]; c.qm1D[lane] = c.q0D[lane]; c.qdm1[lane] = c.qd0[lane];
+        c.q0[lane] = c.q[lane]; c.q0D[lane] = c.qD[lane]; c.qd0[lane] = c.qd[lane];
+      }
+      if (fin) { has_prev = true; ++s; }
+      __syncthreads();
+      const bool frame_end = fin && s == a.nsub;
+      if (__any(frame_end)) {
+        if (frame_end && lane < nr && valid) {
+          const size_t o = ((size_t)f * a.B + env) * nr + lane;
+          if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
+          if (a.qd_out) a.qd_out[o] = c.qd0[lane];
+        }
+        // link poses / velocities in LDS are those of the slot's accepted state (its last evaluation); the other slots take
+        // part with their writes masked (their pair staging records are rebuilt by their next evaluation anyway)
+        int tslot = f;
+        if (a.tac_slot) tslot = frame_end ? a.tac_slot[min(f, a.nframes - 1)] : -1;
+        readout<LPE>(c, lane, env, valid && frame_end, valid && frame_end && tslot >= 0,
+                     a.var_out != nullptr, a.tac_out != nullptr,
+                     a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
+                     a.tac_out ? a.tac_out + (size_t)max(tslot, 0) * a.B * 3 * c.ntax : nullptr);
+        __syncthreads();
+        if (frame_end) {
+          ++f; s = 0;
+          alive = f < a.nframes;
+          if (alive && lane < nu) c.u[lane] = a.u[((size_t)f * a.B + env) * nu + lane];
+        }
+        __syncthreads();
+      }
+      begin_substep(fin && alive);
+      __syncthreads();
+    }
+    if (!__any(alive)) break;
+  }
+#else
   // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
   // environment of the batch between env-steps: Newton stragglers average out over the episode.
   for (int f = 0; f < a.nframes; ++f) {
@@ -232,10 +367,12 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   }
   // link poses / velocities in LDS are those of the accepted state (last evaluation)
   const int tslot = a.tac_slot ? a.tac_slot[f] : f;
-  readout<LPE>(c, lane, env, valid, a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
+  readout<LPE>(c, lane, env, valid, valid && tslot >= 0, a.var_out != nullptr, a.tac_out != nullptr && tslot >= 0,
+               a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
                (a.tac_out && tslot >= 0) ? a.tac_out + (size_t)tslot * a.B * 3 * c.ntax : nullptr);
   __syncthreads();
   }
+#endif
   if (valid) {
     if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1D[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = (double)c.qdm1[lane]; }
     if (!a.record) {
@@ -287,7 +424,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   phase1<R, false, true>(c, lane, R(0), R(0), R(0));
   // high-resolution sensors (RollingBall: 40 000 taxels): blockIdx.y selects a slice of the taxels, so one
   // environment's read-out spreads over many CUs; 12 B/lane contiguous stores, SoA coalesced loads
-  readout<TS_WAVE>(c, lane, env, true, blockIdx.y == 0 ? a.var_out : nullptr, a.tac_out, (int)blockIdx.y * a.slice, ((int)blockIdx.y + 1) * a.slice);
+  readout<TS_WAVE>(c, lane, env, true, true, blockIdx.y == 0 && a.var_out != nullptr, a.tac_out != nullptr, a.var_out, a.tac_out, (int)blockIdx.y * a.slice, ((int)blockIdx.y + 1) * a.slice);
 }
 
 // ================================================================================================ branch signature
