@@ -149,6 +149,11 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
  * environments, and the fraction that differs is reported (tests/test_gpu_configs.py).  Needs reset(backward_flag=True). */
 int tsim_debug_signature(tsim_batch* b, int t_first, int n, uint32_t* out, void* stream);
 
+/* Diagnostics: the adjoint kernels of this batch record shader-clock stamps of the first sub-steps of wavefront 0 in `cycles`
+ * (DEVICE int64[32], zero it first; NULL switches it off): loop top | tape record in LDS | phase 1 | output partials | solve |
+ * contacts (3 stamps per pair group) | projection | mass product. */
+int tsim_debug_stamps(tsim_batch* b, long long* cycles);
+
 /* launch statistics of the most recent kernels (HIP events are the caller's business; this only reports
  * static launch geometry of the forward / backward kernels): out[0] = LDS bytes per block, out[1] = threads per block,
  * out[2] = blocks, out[3] = lanes per environment (64 / 32 / 16: a 64-lane block carries 1 / 2 / 4 environments; chosen

@@ -31,6 +31,16 @@
 #include "../../include/tsim_blob.h"
 
 #define TS_WAVE 64
+// A block of the simulation kernels is ONE wavefront, so a workgroup barrier degenerates to ordering the wavefront's own LDS
+// traffic — which the hardware does anyway (the DS instructions of a wavefront execute in issue order).  TS_SYNC() therefore
+// only stops the COMPILER from moving memory accesses across it.  __syncthreads() would add a workgroup-scope fence, i.e.
+// s_waitcnt vmcnt(0): the lone wavefront then sits out the full latency of every outstanding global store (tape records, outputs)
+// and load at each of the ~20 sync points of an evaluation.  -DTS_REAL_BARRIERS restores __syncthreads() (A/B, debugging).
+#ifdef TS_REAL_BARRIERS
+#define TS_SYNC() __syncthreads()
+#else
+#define TS_SYNC() asm volatile("" ::: "memory")
+#endif
 #define TS_PAIR_GROUP 4      // contact pairs staged in LDS at a time
 // per-link value record in LDS (reals)
 enum { LK_R = 0, LK_P = 9, LK_W = 12, LK_V = 15, LK_AW = 18, LK_AV = 21, LK_FN = 24, LK_FF = 27, LK_C = 30, LK_IC = 33,
@@ -377,7 +387,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
       c.I = li + ns;
       lds += (((ns + ni) * 4 + (int)sizeof(R) - 1) / (int)sizeof(R) + 3) / 4 * 4;
     }
-    __syncthreads();
+    TS_SYNC();
     c.Fg = F; c.F = mf;
     c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt) ? mf : F) + I[TSIM_IH_FOFF_CPT];
     F = mf;

@@ -35,7 +35,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
   pRd = ldm(c.LPd); ppd = zero3<double>(); pV = zero6<R>(); pA = zero6<R>(); pdV = zero6<R>(); pdA = zero6<R>();
   int prev = 0;
   for (int st = 0; st < nsteps; ++st) {
-    __syncthreads();                                 // value records stored by the leaders in the previous step
+    TS_SYNC();                                 // value records stored by the leaders in the previous step
     const int ent = lane < 16 ? S[TS_SCHED_ENT + st * 16 + l16] : 0;
     const int i = ent & 0xff;
     const bool leader = (ent >> 8) != 0;
@@ -214,7 +214,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
     pRd = XRd; ppd = Xpd; pV = V; pA = A; pdV = dV; pdA = dA; prev = i;
     TS_STAMP2(c);
   }
-  __syncthreads();
+  TS_SYNC();
 }
 
 // ================================================================================================ staged pairs
@@ -507,7 +507,7 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
     const int pe = min(p0 + TS_PAIR_GROUP, c.npair), np = pe - p0;
     // lanes = pairs of the group: value records
     if (lane < np && (ts_pair_rec(c, p0 + lane)[TSIM_PI_FLAGS] & 1)) pair_stage_value(c, p0 + lane, lane, true);
-    __syncthreads();
+    TS_SYNC();
     TS_STAMP(c);
     // lanes = (pair, direction): per-direction records
     {
@@ -523,15 +523,15 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
         }
       }
     }
-    __syncthreads();
+    TS_SYNC();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
-    __syncthreads();
+    TS_SYNC();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = directions; serial over pairs: two pairs may touch the same link
       if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_fold(c, pk, pk - p0, lane, sq);
-    __syncthreads();
+    TS_SYNC();
   }
 }
 
@@ -559,7 +559,7 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
     S6<R> cF = zero6<R>(), cdF = zero6<R>();
     int carry_to = -1;
     for (int st = nsteps - 1; st >= 0; --st) {
-      __syncthreads();                               // wrenches folded into branching parents in the previous step
+      TS_SYNC();                               // wrenches folded into branching parents in the previous step
       const int i = has ? (S[TS_SCHED_ENT + st * 16 + col] & 0xff) : 0;
       if (i == 0) continue;
       const int* li = S + rec0 + (i - 1) * TS_LR_SIZE;
@@ -589,7 +589,7 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
       }
     }
   }
-  __syncthreads();
+  TS_SYNC();
   TS_STAMP2(c);
   // joint-space forces: damping, limits, motor (lanes = dofs; the motor of a dof comes from the schedule in LDS), and the
   // 1 / ca scaling of g and H (each lane scales its own column)
@@ -619,7 +619,7 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
     }
     c.g[j] = gj * h2; c.H[j * nr + j] += hjj * h2;
   }
-  __syncthreads();
+  TS_SYNC();
 }
 
 // full evaluation at the trial increment held in c.dl (with c.q0, c.qd0, c.u): fills c.q, c.qd, c.qa, link state, g, H.
@@ -636,7 +636,7 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
     c.q[lane] = c.qp[lane] + d;
     c.qD[lane] = c.qpD[lane] + (double)d;
   }
-  __syncthreads();
+  TS_SYNC();
   TS_STAMP(c);
   phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
   TS_STAMP(c);
@@ -704,7 +704,7 @@ __device__ __forceinline__ void solve_lanes(const R* A, const R* b, R* x, int n,
     }
   }
   if (write && row && mycol >= 0) x[mycol] = (R)(rb * fast_rcp(mypiv));
-  __syncthreads();
+  TS_SYNC();
 }
 
 template <int LPE, class R> __device__ __forceinline__ R block_norm2(const R* v, int n, int lane) {

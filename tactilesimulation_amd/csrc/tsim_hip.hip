@@ -53,9 +53,9 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
     const int t0 = si[TSIM_SI_TAX0], nt = si[TSIM_SI_NTAX], sp0 = si[TSIM_SI_SPRIM0], nsp = si[TSIM_SI_NSPRIM];
     for (int j0 = 0; j0 < nsp || j0 == 0; j0 += TS_PAIR_GROUP) {
       const int je = min(j0 + TS_PAIR_GROUP, nsp);
-      __syncthreads();
+      TS_SYNC();
       for (int j = j0; j < je; ++j) pair_stage_value(c, c.I[c.off_sprim + sp0 + j], j - j0, lane == 0);
-      __syncthreads();
+      TS_SYNC();
       // this block's slice [tb, te) of the global taxel range, intersected with the sensor
       const int lo = max(tb, t0) - t0, hi = min(te, t0 + nt) - t0;
       for (int base = lo; base < hi; base += LPE) {
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
     if (lane < nr) { c.q0D[lane] = rec_q(st)[lane]; c.q0[lane] = (R)c.q0D[lane]; c.qd0[lane] = st[rec_qd<R>(nr) + lane]; }
   }
-  __syncthreads();
+  TS_SYNC();
   R* dlbase = c.dq + nr;
   int bad = 0; bool nonfinite = false;
   int evals = 0;
@@ -128,145 +128,12 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     c.qm1D[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qm1[lane] = (R)c.qm1D[lane];
     c.qdm1[lane] = (R)a.prev[(size_t)env * 2 * nr + nr + lane];
   }
-  __syncthreads();
-#ifndef TS_SYNC_SLOTS
-  // A launch covers nframes env-steps (1 for tsim_step).  The slots of a wavefront progress INDEPENDENTLY through their
-  // frames and sub-steps: every round of the loop below is one residual evaluation for every slot at that slot's own
-  // (frame, sub-step, Newton state); a slot whose sub-step has converged commits it and starts the next one in the same
-  // round instead of idling until the other slots of the wavefront have converged too.  (Sub-step-synchronous slots cost a
-  // wavefront the sum over sub-steps of the per-sub-step maximum over its slots: +18 % rounds on the bench workload, and the
-  // slowest wavefront — which is what an episode launch lasts — 378 instead of 335 rounds per 20 env-steps;
-  // profiles/r02_async_slots.md.)  Model-dependent control flow stays wave-uniform; everything per slot is a predicate.
-  int f = 0, s = 0;                              // this slot's frame and sub-step
-  bool alive = a.nframes > 0;                    // this slot still has sub-steps to do
-  R gn = R(0), alpha = R(1);
-  int iter = 0, ls = -1, kicks = 0;              // ls < 0: the evaluation just done is not a line-search trial
-  bool conv = false, forced = false, giving_up = false, deep = false;
-  // start of a sub-step: force-free predictor of the implicit step, the coefficients of qd1, qdd1 in the increment, dl = 0
-  auto begin_substep = [&](bool who) {
-    if (bdf2_model && has_prev) {
-      if (who) { c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h); }
-      if (who && lane < nr) {
-        const double hD = (double)c.h;
-        const double qp = 4.0 / 3 * c.q0D[lane] - 1.0 / 3 * c.qm1D[lane] + hD * (8.0 / 9 * (double)c.qd0[lane] - 2.0 / 9 * (double)c.qdm1[lane]);
-        c.qpD[lane] = qp; c.qp[lane] = (R)qp;
-        c.qdp[lane] = (R)((3.0 * qp - 4.0 * c.q0D[lane] + c.qm1D[lane]) / (2.0 * hD));
-      }
-    } else {
-      if (who) { c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h); }
-      if (who && lane < nr) { c.qpD[lane] = c.q0D[lane] + (double)c.h * (double)c.qd0[lane]; c.qp[lane] = (R)c.qpD[lane]; c.qdp[lane] = c.qd0[lane]; }
-    }
-    if (who && lane < nr) c.dl[lane] = R(0);     // initial guess: the predictor
-    if (who) { gn = R(0); alpha = R(1); iter = 0; ls = -1; kicks = 0; conv = false; forced = false; giving_up = false; deep = false; }
-  };
-  if (alive && lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];       // frame 0
-  begin_substep(alive);
-  __syncthreads();
-  // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
-  // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).  The state is per slot
-  // (identical in all lanes of a slot).
-  // Globalisation: backtracking on ||g||.  ||g|| has non-smooth local minima next to contact /
-  // friction kinks where no short step along the Newton direction reduces it; there the full Newton step is taken
-  // anyway (it lands across the kink, from where the iteration normally converges in two or three steps).  A
-  // sub-step that needs more than TSIM_KICK_MAX such steps (a cycle) is restarted from the predictor with plain
-  // monotone backtracking down to 2^-max_ls, which returns to the last accepted iterate when even that finds no
-  // decrease.
-  while (true) {
-    const R sq = R(1), sv = c.cv, sa = c.ca;
-    evaluate<R, NRM, EXPJ, LPE>(c, lane, sq, sv, sa);
-    const R gnew = block_norm2<LPE>(c.g, nr, lane);
-    bool solve = false, fin = false;
-    if (alive) {
-      ++evals;
-      if (giving_up) { gn = gnew; conv = gn < R(100) * c.tol; fin = true; }      // back at the last accepted iterate
-      else if (ls >= 0 && !forced && !(gnew < gn)) {                             // a rejected line-search trial
-        if (!deep && ls >= min(c.max_ls, TSIM_LS_SHORT)) {
-          if (kicks < TSIM_KICK_MAX) {
-            ++kicks; forced = true;
-            if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-          } else {                           // restart the sub-step, monotone from here on
-            deep = true; iter = 0; ls = -1;
-            if (lane < nr) c.dl[lane] = R(0);
-          }
-        } else if (ls >= c.max_ls) {
-          giving_up = true;
-          if (lane < nr) c.dl[lane] = dlbase[lane];
-        } else {
-          alpha *= R(0.5); ++ls;
-          if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
-        }
-      } else {
-        if (ls >= 0) ++iter;
-        forced = false;
-        gn = gnew;
-        if (!(gn == gn)) { nonfinite = true; fin = true; }
-        else if (gn < c.tol) { conv = true; fin = true; }
-        else if (iter >= c.max_iter) fin = true;
-        else {
-          solve = true;
-          if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
-        }
-      }
-    }
-    __syncthreads();
-    if (__any(solve)) {
-      solve_lanes<R, NRM, LPE, double>(c.H, c.rhs, c.dq, nr, false, lane, solve);
-      if (solve) {
-        alpha = R(1); ls = 0;
-        if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-      }
-      __syncthreads();
-    }
-    // ---- slots whose sub-step is finished commit it: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
-    if (__any(fin)) {
-      if (fin && !conv) ++bad;
-      if (fin && a.record && valid) {
-        R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
-        if (lane < nr) { rec_q(rec)[lane] = c.qD[lane]; rec[rec_qd<R>(nr) + lane] = c.qd[lane]; }
-        for (int e = lane; e < nr * nr; e += LPE) rec[rec_H<R>(nr) + e] = c.H[e];
-        if (lane < nu) rec[rec_u<R>(nr) + lane] = c.u[lane];
-      }
-      __syncthreads();
-      if (fin && lane < nr) {
-        c.qm1[lane] = c.q0[lane]; c.qm1D[lane] = c.q0D[lane]; c.qdm1[lane] = c.qd0[lane];
-        c.q0[lane] = c.q[lane]; c.q0D[lane] = c.qD[lane]; c.qd0[lane] = c.qd[lane];
-      }
-      if (fin) { has_prev = true; ++s; }
-      __syncthreads();
-      const bool frame_end = fin && s == a.nsub;
-      if (__any(frame_end)) {
-        if (frame_end && lane < nr && valid) {
-          const size_t o = ((size_t)f * a.B + env) * nr + lane;
-          if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
-          if (a.qd_out) a.qd_out[o] = c.qd0[lane];
-        }
-        // link poses / velocities in LDS are those of the slot's accepted state (its last evaluation); the other slots take
-        // part with their writes masked (their pair staging records are rebuilt by their next evaluation anyway)
-        int tslot = f;
-        if (a.tac_slot) tslot = frame_end ? a.tac_slot[min(f, a.nframes - 1)] : -1;
-        readout<LPE>(c, lane, env, valid && frame_end, valid && frame_end && tslot >= 0,
-                     a.var_out != nullptr, a.tac_out != nullptr,
-                     a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
-                     a.tac_out ? a.tac_out + (size_t)max(tslot, 0) * a.B * 3 * c.ntax : nullptr);
-        __syncthreads();
-        if (frame_end) {
-          ++f; s = 0;
-          alive = f < a.nframes;
-          if (alive && lane < nu) c.u[lane] = a.u[((size_t)f * a.B + env) * nu + lane];
-        }
-        __syncthreads();
-      }
-      begin_substep(fin && alive);
-      __syncthreads();
-    }
-    if (!__any(alive)) break;
-  }
-#else
+  TS_SYNC();
   // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
   // environment of the batch between env-steps: Newton stragglers average out over the episode.
   for (int f = 0; f < a.nframes; ++f) {
   if (lane < nu) c.u[lane] = a.u[((size_t)f * a.B + env) * nu + lane];
-  __syncthreads();
+  TS_SYNC();
   for (int s = 0; s < a.nsub; ++s) {
     // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment
     if (bdf2_model && has_prev) {
@@ -283,7 +150,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     }
     const R sq = R(1), sv = c.cv, sa = c.ca;
     if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
-    __syncthreads();
+    TS_SYNC();
     // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
     // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).  The state is per slot
     // (identical in all lanes of a slot); a slot that has finished its sub-step keeps evaluating at its final iterate
@@ -333,14 +200,14 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
           }
         }
       }
-      __syncthreads();
+      TS_SYNC();
       if (__any(solve)) {
         solve_lanes<R, NRM, LPE, double>(c.H, c.rhs, c.dq, nr, false, lane, solve);
         if (solve) {
           alpha = R(1); ls = 0;
           if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
         }
-        __syncthreads();
+        TS_SYNC();
       }
       if (__all(fin)) break;
     }
@@ -352,13 +219,13 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
       for (int e = lane; e < nr * nr; e += LPE) rec[rec_H<R>(nr) + e] = c.H[e];
       if (lane < nu) rec[rec_u<R>(nr) + lane] = c.u[lane];
     }
-    __syncthreads();
+    TS_SYNC();
     if (lane < nr) {
       c.qm1[lane] = c.q0[lane]; c.qm1D[lane] = c.q0D[lane]; c.qdm1[lane] = c.qd0[lane];
       c.q0[lane] = c.q[lane]; c.q0D[lane] = c.qD[lane]; c.qd0[lane] = c.qd[lane];
     }
     has_prev = true;
-    __syncthreads();
+    TS_SYNC();
   }
   if (lane < nr && valid) {
     const size_t o = ((size_t)f * a.B + env) * nr + lane;
@@ -370,9 +237,8 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   readout<LPE>(c, lane, env, valid, valid && tslot >= 0, a.var_out != nullptr, a.tac_out != nullptr && tslot >= 0,
                a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
                (a.tac_out && tslot >= 0) ? a.tac_out + (size_t)tslot * a.B * 3 * c.ntax : nullptr);
-  __syncthreads();
+  TS_SYNC();
   }
-#endif
   if (valid) {
     if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1D[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = (double)c.qdm1[lane]; }
     if (!a.record) {
@@ -420,7 +286,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   init_world(c, lane, TS_WAVE);
   const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
   if (lane < nr) { c.qD[lane] = rec_q(st)[lane]; c.q[lane] = (R)c.qD[lane]; c.qd[lane] = st[rec_qd<R>(nr) + lane]; c.qa[lane] = R(0); }
-  __syncthreads();
+  TS_SYNC();
   phase1<R, false, true>(c, lane, R(0), R(0), R(0));
   // high-resolution sensors (RollingBall: 40 000 taxels): blockIdx.y selects a slice of the taxels, so one
   // environment's read-out spreads over many CUs; 12 B/lane contiguous stores, SoA coalesced loads
@@ -450,18 +316,18 @@ __global__ void __launch_bounds__(TS_WAVE) k_signature(SigArgs<R> a) {
   init_world(c, lane, TS_WAVE);
   for (int j = 0; j < a.n; ++j) {
     const R* st = a.tape + ((size_t)(a.t_first + 1 + j) * a.B + env) * REC;
-    __syncthreads();
+    TS_SYNC();
     if (lane < nr) { c.qD[lane] = rec_q(st)[lane]; c.q[lane] = (R)c.qD[lane]; c.qd[lane] = st[rec_qd<R>(nr) + lane]; c.qa[lane] = R(0); }
-    __syncthreads();
+    TS_SYNC();
     phase1<R, false, true>(c, lane, R(0), R(0), R(0));
     unsigned cnt = 0, sum = 0;
     for (int pk = 0; pk < c.npair; ++pk) {                     // dynamics-active contact pairs
       const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
       if (!(pi[TSIM_PI_FLAGS] & 1)) continue;
       const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-      __syncthreads();
+      TS_SYNC();
       pair_stage_value(c, pk, 0, lane == 0);
-      __syncthreads();
+      TS_SYNC();
       const R* S = c.PP;
       const M3<double> RPAd = ldm(c.PPd); const V3<double> pPAd = ldv(c.PPd + 9);
       const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
@@ -483,9 +349,9 @@ __global__ void __launch_bounds__(TS_WAVE) k_signature(SigArgs<R> a) {
         const int pk = c.I[c.off_sprim + si[TSIM_SI_SPRIM0] + jp];
         const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
         const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-        __syncthreads();
+        TS_SYNC();
         pair_stage_value(c, pk, 0, lane == 0);
-        __syncthreads();
+        TS_SYNC();
         const R* S = c.PP;
         const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
         for (int i = lane; i < si[TSIM_SI_NTAX]; i += TS_WAVE) {
@@ -525,13 +391,13 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
     c.qpD[lane] = (double)a.q1[(size_t)env * nr + lane] - (double)c.dl[lane];      // so that qD = qpD + dl is the given q1
   }
   if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
-  __syncthreads();
+  TS_SYNC();
   if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve; one row
                  // per wavefront (the row of its first environment), the other rows stay zero
     c.stamps = a.cyc + (size_t)env * 32;
     evaluate<R, 8, false, LPE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
     if (lane < nr) c.rhs[lane] = -c.g[lane];
-    __syncthreads();
+    TS_SYNC();
     solve_lanes<R, 8, LPE>(c.H, c.rhs, c.dq, nr, false, lane);
     TS_STAMP(c);
     if (lane == 0 && valid) for (int i = (slot == 0 ? c.nstamp : 0); i < 32; ++i) c.stamps[i] = 0;
@@ -554,22 +420,32 @@ template <class R> struct BwdArgs {
   const R *df_dq, *df_dvar, *df_dtac;
   R *lamq, *lamv, *df_du;
   int stage_cpt;
+  long long* cyc;         // diagnostics: shader-clock stamps of the first sub-steps of wavefront 0 (tsim_debug_stamps), or null
 };
 
-// (M z)_j for lane j: direct sums over the links below dof j (no recursion, no scratch)
-template <class R>
-__device__ __forceinline__ R mass_times_z(const Ctx<R>& c, int j) {
-  R tau = R(0);
-  const S6<R> Wj = ld6(c.WP + j * 6);
-  for (int i = 1; i <= c.nl; ++i) {
-    const int anc = c.I[c.off_link + (i - 1) * TSIM_LI_SIZE + TSIM_LI_ANCMASK];
-    if (!((anc >> j) & 1)) continue;
+// (M z)_j for lane j, M = sum_i J_i^T I_i J_i:  lanes = links form f_i = I_i (sum_{k above i} W_k z_k) in the (idle) pair-staging
+// scratch, then lanes = dofs add up W_j . f_i over the links below dof j.  (The direct double loop per lane was ~600
+// instructions, a tenth of an adjoint sub-step.)
+template <int LPE, class R>
+__device__ __forceinline__ R mass_times_z(const Ctx<R>& c, int lane) {
+  const int* LR = c.LI + ts_sched_rec(c.LI);
+  R* fi = c.PT;                                    // [nl + 1][6], free between phase 2 and the next staging
+  for (int i = 1 + lane; i <= c.nl; i += LPE) {
+    const int anc = LR[(i - 1) * TS_LR_SIZE + TS_LR_ANCMASK];
     S6<R> A = zero6<R>();
     for (int k = 0; k < c.nr; ++k)
       if ((anc >> k) & 1) A = A + ld6(c.WP + k * 6) * c.z[k];
     const R* X = c.LP + i * LK_SIZE;
-    tau += dot6(Wj, imul(c.F[c.foff_link + (i - 1) * TSIM_LF_SIZE + TSIM_LF_MASS], ldv(X + LK_C), X + LK_IC, A));
+    st6(fi + i * 6, imul(c.F[c.foff_link + (i - 1) * TSIM_LF_SIZE + TSIM_LF_MASS], ldv(X + LK_C), X + LK_IC, A));
   }
+  TS_SYNC();
+  R tau = R(0);
+  if (lane < c.nr) {
+    const S6<R> Wj = ld6(c.WP + lane * 6);
+    for (int i = 1; i <= c.nl; ++i)
+      if ((LR[(i - 1) * TS_LR_SIZE + TS_LR_ANCMASK] >> lane) & 1) tau += dot6(Wj, ld6(fi + i * 6));
+  }
+  TS_SYNC();
   return tau;
 }
 
@@ -592,7 +468,7 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
     }
     c.lamq[lane] += acc;
   }
-  __syncthreads();
+  TS_SYNC();
   if (!wtac) return;
   for (int s = 0; s < c.nsensor; ++s) {
     const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
@@ -602,9 +478,9 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
       const int pk = c.I[c.off_sprim + sp0 + j];
       const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
       const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-      __syncthreads();
+      TS_SYNC();
       pair_stage_value(c, pk, 0, lane == 0);
-      __syncthreads();
+      TS_SYNC();
       const R* S = c.PP;
       const M3<R> RPA = ldm(S + PP_RPA);
       const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
@@ -663,7 +539,7 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
       }
     }
   }
-  __syncthreads();
+  TS_SYNC();
 }
 
 template <class R, int NRM, bool EXPJ, int LPE>
@@ -679,23 +555,49 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
   R* H2 = c.H2;    // taped Newton matrix of the sub-step
   init_world(c, lane, LPE);
+  if (a.cyc && blockIdx.x == 0) c.stamps = a.cyc;
   if (lane < nr) { c.lamq[lane] = a.lamq[(size_t)env * nr + lane]; c.lamv[lane] = a.lamv[(size_t)env * nr + lane]; }
-  __syncthreads();
+  TS_SYNC();
   R du_frame = R(0);
+  // The tape record of sub-step t (q1, qd1, u, H) and the state before it (q, qd of record t - 1) are fetched ONE ITERATION AHEAD
+  // into registers: a lone wavefront cannot hide the ~2 x 1.5 k cycles of HBM latency of dependent loads at the top of every
+  // sub-step, but the loads for the next sub-step fly during the whole of this one.  (Record t - 1 supplies q0, qd0 now and
+  // q1, qd1 of the next iteration, so each iteration fetches u, H of record t - 1 and q, qd of record t - 2.)
+  constexpr int NHL = (NRM * NRM + LPE - 1) / LPE;
+  const int oqd = rec_qd<R>(nr), oH = rec_H<R>(nr), ou = rec_u<R>(nr);
+  double pq1 = 0.0, pq0 = 0.0; R pqd1 = R(0), pqd0 = R(0), pu = R(0), pH[NHL];
+  {
+    const R* r1 = a.tape + ((size_t)a.t_end * a.B + env) * REC;
+    const R* r0 = a.tape + ((size_t)(a.t_end - 1) * a.B + env) * REC;
+    if (lane < nr) { pq1 = rec_q(r1)[lane]; pqd1 = r1[oqd + lane]; pq0 = rec_q(r0)[lane]; pqd0 = r0[oqd + lane]; }
+    if (lane < nu) pu = r1[ou + lane];
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; pH[i] = e < nr * nr ? r1[oH + e] : R(0); }
+  }
   for (int j = a.n - 1; j >= 0; --j) {
     const int t = a.t_end - (a.n - 1 - j);
-    const R* r1 = a.tape + ((size_t)t * a.B + env) * REC;
-    const R* r0 = a.tape + ((size_t)(t - 1) * a.B + env) * REC;
     if (lane < nr) {
-      const int oqd = rec_qd<R>(nr);
-      c.qD[lane] = rec_q(r1)[lane]; c.q[lane] = (R)c.qD[lane]; c.q0[lane] = (R)rec_q(r0)[lane]; c.qd0[lane] = r0[oqd + lane];
-      c.qd[lane] = r1[oqd + lane];                              // taped (q1 - q0)/h
-      c.qa[lane] = (r1[oqd + lane] - r0[oqd + lane]) / c.h;     // discrete acceleration, no position cancellation
+      c.qD[lane] = pq1; c.q[lane] = (R)pq1; c.q0[lane] = (R)pq0; c.qd0[lane] = pqd0;
+      c.qd[lane] = pqd1;                              // taped (q1 - q0)/h
+      c.qa[lane] = (pqd1 - pqd0) / c.h;               // discrete acceleration, no position cancellation
     }
-    if (lane < nu) c.u[lane] = r1[rec_u<R>(nr) + lane];
-    for (int e = lane; e < nr * nr; e += LPE) H2[e] = r1[rec_H<R>(nr) + e];
-    __syncthreads();
+    if (lane < nu) c.u[lane] = pu;
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; if (e < nr * nr) H2[e] = pH[i]; }
+    TS_STAMP(c);
+    if (j > 0) {                                      // next iteration: sub-step t - 1
+      const R* r1 = a.tape + ((size_t)(t - 1) * a.B + env) * REC;
+      const R* r0 = a.tape + ((size_t)(t - 2) * a.B + env) * REC;
+      pq1 = pq0; pqd1 = pqd0;
+      if (lane < nr) { pq0 = rec_q(r0)[lane]; pqd0 = r0[oqd + lane]; }
+      if (lane < nu) pu = r1[ou + lane];
+#pragma unroll
+      for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; pH[i] = e < nr * nr ? r1[oH + e] : R(0); }
+    }
+    TS_SYNC();
+    TS_STAMP(c);
     phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
+    TS_STAMP(c);
     // direct partials of the loss w.r.t. this sub-step's outputs
     const bool seeded = (j + 1) % a.seed_stride == 0;
     if (seeded) {
@@ -704,19 +606,24 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
       const int tslot = (a.frames && a.tac_slot) ? a.tac_slot[fr] : 0;
       const size_t sot = (a.frames && a.tac_slot) ? (size_t)max(tslot, 0) * a.B + env : so;
       if (a.df_dq && lane < nr) c.lamq[lane] += a.df_dq[so * nr + lane];
-      __syncthreads();
+      TS_SYNC();
       output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr,
                       (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr);
     }
+    TS_STAMP(c);
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.lamv[lane] / c.h;
-    __syncthreads();
+    TS_SYNC();
     solve_lanes<R, NRM, LPE>(H2, c.rhs, c.z, nr, true, lane);
+    TS_STAMP(c);
     phase2<R, NRM, LPE>(c, lane, R(1));
+    TS_STAMP(c);
     phase3<R, EXPJ, LPE>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
+    TS_STAMP(c);
+    const R ym = mass_times_z<LPE>(c, lane);
+    TS_STAMP(c);
     if (lane < nr) {
       R yq = R(0);
       for (int i = 0; i < nr; ++i) yq += c.z[i] * c.H[i * nr + lane];
-      const R ym = mass_times_z(c, lane);
       c.lamq[lane] -= yq;
       c.lamv[lane] = c.h * ym;
     }
@@ -733,7 +640,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
         if (j % a.seed_stride == 0) { a.df_du[((size_t)(j / a.seed_stride) * a.B + env) * nu + lane] = du_frame; du_frame = R(0); }
       }
     }
-    __syncthreads();
+    TS_SYNC();
   }
   if (lane < nr && valid) { a.lamq[(size_t)env * nr + lane] = c.lamq[lane]; a.lamv[(size_t)env * nr + lane] = c.lamv[lane]; }
 }
@@ -776,6 +683,7 @@ struct tsim_batch {
   size_t esz;
   std::vector<CacheEntry> cache;   // saved tapes, newest last
   std::vector<void*> pool;          // spare tape buffers
+  long long* bwd_stamps = nullptr;  // diagnostics (tsim_debug_stamps)
 };
 
 // sweep schedule of the link tree (layout: ts_sched in tsim_device.h)
@@ -946,7 +854,7 @@ static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, co
   BwdArgs<R> a;
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames; a.tac_slot = tac_slot;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
-  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt;
+  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = b->bwd_stamps;
   TS_LAUNCH(k_backward, R, b, st, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1253,6 +1161,8 @@ int tsim_debug_signature(tsim_batch* b, int t_first, int n, uint32_t* out, void*
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+int tsim_debug_stamps(tsim_batch* b, long long* cycles) { b->bwd_stamps = cycles; return 0; }
 
 int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* qd0, const void* u, void* g_out, void* H_out, long long* cycles, void* stream) {
   TS_DEVICE(b);

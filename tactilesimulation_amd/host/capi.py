@@ -33,6 +33,7 @@ _SIGS = {
     "tsim_cache_reserve": (C.c_int, [_vp, C.c_int]), "tsim_cache_depth": (C.c_int, [_vp]),
     "tsim_debug_signature": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "tsim_debug_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_debug_stamps": (C.c_int, [_vp, _vp]),
     "tsim_launch_info": (C.c_int, [_vp, _ip]),
     "tsim_set_lanes_per_env": (C.c_int, [_vp, C.c_int]),
     "tsim_last_evals": (C.c_int, [_vp, _ip]),
