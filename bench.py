@@ -395,7 +395,9 @@ def fill_roofline_counters(rl, c, src, B, frames, kernel_ms):
     valu = c["SQ_INSTS_VALU"]                                   # wave-level VALU instructions of the launch
     f32 = c["SQ_INSTS_VALU_ADD_F32"] + c["SQ_INSTS_VALU_MUL_F32"] + 2.0 * c["SQ_INSTS_VALU_FMA_F32"]
     f64 = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2.0 * c["SQ_INSTS_VALU_FMA_F64"]
-    lanes = c["SQ_THREAD_CYCLES_VALU"] / max(4.0 * c["SQ_ACTIVE_INST_VALU"], 1.0) / 64.0     # mean fraction of the 64 lanes active in a VALU instruction
+    # mean fraction of the 64 lanes active in a VALU instruction: SQ_THREAD_CYCLES_VALU counts active lanes per instruction (a
+    # full-lane elementwise kernel reads exactly 64 per SQ_INSTS_VALU: profiles/r02_pmc_calibration.json)
+    lanes = c["SQ_THREAD_CYCLES_VALU"] / max(64.0 * c["SQ_INSTS_VALU"], 1.0)
     flops = 64.0 * lanes * (f32 + f64)                          # lane-level flops (FMA = 2), idle lanes not counted
     rl["valu"] = {
         "source": src,

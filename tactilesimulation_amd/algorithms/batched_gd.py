@@ -60,8 +60,12 @@ class GraphedRollout:
         torch.cuda.current_stream().wait_stream(side)
         for p in actor.parameters():
             p.grad = None
+        # Capture on the SAME side stream the warm-up ran on: the parameters' AccumulateGrad nodes were created there, and a
+        # capture on another stream makes autograd fork the gradient accumulation onto the warm-up stream inside the graph —
+        # replays with new episode data then read gradient buffers before that branch has written them (garbage policy
+        # gradients of 1e16 ... 1e24 at B = 4096, profiles/r02_graphed_rollout_fix.md; replays of unchanged data hid it).
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = rollout_loss(env, actor, horizon, q0=q0, goal=goal, disturbances=disturbances)
             self.loss.backward()
 

@@ -752,6 +752,21 @@ static int upload_model(tsim_batch* b, hipStream_t st) {
   return 0;
 }
 
+// Zero-fill by a plain kernel.  hipMemsetAsync nodes did NOT reliably take effect when a captured HIP graph was replayed
+// (the carried adjoint kept the previous episode's final value at B >= 2048: policy gradients of 1e16 ... NaN in the graphed GD
+// loop as soon as an episode's data changed; profiles/r02_graphed_rollout_fix.md) — a kernel node does.
+__global__ void k_zero_words(uint32_t* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static int zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;                       // all buffers zeroed here hold 4- or 8-byte reals
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // scatter [B][nr] q / qd into tape record 0
 template <class R> __global__ void k_set_state(R* tape, const R* q, const R* qd, int B, int nr, int rec) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -990,8 +1005,7 @@ int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag
   if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_set_state<float>, dim3(grd), dim3(blk), 0, st, (float*)b->tape, (const float*)q0, (const float*)qd0, b->B, b->nr, b->rec);
   else hipLaunchKernelGGL(k_set_state<double>, dim3(grd), dim3(blk), 0, st, (double*)b->tape, (const double*)q0, (const double*)qd0, b->B, b->nr, b->rec);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(b->lamq, 0, (size_t)b->B * b->nr * b->esz, st));
-  HIPCHK(hipMemsetAsync(b->lamv, 0, (size_t)b->B * b->nr * b->esz, st));
+  if (zero_async(b->lamq, (size_t)b->B * b->nr * b->esz, st) || zero_async(b->lamv, (size_t)b->B * b->nr * b->esz, st)) return 1;
   b->t_cur = 0; b->record = backward_flag ? 1 : 0; b->order_valid = 0; b->has_prev = 0;
   return 0;
 }
@@ -1133,8 +1147,7 @@ int tsim_cache_pop(tsim_batch* b, void* stream) {
   b->pool.push_back(b->tape);                 // stream order keeps earlier kernels on the old buffer safe: it is only
   b->tape = e.buf;                            // handed out again by a later save on the same stream
   b->t_cur = e.len; b->record = e.record; b->has_prev = 0; b->order_valid = 0;
-  HIPCHK(hipMemsetAsync(b->lamq, 0, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream));
-  HIPCHK(hipMemsetAsync(b->lamv, 0, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream));
+  if (zero_async(b->lamq, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream) || zero_async(b->lamv, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream)) return 1;
   return 0;
 }
 int tsim_cache_clear(tsim_batch* b) {
