@@ -91,3 +91,106 @@ def test_spec_edits_recompile(pusher_model):
     assert m2.F[m2.I[B.TSIM_IH_FOFF_DOF] + 6 * B.TSIM_DF_SIZE + B.TSIM_DF_DAMPING] == 0.7
     with pytest.raises(KeyError):
         mc.edit_spec(spec, "body_density", "no_such_body", 1.0)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# A SECOND, independent reading of the reference's XMLs (plain ElementTree, counting rules written out here, nothing shared with
+# model/compiler.py): the oracle and the kernels consume the same compiled blob, so a parser error would be invisible to parity
+# tests.  Checked per asset: dof / motor / variable / taxel / contact-point / link counts and the total mass of the closed-form
+# bodies against what the compiled blob says.
+_NDOF = {"fixed": 0, "revolute": 1, "prismatic": 1, "planar": 2, "translational": 3, "free3d-euler": 6, "free3d-exp": 6}
+_NLINKS = {"fixed": 0, "revolute": 1, "prismatic": 1, "planar": 1, "translational": 1, "free3d-euler": 4, "free3d-exp": 2}
+_XMLS = {"pusher": "envs/assets/pusher/pusher.xml", "dclaw_position_control": "envs/assets/dclaw_rotate/dclaw_position_control.xml",
+         "tactile_insertion": "envs/assets/tactile_insertion/tactile_insertion.xml", "stable_grasp": "envs/assets/stable_grasp/stable_grasp.xml",
+         "tactile_pad": "assets/tactile_pad/tactile_pad.xml"}
+
+
+def _xml_statistics(path):
+    import math
+    import xml.etree.ElementTree as ET
+    root = ET.parse(path).getroot()
+    d = os.path.dirname(path)
+    fl = lambda s: [float(x) for x in s.split()]
+    joints = {j.get("name"): j.get("type") for r in root.iter("robot") for j in r.iter("joint")}        # not the <default> entries
+    bodies = {b.get("name"): b for r in root.iter("robot") for b in r.iter("body")}
+
+    def first_count(fn):
+        with open(os.path.join(d, fn)) as f:
+            return int(f.readline().split()[0])
+
+    def points_of(b):
+        t = b.get("type")
+        if t == "cuboid":
+            nx, ny, nz = (int(x) for x in b.get("general_contact_resolution", "2 2 2").split())
+            return nx * ny * nz - max(nx - 2, 0) * max(ny - 2, 0) * max(nz - 2, 0)          # surface lattice
+        if t == "cylinder":
+            return 2 * (1 + int(b.get("general_contact_angle_resolution", "8")) * int(b.get("general_contact_radius_resolution", "2")))
+        if t == "sphere":
+            return 1                                                                      # [CHOICE] lowest point on the ground
+        if t == "abstract":
+            c = b.find("collision")
+            return first_count(c.get("contacts"))
+        raise AssertionError("sampled body of type %s" % t)
+    st = {"ndof_r": sum(_NDOF[t] for t in joints.values()), "n_links": sum(_NLINKS[t] for t in joints.values()),
+          "ndof_u": sum(_NDOF[joints[m.get("joint")]] for m in root.iter("motor") if m.get("joint")),
+          "ndof_var": 3 * len(list(root.iter("endeffector")))}
+    ntax = 0
+    for s in root.iter("tactile"):
+        if s.get("type") == "rect_array":
+            r, c = (int(x) for x in s.get("resolution").split())
+            ntax += r * c
+        elif s.get("type") == "abstract":
+            ntax += first_count(s.get("spec"))
+    st["ndof_tactile"] = 3 * ntax
+    contact = root.find("contact")
+    ncpt = 0
+    for c in (contact if contact is not None else []):
+        ncpt += points_of(bodies[c.get("body") if c.tag == "ground_contact" else c.get("general_body")])
+    st["ncpt"] = ncpt
+    mass, has_mesh = 0.0, False
+
+    def body_mass(b):
+        t, rho = b.get("type"), float(b.get("density", "1"))                              # [CHOICE] default density 1
+        if t == "cuboid":
+            sx, sy, sz = fl(b.get("size")); return rho * sx * sy * sz
+        if t == "sphere":
+            return rho * 4.0 / 3.0 * math.pi * float(b.get("radius")) ** 3
+        if t == "cylinder":
+            return rho * math.pi * float(b.get("radius")) ** 2 * float(b.get("length"))
+        if t == "abstract":
+            return float(b.get("mass"))
+        return None                                                                       # mesh
+
+    def walk(link, moving):                        # bodies fixed to the world (every joint up to the root is `fixed`) carry no dynamics
+        nonlocal mass, has_mesh
+        j = link.find("joint")
+        moving = moving or (j is not None and j.get("type") != "fixed")
+        b = link.find("body")
+        if b is not None and moving:
+            bm = body_mass(b)
+            if bm is None:
+                has_mesh = True
+            else:
+                mass += bm
+        for ch in link.findall("link"):
+            walk(ch, moving)
+    for r in root.iter("robot"):
+        for l in r.findall("link"):
+            walk(l, False)
+    st["closed_form_mass"], st["has_mesh"] = mass, has_mesh
+    return st
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("name", list(_XMLS))
+def test_compiled_blob_agrees_with_an_independent_reading_of_the_xml(name):
+    st = _xml_statistics(os.path.join(REF, _XMLS[name]))
+    m = mc.load_model(asset(name))
+    assert (m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile) == (st["ndof_r"], st["ndof_u"], st["ndof_var"], st["ndof_tactile"])
+    assert m.n_links == st["n_links"], (m.n_links, st["n_links"])
+    assert int(m.I[B.TSIM_IH_NCPT]) == st["ncpt"], (int(m.I[B.TSIM_IH_NCPT]), st["ncpt"])
+    total = float(sum(m.meta["link_mass"]))                       # links 1..nl: the bodies that move
+    if not st["has_mesh"]:
+        assert abs(total - st["closed_form_mass"]) < 1e-9 * max(total, 1.0), (total, st["closed_form_mass"])
+    else:
+        assert total > st["closed_form_mass"]                     # the meshes add theirs (known volumes: test above)
