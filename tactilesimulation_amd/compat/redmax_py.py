@@ -81,6 +81,7 @@ class Simulation:
         return t.detach().to(torch.float64).cpu().numpy().reshape(-1)
 
     def _refresh(self):
+        self._sync_model()
         if self._dirty_outputs:
             q, qd = self._sim.get_state()
             var, tac = self._sim.readout()
@@ -110,6 +111,7 @@ class Simulation:
 
     # ------------------------------------------------------------------ stepping
     def reset(self, backward_flag=False, backward_design_params_flag=False):
+        self._sync_model()
         self._backward_flag = bool(backward_flag)
         self._sim.reset(self._t(self._q_init, self.ndof_r, "q_init"), self._t(self._qdot_init, self.ndof_r, "qdot_init"),
                         backward_flag=self._backward_flag)
@@ -124,6 +126,7 @@ class Simulation:
     def forward(self, num_steps, verbose=False, test_derivatives=False, save_last_frame_var_only=False):
         if test_derivatives:
             raise NotImplementedError("test_derivatives: use tests/test_gpu_parity.py (adjoint vs oracle / finite differences)")
+        self._sync_model()
         # high-resolution sensors (RollingBall: 120 000 values) are read out on demand by the sliced read-out kernel
         # instead of after every step (test_sim_speed.py:79 asks for them every 5th step only)
         lazy = self.ndof_tactile > 4096
@@ -188,6 +191,7 @@ class Simulation:
 
     def backward_steps(self, num_steps):
         """envs/redmax_torch_functions.py:167 — newest num_steps sub-steps, continuing the carried adjoint."""
+        self._sync_model()
         n = int(num_steps)
         a, b, c = self._seeds(n)
         du = self._sim.backward_steps(n, a, b, c, all_steps=True)
@@ -216,10 +220,17 @@ class Simulation:
 
     # ------------------------------------------------------------------ model edits (domain randomisation)
     def _edit(self, what, name, *args, **kw):
+        """Edits only touch the spec; the blob is recompiled and uploaded ONCE, by the next call that needs the model on the
+        device (envs/dclaw_rotate_env.py:173-178 makes four edits in a row at every reset)."""
         _mc.edit_spec(self._model.spec, what, name, *args, **kw)
         if what != "virtual_object":
+            self._model_dirty = True
+
+    def _sync_model(self):
+        if getattr(self, "_model_dirty", False):
             self._model = _mc.compile_spec(self._model.spec)
             self._sim.update_model(self._model)
+            self._model_dirty = False
             self._dirty_outputs = True
 
     def update_virtual_object(self, name, data):            # envs/tactile_push_env.py:148-152 (render only)

@@ -270,7 +270,9 @@ template <int LPE, class R> __device__ __forceinline__ R seg_bcast(R x, int src)
 template <class R> struct Ctx {
   const int* I; const R* F;               // model records (int blob; link / dof / motor / pair / sensor float tables): staged in LDS
   const R* Fg;                            // whole float blob in global memory (taxel SoA arrays; large contact-point arrays)
-  const R* CPT;                           // contact-point SoA arrays x[] y[] z[]: LDS copy when small, else global
+  const R* CPT;                           // contact-point SoA arrays x[] y[] z[] in global memory ...
+  __attribute__((address_space(3))) const R* CPTl; bool cpt_lds;   // ... and their LDS copy when staged (typed as an LDS pointer).  Two pointers, one flag: a single pointer that may be either
+                                          // makes every point load a flat_load (vector-memory latency, waits on vmcnt) instead of a ds_read
   int nl, nr, nu, nvar, npair, ncpt, nsensor, ntax, nd;
   int off_link, off_dof, off_motor, off_var, off_pair, off_sensor, off_sprim;
   int foff_link, foff_dof, foff_motor, foff_var, foff_pair, foff_sensor, foff_cpt, foff_tax;
@@ -389,7 +391,9 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     }
     TS_SYNC();
     c.Fg = F; c.F = mf;
-    c.CPT = (ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt) ? mf : F) + I[TSIM_IH_FOFF_CPT];
+    c.cpt_lds = ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt) != 0;
+    c.CPT = F + I[TSIM_IH_FOFF_CPT];
+    c.CPTl = (__attribute__((address_space(3))) const R*)(mf + (c.cpt_lds ? I[TSIM_IH_FOFF_CPT] : 0));
     F = mf;
   }
   c.stamps = nullptr; c.nstamp = 0;
@@ -443,6 +447,12 @@ template <class R> __device__ __forceinline__ void init_world(const Ctx<R>& c, i
   }
   for (int i = lane; i < (c.nl + 1) * c.nd * DT_SIZE; i += lpe) c.DT[i] = R(0);    // incl. the (link, dof) records no sweep writes
   for (int i = lane; i < 12; i += lpe) c.LPd[i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
+}
+
+// contact point i (SoA planes x, y, z) from its LDS copy or from global memory (wave-uniform choice)
+template <class R> __device__ __forceinline__ V3<R> ld_cpt(const Ctx<R>& c, int i) {
+  if (c.cpt_lds) return mk3<R>(c.CPTl[i], c.CPTl[i + c.ncpt], c.CPTl[i + 2 * c.ncpt]);
+  return mk3<R>(c.CPT[i], c.CPT[i + c.ncpt], c.CPT[i + 2 * c.ncpt]);
 }
 
 __device__ __forceinline__ int anc_of(const int* I, int off_link, int link) {

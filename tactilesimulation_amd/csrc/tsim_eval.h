@@ -308,8 +308,8 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
     V3<R> cP = zero3<R>(), xP = cP, F = cP;
     M3<R> Jx, Jv;
     if (pidx < npt) {
-      const R* cp = c.CPT + pt0 + pidx;                    // SoA: consecutive lanes -> consecutive addresses
-      V3<double> xPd = mulMv(RPAd, mk3<double>((double)cp[0], (double)cp[c.ncpt], (double)cp[2 * c.ncpt])) + pPAd;
+      const V3<R> cp = ld_cpt(c, pt0 + pidx);                // SoA: consecutive lanes -> consecutive addresses
+      V3<double> xPd = mulMv(RPAd, cvt3<double>(cp)) + pPAd;
       cP = cvt3<R>(xPd);
       if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
       xP = cvt3<R>(xPd);
@@ -417,8 +417,8 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
     V3<R> cP = zero3<R>(), xP = cP, F = cP;
     M3<R> Jx, Jv;
     if (pidx < npt) {
-      const R* cp = c.CPT + pt0 + pidx;                    // SoA: consecutive lanes -> consecutive addresses
-      V3<double> xPd = mulMv(RPAd, mk3<double>((double)cp[0], (double)cp[c.ncpt], (double)cp[2 * c.ncpt])) + pPAd;
+      const V3<R> cp = ld_cpt(c, pt0 + pidx);                // SoA: consecutive lanes -> consecutive addresses
+      V3<double> xPd = mulMv(RPAd, cvt3<double>(cp)) + pPAd;
       cP = cvt3<R>(xPd);
       if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
       xP = cvt3<R>(xPd);

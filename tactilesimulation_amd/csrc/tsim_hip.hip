@@ -332,8 +332,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_signature(SigArgs<R> a) {
       const M3<double> RPAd = ldm(c.PPd); const V3<double> pPAd = ldv(c.PPd + 9);
       const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
       for (int i = lane; i < pi[TSIM_PI_NPT]; i += TS_WAVE) {
-        const R* cp = c.CPT + pi[TSIM_PI_PT0] + i;
-        V3<double> xPd = mulMv(RPAd, mk3<double>((double)cp[0], (double)cp[c.ncpt], (double)cp[2 * c.ncpt])) + pPAd;
+        V3<double> xPd = mulMv(RPAd, cvt3<double>(ld_cpt(c, pi[TSIM_PI_PT0] + i))) + pPAd;
         if (pi[TSIM_PI_FLAGS] & 2) xPd.z -= (double)pf[TSIM_PF_SHAPE];
         const V3<R> xP = cvt3<R>(xPd);
         V3<R> F; M3<R> Jx, Jv; int br = 0;
@@ -857,7 +856,8 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   HIPCHK(hipGetLastError());
   if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
   else if (b->B >= 256) {
-    hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B, (b->B % (TS_WAVE / launch_shape(b).lpe) == 0) ? TS_WAVE / launch_shape(b).lpe : 1);
+    const int ns = TS_WAVE / launch_shape(b).lpe;
+    hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B, (b->B % ns == 0) ? ns : 1);
     HIPCHK(hipGetLastError());
     b->order_valid = 1;
   }

@@ -62,7 +62,6 @@ def test_reset_randomisers_match_an_oracle_compiled_from_the_edited_model():
     assert np.allclose(F[lf + Bl.TSIM_LF_P:lf + Bl.TSIM_LF_P + 2] - F0[lf + Bl.TSIM_LF_P:lf + Bl.TSIM_LF_P + 2], [dx, dy])
     pf = I[Bl.TSIM_IH_FOFF_PAIR]
     assert all(abs(F[pf + p * Bl.TSIM_PF_SIZE + Bl.TSIM_PF_SHAPE] - radius) < 1e-15 for p in range(3))
-    assert np.array_equal(sim._model.F, F) and np.array_equal(sim._model.I, I)
 
     rng = np.random.default_rng(3)
     q_init = sim.get_q_init().copy()
@@ -71,7 +70,8 @@ def test_reset_randomisers_match_an_oracle_compiled_from_the_edited_model():
     # bring the fingertips onto the cap so that contacts and taxels are active
     q_init[[1, 4, 7]], q_init[[2, 5, 8]] = 0.1 + 0.01 * rng.normal(size=3), 0.97
     sim.set_state_init(q_init, np.zeros(10))
-    sim.reset(backward_flag=False)
+    sim.reset(backward_flag=False)                                         # the four edits are compiled and uploaded here, once
+    assert np.array_equal(sim._model.F, F) and np.array_equal(sim._model.I, I)
     o = OracleSim(edited)
     o.reset(q_init, np.zeros(10))
     o_plain = OracleSim(base)
