@@ -399,9 +399,6 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
   c.stamps = nullptr; c.nstamp = 0;
   c.nl = I[TSIM_IH_NL]; c.nr = I[TSIM_IH_NR]; c.nu = I[TSIM_IH_NU]; c.nvar = I[TSIM_IH_NVAR];
   c.npair = I[TSIM_IH_NPAIR]; c.ncpt = I[TSIM_IH_NCPT]; c.nsensor = I[TSIM_IH_NSENSOR]; c.ntax = I[TSIM_IH_NTAXEL];
-#ifdef TS_EXPERIMENT_FIXED_DIMS      // A/B experiment: what do compile-time sizes buy?  (TactilePush only)
-  c.nl = 4; c.nr = 7; c.nu = 6; c.nvar = 2; c.npair = 2; c.ncpt = 74; c.nsensor = 1; c.ntax = 130;
-#endif
   c.nd = c.nr;
   c.off_link = I[TSIM_IH_OFF_LINK]; c.off_dof = I[TSIM_IH_OFF_DOF]; c.off_motor = I[TSIM_IH_OFF_MOTOR];
   c.off_var = I[TSIM_IH_OFF_VAR]; c.off_pair = I[TSIM_IH_OFF_PAIR]; c.off_sensor = I[TSIM_IH_OFF_SENSOR];
