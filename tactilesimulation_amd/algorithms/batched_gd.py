@@ -8,6 +8,26 @@ import torch
 from ..dist import allreduce_policy_grad_
 
 
+class _LinearGemmBiasGrad(torch.autograd.Function):
+    """torch.nn.functional.linear with the bias gradient computed as a GEMM (ones[1, B] @ g) instead of autograd's column
+    reduction g.sum(0).  Same values; the reason is the HIP-graph path: for B >= 2048 rows torch's reduction splits the
+    column sum over several blocks, which synchronise through a semaphore buffer zeroed by a hipMemsetAsync node, and on
+    this ROCm stack memset nodes are not reliably ordered when a captured graph is REPLAYED (the same defect as
+    profiles/r02_graphed_rollout_fix.md found in the simulator's own zero-fills).  Replays then returned bias gradients of
+    the 64-wide layers that were 40-140 % off, silently: the loss and every other gradient were right
+    (tools/graph_mlp_probe.py reproduces it without the simulator; profiles/r02_graph_bias_grad.md)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ones):
+        ctx.save_for_backward(x, weight, ones)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, ones = ctx.saved_tensors
+        return g @ weight, g.t() @ x, (ones @ g).reshape(-1), None
+
+
 class Actor(torch.nn.Module):
     """Deterministic part of utils/model.py:123-151 DiagGaussianActor for gd_tactile.yaml: 393 -> 64 -> 64 -> 3, ELU,
     plus the (unused in deterministic mode) log-std vector: 29 574 parameters, the all-reduce payload of SURVEY.md §8e."""
@@ -22,9 +42,15 @@ class Actor(torch.nn.Module):
         self.mu_net = torch.nn.Sequential(*layers)
         self.logstd = torch.nn.Parameter(torch.full((act_dim,), -1.0))
         self.to(dtype)
+        self._ones = None
 
     def forward(self, obs):
-        return self.mu_net(obs)
+        if self._ones is None or self._ones.shape[1] != obs.shape[0] or self._ones.dtype != obs.dtype or self._ones.device != obs.device:
+            self._ones = torch.ones(1, obs.shape[0], device=obs.device, dtype=obs.dtype)
+        x = obs
+        for m in self.mu_net:
+            x = _LinearGemmBiasGrad.apply(x, m.weight, m.bias, self._ones) if isinstance(m, torch.nn.Linear) else m(x)
+        return x
 
 
 def rollout_loss(env, actor, horizon, q0=None, goal=None, disturbances=None):

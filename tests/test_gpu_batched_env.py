@@ -150,12 +150,16 @@ def test_batched_gd_training_reduces_the_loss(pusher_model):
             dst.copy_(src)
         if e == 0:                                             # graph replay vs eager on the new episode, before any update
             gr.replay()
-            got = torch.cat([p.grad.reshape(-1) for p in actor.parameters() if p.grad is not None]).clone()
+            named = [(n, p) for n, p in actor.named_parameters() if p.grad is not None]
+            got = [p.grad.clone() for _, p in named]
             ref_env = BatchedTactilePushEnv(pusher_model, B, dtype=dt, gradient=True, seed=3, tape_steps=T)
             le = rollout_loss(ref_env, actor, T, q0=q0, goal=goal, disturbances=D)
-            ref = torch.cat([r.reshape(-1) for r in torch.autograd.grad(le, [p for p in actor.parameters()], allow_unused=True) if r is not None])
-            assert bool(torch.isfinite(got).all())
-            assert float((got - ref).norm()) < 1e-3 * float(ref.norm()), (float(got.norm()), float(ref.norm()))
+            ref = torch.autograd.grad(le, [p for _, p in named])
+            # parameter by parameter: the replayed bias gradients of the 64-wide layers were 40-140 % off while the flat
+            # gradient's norm hid it (profiles/r02_graph_bias_grad.md); the same kernels on the same data: equal to rounding
+            for (n, _), a, b in zip(named, got, ref):
+                assert bool(torch.isfinite(a).all()), n
+                assert float((a - b).norm()) <= 1e-5 * float(b.norm()), (n, float((a - b).norm()), float(b.norm()))
             del ref_env
         losses.append(float(train_epoch_graphed(gr, opt, B).detach()) / B)
     print("loss per episode:", ["%.1f" % l for l in losses])
