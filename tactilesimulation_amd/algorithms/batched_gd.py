@@ -28,6 +28,26 @@ class _LinearGemmBiasGrad(torch.autograd.Function):
         return g @ weight, g.t() @ x, (ones @ g).reshape(-1), None
 
 
+class _LinearDeferredWeightGrad(torch.autograd.Function):
+    """linear() whose backward only propagates to its input (g @ W) and parks (x, g) in `sink`; the weight and bias gradients
+    of ALL env-steps of the episode are then formed at once by Actor.assemble_grads().  Per env-step the weight gradient is a
+    [out x B] @ [B x in] GEMM — 64 x 393 outputs with K = B = 4096: 14 workgroups looping over K, 40-63 us each for 0.2 GFLOP, three
+    of them per step, 27 % of the closed loop's GPU time (profiles/r02_closed_loop_kernels.md).  Over the episode the same sum
+    is one batched GEMM with T x 14 workgroups."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, sink):
+        ctx.save_for_backward(x, weight)
+        ctx.sink = sink
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        ctx.sink.append((x, g))
+        return (g @ weight) if ctx.needs_input_grad[0] else None, None, None, None
+
+
 class Actor(torch.nn.Module):
     """Deterministic part of utils/model.py:123-151 DiagGaussianActor for gd_tactile.yaml: 393 -> 64 -> 64 -> 3, ELU,
     plus the (unused in deterministic mode) log-std vector: 29 574 parameters, the all-reduce payload of SURVEY.md §8e."""
@@ -43,25 +63,52 @@ class Actor(torch.nn.Module):
         self.logstd = torch.nn.Parameter(torch.full((act_dim,), -1.0))
         self.to(dtype)
         self._ones = None
+        self.defer_weight_grads = False         # GraphedRollout / train_epoch(defer=True) switch this on
+        self._sinks = [[] for m in self.mu_net if isinstance(m, torch.nn.Linear)]
 
     def forward(self, obs):
         if self._ones is None or self._ones.shape[1] != obs.shape[0] or self._ones.dtype != obs.dtype or self._ones.device != obs.device:
             self._ones = torch.ones(1, obs.shape[0], device=obs.device, dtype=obs.dtype)
-        x = obs
+        x, k = obs, 0
         for m in self.mu_net:
-            x = _LinearGemmBiasGrad.apply(x, m.weight, m.bias, self._ones) if isinstance(m, torch.nn.Linear) else m(x)
+            if not isinstance(m, torch.nn.Linear):
+                x = m(x)
+            elif self.defer_weight_grads:
+                x = _LinearDeferredWeightGrad.apply(x, m.weight, m.bias, self._sinks[k]); k += 1
+            else:
+                x = _LinearGemmBiasGrad.apply(x, m.weight, m.bias, self._ones)
         return x
+
+    def begin_episode(self):
+        """Deferred mode: forget the (input, output-gradient) pairs of earlier backward passes."""
+        for s in self._sinks:
+            s.clear()
+
+    def assemble_grads(self, keep=False):
+        """Deferred mode, after the episode's backward: weight.grad = sum_t g_t^T x_t as ONE batched GEMM per layer and
+        bias.grad = sum_t sum_b g_t (assigned, not accumulated).  keep=True leaves the parked tensors in place — they are the
+        static buffers of a captured graph, rewritten by every replay.  Runs eagerly, outside any graph."""
+        linears = [m for m in self.mu_net if isinstance(m, torch.nn.Linear)]
+        for m, sink in zip(linears, self._sinks):
+            if not sink:
+                m.weight.grad = m.bias.grad = None
+                continue
+            X, G = torch.stack([x for x, _ in sink]), torch.stack([g for _, g in sink])        # [T, B, in], [T, B, out]
+            m.weight.grad = torch.bmm(G.transpose(1, 2), X).sum(0)
+            m.bias.grad = G.sum((0, 1))
+            if not keep:
+                sink.clear()
 
 
 def rollout_loss(env, actor, horizon, q0=None, goal=None, disturbances=None):
     """-sum of rewards of all environments over one episode (un-normalised; see train_epoch)."""
     obs = env.reset(q0, goal)
-    total = obs.new_zeros(())
+    acc = None                                   # per-environment return: one add per env-step, no per-step reduction
     for t in range(horizon):
         u = actor(obs)
         obs, rew, _ = env.step(u, None if disturbances is None else disturbances[t])
-        total = total - rew.sum()
-    return total
+        acc = rew if acc is None else acc + rew
+    return -acc.sum()
 
 
 class GraphedRollout:
@@ -76,16 +123,25 @@ class GraphedRollout:
     def __init__(self, env, actor, horizon, q0, goal, disturbances, warmup=2):
         self.env, self.actor, self.horizon = env, actor, horizon
         self.q0, self.goal, self.dist = q0, goal, disturbances
+        self.deferred = hasattr(actor, "assemble_grads")      # the weight gradients of all env-steps as one GEMM after the replay
+        if self.deferred:
+            actor.defer_weight_grads = True
         side = torch.cuda.Stream(env.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                         # eager warm-up on a side stream (allocator, lazy init)
             for _ in range(warmup):
                 for p in actor.parameters():
                     p.grad = None
+                if self.deferred:
+                    actor.begin_episode()
                 rollout_loss(env, actor, horizon, q0=q0, goal=goal, disturbances=disturbances).backward()
+                if self.deferred:
+                    actor.assemble_grads()
         torch.cuda.current_stream().wait_stream(side)
         for p in actor.parameters():
             p.grad = None
+        if self.deferred:
+            actor.begin_episode()
         # Capture on the SAME side stream the warm-up ran on: the parameters' AccumulateGrad nodes were created there, and a
         # capture on another stream makes autograd fork the gradient accumulation onto the warm-up stream inside the graph —
         # replays with new episode data then read gradient buffers before that branch has written them (garbage policy
@@ -97,6 +153,8 @@ class GraphedRollout:
 
     def replay(self):
         self.graph.replay()
+        if self.deferred:
+            self.actor.assemble_grads(keep=True)
         return self.loss
 
 
@@ -115,8 +173,13 @@ def train_epoch(env, actor, optimizer, horizon, global_episodes, grad_clip=1.0, 
     """One optimiser step on `global_episodes` episodes (= sum over ranks of env.B): local BPTT, ONE all-reduce of the
     flat gradient, normalisation by the global episode count, then clip-by-global-norm and Adam (gd.py:157-164,258)."""
     optimizer.zero_grad(set_to_none=True)
+    deferred = getattr(actor, "defer_weight_grads", False)
+    if deferred:
+        actor.begin_episode()
     loss = rollout_loss(env, actor, horizon, **rollout_kw)
     loss.backward()
+    if deferred:
+        actor.assemble_grads()
     allreduce_policy_grad_(list(actor.parameters()), global_episodes)
     if grad_clip:
         torch.nn.utils.clip_grad_norm_(actor.parameters(), grad_clip)

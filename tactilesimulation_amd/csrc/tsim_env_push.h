@@ -1,0 +1,127 @@
+// TactilePush per-step formulas as fused element-wise kernels (include/tsim_env.h).  Included at the end of tsim_hip.hip.
+// HBM-bound and tiny: one env-step moves ~3.2 KB per environment (13 MB at B = 4096, ~3 us at HBM rate), so these are
+// launch-latency kernels; the point is ONE launch instead of ~45 each way.  Flat thread -> (environment, column) so that the
+// observation rows are written / the tactile gradient rows are read fully coalesced; the 3 + 1 closed-form columns are
+// computed by the first threads of each row.
+#pragma once
+
+template <class R>
+__global__ void __launch_bounds__(256) k_push_action(int B, const R* __restrict__ u, const R* __restrict__ ext, R* __restrict__ a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * 6) return;
+  const int e = i / 6, c = i - e * 6;
+  a[i] = c < 3 ? (R)tanh((double)u[e * 3 + c]) : (c < 5 ? ext[e * 2 + c - 3] : (R)0);
+}
+
+template <class R>
+__global__ void __launch_bounds__(256) k_push_action_bwd(int B, const R* __restrict__ u, const R* __restrict__ da, R* __restrict__ du) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * 3) return;
+  const int e = i / 3, c = i - e * 3;
+  const double t = tanh((double)u[i]);
+  du[i] = (R)((double)da[e * 6 + c] * (1.0 - t * t));
+}
+
+template <class R>
+__global__ void __launch_bounds__(256) k_push_observe(int B, int ntac, const R* __restrict__ q, const R* __restrict__ var,
+                                                      const R* __restrict__ tac, const R* __restrict__ goal, const R* __restrict__ u,
+                                                      R* __restrict__ obs, R* __restrict__ rew) {
+  const int W = 3 + ntac;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * W) return;
+  const int e = (int)(i / W), c = (int)(i - (long long)e * W);
+  if (c >= 3) { obs[i] = tac[(long long)e * ntac + c - 3]; return; }
+  const R* qe = q + e * 7; const R* g = goal + e * 3;
+  const double th = qe[0], cs = cos(th), sn = sin(th), gx = g[0], gy = g[1];
+  // goal pose in the gripper frame: rotation by -yaw, then the gripper's position is subtracted (tactile_push_env.py:84-92)
+  const double v = c == 0 ? cs * gx + sn * gy - (double)qe[1] : (c == 1 ? -sn * gx + cs * gy - (double)qe[2] : (double)g[2] - th);
+  obs[i] = (R)v;
+  if (c == 0 && rew) {
+    const double dx = ((double)qe[3] - gx) * 100.0, dy = ((double)qe[4] - gy) * 100.0, dr = ((double)qe[6] - (double)g[2]) * (36.0 / M_PI);
+    double t2 = 0, a2 = 0;
+    for (int k = 0; k < 3; ++k) { const double d = (double)var[e * 6 + k] - (double)var[e * 6 + 3 + k]; t2 += d * d; a2 += (double)u[e * 3 + k] * (double)u[e * 3 + k]; }
+    rew[e] = (R)(-(dx * dx + dy * dy) * 0.01 - dr * dr * 0.1 - t2 * 2500.0 - a2 * 0.1);
+  }
+}
+
+template <class R>
+__global__ void __launch_bounds__(256) k_push_observe_bwd(int B, int ntac, const R* __restrict__ q, const R* __restrict__ var,
+                                                          const R* __restrict__ goal, const R* __restrict__ u, const R* __restrict__ dobs,
+                                                          const R* __restrict__ drew, long long drs, R* __restrict__ dq, R* __restrict__ dvar,
+                                                          R* __restrict__ dtac, R* __restrict__ du) {
+  const int W = 3 + ntac;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)B * W) return;
+  const int e = (int)(i / W), c = (int)(i - (long long)e * W);
+  if (c >= 3) { dtac[(long long)e * ntac + c - 3] = dobs[i]; return; }
+  if (c != 0) return;
+  const R* qe = q + e * 7; const R* g = goal + e * 3;
+  const double th = qe[0], cs = cos(th), sn = sin(th), gx = g[0], gy = g[1];
+  const double d0 = dobs[i], d1 = dobs[i + 1], d2 = dobs[i + 2];
+  double o[7] = {d0 * (-sn * gx + cs * gy) + d1 * (-cs * gx - sn * gy) - d2, -d0, -d1, 0, 0, 0, 0};
+  if (drew) {
+    const double r = drew[(long long)e * drs];
+    o[3] = -200.0 * ((double)qe[3] - gx) * r;                                   // -0.01 * 2 (q3 - gx) / 0.01^2
+    o[4] = -200.0 * ((double)qe[4] - gy) * r;
+    o[6] = -0.2 * ((double)qe[6] - (double)g[2]) * (36.0 / M_PI) * (36.0 / M_PI) * r;
+    for (int k = 0; k < 3; ++k) {
+      const double d = (double)var[e * 6 + k] - (double)var[e * 6 + 3 + k];
+      dvar[e * 6 + k] = (R)(-5000.0 * d * r); dvar[e * 6 + 3 + k] = (R)(5000.0 * d * r);
+      du[e * 3 + k] = (R)(-0.2 * (double)u[e * 3 + k] * r);
+    }
+  }
+  for (int k = 0; k < 7; ++k) dq[e * 7 + k] = (R)o[k];
+}
+
+static inline unsigned push_blocks(long long n) { return (unsigned)((n + 255) / 256); }
+#define TS_PUSH_ARGS_OK(B, dtype) do { if ((B) <= 0) return fail("push env: B must be > 0"); \
+    if ((dtype) != TSIM_F32 && (dtype) != TSIM_F64) return fail("push env: dtype must be TSIM_F32 or TSIM_F64"); } while (0)
+
+extern "C" int tsim_push_action(int B, int dtype, const void* u, const void* ext, void* action, void* stream) {
+  TS_PUSH_ARGS_OK(B, dtype);
+  if (!u || !ext || !action) return fail("tsim_push_action: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TSIM_F32) hipLaunchKernelGGL(k_push_action<float>, dim3(push_blocks((long long)B * 6)), dim3(256), 0, st, B, (const float*)u, (const float*)ext, (float*)action);
+  else hipLaunchKernelGGL(k_push_action<double>, dim3(push_blocks((long long)B * 6)), dim3(256), 0, st, B, (const double*)u, (const double*)ext, (double*)action);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsim_push_action_backward(int B, int dtype, const void* u, const void* d_action, void* du, void* stream) {
+  TS_PUSH_ARGS_OK(B, dtype);
+  if (!u || !d_action || !du) return fail("tsim_push_action_backward: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TSIM_F32) hipLaunchKernelGGL(k_push_action_bwd<float>, dim3(push_blocks((long long)B * 3)), dim3(256), 0, st, B, (const float*)u, (const float*)d_action, (float*)du);
+  else hipLaunchKernelGGL(k_push_action_bwd<double>, dim3(push_blocks((long long)B * 3)), dim3(256), 0, st, B, (const double*)u, (const double*)d_action, (double*)du);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsim_push_observe(int B, int ntac, int dtype, const void* q, const void* var, const void* tactile, const void* goal,
+                                 const void* u, void* obs, void* rew, void* stream) {
+  TS_PUSH_ARGS_OK(B, dtype);
+  if (ntac < 0) return fail("tsim_push_observe: ntac < 0");
+  if (!q || !goal || !obs || (ntac && !tactile)) return fail("tsim_push_observe: null pointer");
+  if (rew && (!var || !u)) return fail("tsim_push_observe: the reward needs var and u");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = push_blocks((long long)B * (3 + ntac));
+  if (dtype == TSIM_F32) hipLaunchKernelGGL(k_push_observe<float>, dim3(nb), dim3(256), 0, st, B, ntac, (const float*)q, (const float*)var, (const float*)tactile, (const float*)goal, (const float*)u, (float*)obs, (float*)rew);
+  else hipLaunchKernelGGL(k_push_observe<double>, dim3(nb), dim3(256), 0, st, B, ntac, (const double*)q, (const double*)var, (const double*)tactile, (const double*)goal, (const double*)u, (double*)obs, (double*)rew);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsim_push_observe_backward(int B, int ntac, int dtype, const void* q, const void* var, const void* goal, const void* u,
+                                          const void* d_obs, const void* d_rew, long long d_rew_stride,
+                                          void* dq, void* dvar, void* dtac, void* du, void* stream) {
+  TS_PUSH_ARGS_OK(B, dtype);
+  if (ntac < 0) return fail("tsim_push_observe_backward: ntac < 0");
+  if (!q || !goal || !d_obs || !dq || (ntac && !dtac)) return fail("tsim_push_observe_backward: null pointer");
+  if (d_rew && (!var || !u || !dvar || !du)) return fail("tsim_push_observe_backward: the reward gradient needs var, u, dvar and du");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = push_blocks((long long)B * (3 + ntac));
+  if (dtype == TSIM_F32) hipLaunchKernelGGL(k_push_observe_bwd<float>, dim3(nb), dim3(256), 0, st, B, ntac, (const float*)q, (const float*)var, (const float*)goal, (const float*)u, (const float*)d_obs, (const float*)d_rew, d_rew_stride, (float*)dq, (float*)dvar, (float*)dtac, (float*)du);
+  else hipLaunchKernelGGL(k_push_observe_bwd<double>, dim3(nb), dim3(256), 0, st, B, ntac, (const double*)q, (const double*)var, (const double*)goal, (const double*)u, (const double*)d_obs, (const double*)d_rew, d_rew_stride, (double*)dq, (double*)dvar, (double*)dtac, (double*)du);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -1200,3 +1200,7 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
 }
 
 }  // extern "C"
+
+// ================================================================================================ TactilePush per-step formulas
+#include "../../include/tsim_env.h"
+#include "tsim_env_push.h"

@@ -2,7 +2,8 @@
 
 Vectorised counterpart of the reference's envs/tactile_push_env.py (observation_type "tactile_flatten", use_torch):
 same action mapping (:175-193), observation (:72-131) and reward (:202-211), evaluated for all B environments in torch
-on the device; the simulator step is BatchedStepSimFunction (one HIP launch forward, one backward per env-step). The
+on the device by the fused kernels of include/tsim_env.h (envs/push_ops.py: one launch each way for the action mapping, one for
+observation + reward); the simulator step is BatchedStepSimFunction (one HIP launch forward, one backward per env-step). The
 per-environment gym wrapper of the reference keeps working through compat/redmax_py.py; this class is what SURVEY.md
 §8(f).1 calls the batched counterpart.
 """
@@ -13,6 +14,7 @@ import numpy as np
 import torch
 
 from ..functions import BatchedStepSimFunction
+from .push_ops import PushAction, PushObserve, observe_reset
 from ..host.batch import BatchSim
 from ..model.compiler import load_model
 
@@ -40,14 +42,6 @@ class BatchedTactilePushEnv:
             return a.to(device=self.device, dtype=self.dtype)
         return torch.as_tensor(np.asarray(a), device=self.device, dtype=self.dtype)
 
-    def _obs(self, q, tactile):
-        """goal pose in the gripper frame (3) + flattened tactile (390)   (tactile_push_env.py:84-114)"""
-        th = q[:, 0]
-        c, s = torch.cos(-th), torch.sin(-th)
-        gx, gy = self.goal[:, 0], self.goal[:, 1]
-        gl = torch.stack([c * gx - s * gy - q[:, 1], s * gx + c * gy - q[:, 2], self.goal[:, 2] - th], dim=1)
-        return torch.cat([gl, tactile], dim=1)
-
     # ------------------------------------------------------------------ gym-like API, batched
     def reset(self, q0=None, goal=None):
         """Per-environment draws of tactile_push_env.py:133-172 (box y offset, goal xy, goal yaw), or explicit tables."""
@@ -65,23 +59,26 @@ class BatchedTactilePushEnv:
         _, tac = self.sim.readout(want_var=False)
         self.external_force = torch.zeros(B, 2, device=self.device, dtype=self.dtype)
         self.current_step = 0
-        return self._obs(self.q0, tac)
+        return observe_reset(self.q0, tac, self.goal)
 
     def step(self, u, disturbance=None):
         """u: policy output [B, 3] (pre-tanh). Returns obs [B, 393], reward [B], info dict of reward terms."""
-        action = torch.tanh(u)
         if disturbance is not None:
             self.external_force = disturbance.to(self.device, self.dtype)
         elif self.current_step % 10 == 0:                                   # :185-190
             on = self._t(self.rng.uniform(0.0, 1.0, size=self.B) < 0.5).unsqueeze(1)
             self.external_force = on * self._t(self.rng.uniform(-1.0, 1.0, size=(self.B, 2)))
-        robot_action = torch.cat([action, self.external_force, torch.zeros(self.B, 1, device=self.device, dtype=self.dtype)], dim=1)
+        robot_action = PushAction.apply(u, self.external_force)                                    # [tanh(u), force on the box, 0]
         q, var, tactile = BatchedStepSimFunction.apply(robot_action, self.frame_skip, self.sim, self.gradient)
         self.current_step += 1
-        obs = self._obs(q, tactile)
+        obs, rew = PushObserve.apply(q, var, tactile, self.goal, u)
+        return obs, rew, {"q": q, "var": var}
+
+    def reward_terms(self, q, var, u):
+        """The four terms of the reward (tactile_push_env.py:202-211) in plain torch, for logging; step() computes their sum in
+        the fused kernel."""
         r_pos = -(((q[:, 3:5] - self.goal[:, 0:2]) / 0.01) ** 2).sum(1) * 0.01
         r_rot = -(((q[:, 6] - self.goal[:, 2]) / (math.pi / 36.0)) ** 2) * 0.1
         r_touch = -((var[:, 0:3] - var[:, 3:6]) ** 2).sum(1) / (0.02 ** 2)
         r_act = -(u ** 2).sum(1) * 0.1
-        info = {"reward_pos": r_pos, "reward_rot": r_rot, "reward_touch": r_touch, "reward_action": r_act, "q": q}
-        return obs, r_pos + r_rot + r_touch + r_act, info
+        return {"reward_pos": r_pos, "reward_rot": r_rot, "reward_touch": r_touch, "reward_action": r_act}

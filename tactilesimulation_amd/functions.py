@@ -139,10 +139,12 @@ class BatchedStepSimFunction(autograd.Function):
     @staticmethod
     def backward(ctx, df_dq, df_dvar, df_dtactile):
         sim, n = ctx.sim, ctx.num_steps
-        du = sim.backward_steps(n, df_dq, df_dvar if sim.ndof_var else None, df_dtactile if sim.ndof_tactile else None)
+        # one frame of n sub-steps: the kernel sums df_du over the frame's sub-steps itself (include/tsim.h tsim_backward_episode)
+        f = lambda t, on: t.to(sim.dtype).unsqueeze(0) if (on and t is not None) else None
+        du = sim.backward_episode(1, n, f(df_dq, True), f(df_dvar, sim.ndof_var), f(df_dtactile, sim.ndof_tactile))
         if not ctx.need_du:
             return None, None, None, None
-        return du.sum(dim=1).to(ctx.in_dtype), None, None, None
+        return du[0].to(ctx.in_dtype), None, None, None
 
 
 class BatchedEpisodicSimFunction(autograd.Function):

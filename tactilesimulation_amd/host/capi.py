@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI in include/tsim.h (libtsim_hip.so, built in-tree by __graft_entry__.build()).
+"""ctypes binding of the C ABI in include/tsim.h and include/tsim_env.h (libtsim_hip.so, built in-tree by __graft_entry__.build()).
 
 There is NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
 """
@@ -38,6 +38,11 @@ _SIGS = {
     "tsim_set_lanes_per_env": (C.c_int, [_vp, C.c_int]),
     "tsim_last_evals": (C.c_int, [_vp, _ip]),
     "tsim_last_error": (C.c_char_p, []),
+    # include/tsim_env.h — TactilePush per-step formulas
+    "tsim_push_action": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "tsim_push_action_backward": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "tsim_push_observe": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_push_observe_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = sorted(_SIGS)
 

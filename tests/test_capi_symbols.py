@@ -1,4 +1,4 @@
-"""The C-ABI library loads and exports every symbol include/tsim.h declares (no GPU, no compute calls)."""
+"""The C-ABI library loads and exports every symbol include/*.h declares (no GPU, no compute calls)."""
 import ctypes
 import os
 import re
@@ -9,7 +9,8 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def _declared():
-    txt = open(os.path.join(ROOT, "include", "tsim.h")).read()
+    inc = os.path.join(ROOT, "include")
+    txt = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(tsim_\w+)\s*\(", txt)))
 
