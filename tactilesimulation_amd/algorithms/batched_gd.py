@@ -79,6 +79,25 @@ class Actor(torch.nn.Module):
                 x = _LinearGemmBiasGrad.apply(x, m.weight, m.bias, self._ones)
         return x
 
+    # the reference's checkpoint layout (utils/model.py:123-151 DiagGaussianActor: feature_net.body.{0,2}, mean_net, logstd)
+    _REF_KEYS = (("feature_net.body.0", "mu_net.0"), ("feature_net.body.2", "mu_net.2"), ("mean_net", "mu_net.4"))
+
+    def load_reference_state_dict(self, sd):
+        """Load a DiagGaussianActor state_dict saved by the reference (algorithms/gd.py:189-194) — 393 -> 64 -> 64 -> 3 only."""
+        own = {"logstd": torch.as_tensor(sd["logstd"])}
+        for ref, mine in self._REF_KEYS:
+            for part in ("weight", "bias"):
+                own["%s.%s" % (mine, part)] = torch.as_tensor(sd["%s.%s" % (ref, part)])
+        self.load_state_dict(own)
+
+    def reference_state_dict(self):
+        """The parameters under the reference's names (for its `load` / evaluation scripts)."""
+        sd, out = self.state_dict(), {"logstd": self.logstd.detach().clone()}
+        for ref, mine in self._REF_KEYS:
+            for part in ("weight", "bias"):
+                out["%s.%s" % (ref, part)] = sd["%s.%s" % (mine, part)].detach().clone()
+        return out
+
     def begin_episode(self):
         """Deferred mode: forget the (input, output-gradient) pairs of earlier backward passes."""
         for s in self._sinks:

@@ -8,7 +8,7 @@ from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
 from tactilesimulation_amd.algorithms.batched_gd import Actor, GraphedRollout, train_epoch_graphed
 from tactilesimulation_amd.workloads import PUSHER_BLOB
 from train_tactile_push_gd_batched import draw_episode
-B, T, dt = 4096, 100, torch.float32
+B, T, dt = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096), 100, torch.float32
 rng = np.random.default_rng(0)
 q0, goal, D = draw_episode(rng, B, T, "cuda", dt)
 torch.manual_seed(0); actor = Actor(dtype=dt).cuda(); opt = torch.optim.Adam(actor.parameters(), lr=0.0)
