@@ -72,7 +72,8 @@ int tsim_reset_masked(tsim_batch* b, const void* q0, const void* qd0, const int3
  * (and :48-57 with num_steps = 1).  u: [B][ndof_u], held for num_steps implicit sub-steps.
  * Outputs (any may be NULL): q_out, qd_out [B][ndof_r]; var_out [B][ndof_var]; tac_out [B][ndof_tactile]
  * (taxel-major: shear0, shear1, normal); status [B] int32 = number of sub-steps whose Newton solve did not
- * reach tol (bit 30 set if a non-finite value appeared). */
+ * reach tol (bit 30 set if a non-finite value appeared, in the state or in u: a NaN / inf control is flagged here rather than
+ * swallowed by the motor law's clamp). */
 int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd_out, void* var_out,
               void* tac_out, int32_t* status, void* stream);
 

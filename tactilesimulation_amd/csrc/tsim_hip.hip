@@ -132,7 +132,12 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
   // environment of the batch between env-steps: Newton stragglers average out over the episode.
   for (int f = 0; f < a.nframes; ++f) {
-  if (lane < nu) c.u[lane] = a.u[((size_t)f * a.B + env) * nu + lane];
+  {
+    R uv = R(0);
+    if (lane < nu) { uv = a.u[((size_t)f * a.B + env) * nu + lane]; c.u[lane] = uv; }
+    // a NaN / inf control would be clamped away silently by the motor law's fmin / fmax: flag it (status bit 30) instead
+    if (seg_sum<LPE>((uv - uv == R(0)) ? R(0) : R(1)) > R(0)) nonfinite = true;
+  }
   TS_SYNC();
   for (int s = 0; s < a.nsub; ++s) {
     // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment

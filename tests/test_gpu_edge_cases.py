@@ -1,0 +1,96 @@
+"""Edge cases of the C ABI on the GPU: ragged batches (B no multiple of the environments per wavefront), batch-composition
+independence, error paths that must fail loudly and leave the batch usable, non-finite inputs confined to their environment."""
+import numpy as np
+import pytest
+import torch
+
+from tactilesimulation_amd.workloads import push_workload
+
+pytestmark = pytest.mark.gpu
+S = 5
+
+
+def _run(model, q0, u, lanes, dtype, grad=True, first=0):
+    from tactilesimulation_amd.host.batch import BatchSim
+    B, T = u.shape[0], u.shape[1]
+    sim = BatchSim(model, B, dtype=dtype, tape_capacity=T * S)
+    sim.set_lanes_per_env(lanes)
+    sim.reset(torch.tensor(q0), None, backward_flag=grad)
+    qs, tacs = [], []
+    for t in range(T):
+        o = sim.step(torch.tensor(u[:, t]), S)
+        qs.append(o["q"].clone()); tacs.append(o["tactile"].clone())
+        assert int(o["status"].max()) == 0
+    du = None
+    if grad:
+        w = torch.tensor(np.random.default_rng(3).normal(size=(128, 7))[first:first + B])        # the same seed rows for every batch composition
+        du = []
+        for t in range(T):                                   # newest first
+            du.append(sim.backward_episode(1, S, w[None].to("cuda", dtype), None, None)[0].clone())
+    return torch.stack(qs), torch.stack(tacs), (torch.stack(du) if grad else None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+def test_ragged_batches_and_batch_composition(pusher_model, dtype, lanes):
+    """An environment's results do not depend on which other environments share its wavefront or batch: B = 1, 3, 5 and 67
+    (no multiples of 4 or 2 environments per wavefront: idle slots in the last block) give bit-identical rows."""
+    T = 6
+    q0, u, _ = push_workload(67, T, seed=4)
+    ref = _run(pusher_model, q0, u, lanes, dtype)
+    for B in (1, 3, 5):
+        got = _run(pusher_model, q0[:B], u[:B], lanes, dtype)
+        for a, b, name in zip(got, ref, ("q", "tactile", "df_du")):
+            assert torch.equal(a, b[:, :B]), (name, B)
+    # and the last, partly filled block of the big batch is a real result: compare env 66 alone
+    solo = _run(pusher_model, q0[66:67], u[66:67], lanes, dtype, first=66)
+    for a, b in zip(solo, ref):
+        assert torch.equal(a, b[:, 66:67])
+
+
+def test_errors_fail_loudly_and_leave_the_batch_usable(pusher_model):
+    from tactilesimulation_amd.host.batch import BatchSim
+    B = 6
+    q0, u, _ = push_workload(B, 4, seed=1)
+    sim = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=2 * S)
+    sim.reset(torch.tensor(q0), None, backward_flag=True)
+    with pytest.raises(RuntimeError, match="num_steps"):
+        sim.step(torch.tensor(u[:, 0]), 0)
+    with pytest.raises(RuntimeError, match="nothing|recorded|tape"):
+        sim.backward_steps(S)                                 # nothing recorded yet
+    a = sim.step(torch.tensor(u[:, 0]), S)["q"].clone()
+    sim.step(torch.tensor(u[:, 1]), S)
+    q_before, _ = sim.get_state()
+    with pytest.raises(RuntimeError, match="capacity"):
+        sim.step(torch.tensor(u[:, 2]), S)                    # the tape holds 2 env-steps
+    q_after, _ = sim.get_state()
+    assert torch.equal(q_before, q_after) and sim.tape_len() == 2 * S     # the refused call changed nothing
+    with pytest.raises(RuntimeError):
+        sim.backward_steps(3 * S)                             # more than recorded
+    du = sim.backward_steps(2 * S, torch.ones(B, 7))          # still usable
+    assert bool(torch.isfinite(du).all()) and sim.tape_len() == 0
+    with pytest.raises(RuntimeError, match="recording"):
+        sim.reset(torch.tensor(q0), None, backward_flag=True)
+        sim.reset_masked(torch.tensor(q0), torch.ones(B, dtype=torch.int32))
+    sim.reset(torch.tensor(q0), None, backward_flag=False)
+    assert torch.equal(sim.step(torch.tensor(u[:, 0]), S)["q"], a)         # and deterministic after all of that
+    with pytest.raises(RuntimeError):
+        sim.set_lanes_per_env(48)
+
+
+def test_non_finite_action_is_confined_to_its_environment(pusher_model):
+    from tactilesimulation_amd.host.batch import BatchSim
+    B, T = 9, 3
+    q0, u, _ = push_workload(B, T, seed=2)
+    clean = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=0)
+    dirty = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=0)
+    for s in (clean, dirty):
+        s.reset(torch.tensor(q0), None, backward_flag=False)
+    ud = u.copy(); ud[4, 1, 0] = np.nan
+    for t in range(T):
+        a, b = clean.step(torch.tensor(u[:, t]), S), dirty.step(torch.tensor(ud[:, t]), S)
+        keep = [e for e in range(B) if e != 4]
+        assert torch.equal(a["q"][keep], b["q"][keep]) and torch.equal(a["tactile"][keep], b["tactile"][keep])
+        st = b["status"].cpu().numpy()
+        assert all(st[e] == 0 for e in keep)
+        assert bool(st[4] & (1 << 30)) == (t == 1)           # flagged in the launch that received it, not silently clamped
