@@ -86,3 +86,63 @@ def test_capture_hook_runs_against_the_shim_and_the_consumer_reads_it(tmp_path, 
     assert g["q"].shape == (100, 7) and g["var"].shape == (100, 6) and g["tactile"].shape == (100, 390) and g["df_du"].shape == (500, 6)
     assert np.abs(g["tactile"]).max() > 1e-3 and np.abs(g["df_du"]).max() > 0
     _check(g, *_run_oracle(g, pusher_model), label="oracle vs shim capture")
+
+
+# ------------------------------------------------------------------------------------------------ RollingBall (tactile_pad.xml)
+GOLDEN_PAD = os.path.join(ROOT, "tests", "golden", "diffhand_tactile_pad.npz")
+needs_golden_pad = pytest.mark.skipif(not os.path.exists(GOLDEN_PAD), reason="PARITY UNPINNED: tests/golden/diffhand_tactile_pad.npz absent "
+                                      "(run tools/capture_diffhand_golden.py --model tactile_pad against a DiffRedMax build)")
+
+
+def _pad_model():
+    from tactilesimulation_amd.model.compiler import load_model
+    return load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "tactile_pad.npz"))
+
+
+def _check_pad(g, q, kept, tsum, nonzero, label):
+    """q over the whole roll (the ball's path is smooth: no kinks to amplify the Newton tolerance), tactile on the kept taxels and
+    the sums over all 40 000; the number of loaded taxels may differ by the few on the rim of the contact patch."""
+    assert np.abs(q - g["q"]).max() < 1e-5 * max(1.0, np.abs(g["q"]).max()), label
+    sc = max(np.abs(g["tactile_kept"]).max(), np.abs(g["tactile_sum"]).max() / 100.0, 1e-9)
+    assert np.abs(kept - g["tactile_kept"]).max() < 2e-2 * sc, label
+    assert np.abs(tsum - g["tactile_sum"]).max() < 2e-2 * np.abs(g["tactile_sum"]).max(), label
+    assert np.abs(nonzero - g["tactile_nonzero"]).max() <= max(8, 0.02 * g["tactile_nonzero"].max()), label
+
+
+def _run_pad_oracle(g, model):
+    from oracle.oracle import OracleSim
+    o = OracleSim(model); o.reset(np.zeros(model.ndof_r))
+    n, keep = len(g["u"]), g["kept_taxels"]
+    q = np.zeros_like(g["q"]); kept = np.zeros_like(g["tactile_kept"]); tsum = np.zeros_like(g["tactile_sum"]); nz = np.zeros_like(g["tactile_nonzero"])
+    for i in range(n):
+        o.forward(g["u"][i], 1)
+        q[i] = o.state()[0]
+        if i % 5 == 0:
+            tac = o.outputs()[1].reshape(-1, 3)
+            kept[i // 5], tsum[i // 5], nz[i // 5] = tac[keep], tac.sum(0), int((np.abs(tac).max(1) > 0).sum())
+    return q, kept, tsum, nz
+
+
+@needs_golden_pad
+def test_oracle_matches_diffredmax_golden_rolling_ball():
+    g = np.load(GOLDEN_PAD)
+    m = _pad_model()
+    assert "SHIM" not in str(g["source"]), "the committed file is a shim self-test, not a DiffRedMax capture"
+    assert list(g["dims"]) == [m.ndof_r, m.ndof_u, 0, m.ndof_tactile] and abs(float(g["h"]) - m.h) < 1e-15
+    _check_pad(g, *_run_pad_oracle(g, m), label="oracle vs DiffRedMax (RollingBall)")
+
+
+@pytest.mark.gpu
+def test_capture_hook_rolling_ball_against_the_shim(tmp_path):
+    """Self-test of the tactile_pad hook (NOT parity): runs unmodified against the shim (fp64 kernels), the record stays small, and
+    the consumer accepts it against the oracle.  With a real capture committed, the same consumer pins BDF2 start-up, the
+    rotation-vector joint and the 200 x 200 pad."""
+    out = str(tmp_path / "shim_pad.npz")
+    xml = os.path.join(ROOT, "tactilesimulation_amd", "assets", "tactile_pad.npz")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "capture_diffhand_golden.py"), "--shim", "--model", "tactile_pad",
+                           "--xml", xml, "--out", out])
+    assert os.path.getsize(out) < 400 * 1024
+    g = np.load(out)
+    assert "SHIM" in str(g["source"]) and g["q"].shape == (350, 9) and g["tactile_kept"].shape == (70, 1082, 3)
+    assert g["tactile_nonzero"].max() > 100 and list(g["image_pos_first_last"][1]) == [199, 199]
+    _check_pad(g, *_run_pad_oracle(g, _pad_model()), label="oracle vs shim capture (RollingBall)")

@@ -5,9 +5,10 @@ The reference's simulator source is an un-vendored submodule (`externals/DiffHan
 parity is UNPINNED until someone with a DiffHand build runs this script once:
 
     cd <TactileSimulation checkout with externals/DiffHand built>      # README.md:29-34 "Install DiffRedMax"
-    python /path/to/tools/capture_diffhand_golden.py --xml envs/assets/pusher/pusher.xml --out diffhand_pusher.npz
+    python /path/to/tools/capture_diffhand_golden.py --model pusher        # -> diffhand_pusher.npz
+    python /path/to/tools/capture_diffhand_golden.py --model tactile_pad   # -> diffhand_tactile_pad.npz (RollingBall, forward only)
 
-and commits the result as `tests/golden/diffhand_pusher.npz` (< 400 KB).  `tests/test_diffhand_golden.py` then compares
+and commits the results as `tests/golden/diffhand_pusher.npz` / `diffhand_tactile_pad.npz` (< 400 KB each).  `tests/test_diffhand_golden.py` then compares
 the fp64 oracle and the fp64 HIP kernels with it (it skips while the file is absent).  What is recorded, exactly as
 SURVEY.md §8c lists it: TactilePush model, q0 = get_q_init() with q[1] = -0.001, q[4] = 0.01
 (envs/tactile_push_env.py:134-136), a fixed closed-form 100 x 6 action table (no RNG: independent of numpy versions),
@@ -80,10 +81,56 @@ def capture(redmax, xml, source):
     return out
 
 
+TAXEL_STRIDE = 37        # tactile_pad: every 37th of the 40 000 taxels is kept in full (1 082 taxels), plus sums over all of them
+
+
+def pad_actions():
+    """examples/RollingBallExp/test_sim_speed.py:43-48, verbatim as data: 350 actions."""
+    acts = [[0, 0, .2]] * 100 + [[.1, 0, .2]] * 50 + [[-.2, 0, .2]] * 50 + [[0, .1, .2]] * 50 + [[0, -.2, .2]] * 100
+    return np.asarray(acts, dtype=np.float64)
+
+
+def capture_pad(redmax, xml, source):
+    """RollingBall (BASELINE configs[0]): assets/tactile_pad/tactile_pad.xml — BDF2, free3d-exp sphere, 200 x 200 taxels — driven as
+    test_sim_speed.py:63-81 drives it: reset(False), 350 x (set_u, forward(1)), tactile read-out every 5th step.  Forward only (the
+    reference never differentiates this model).  Pins the [CHOICE] items the pusher cannot: BDF2 start-up, the rotation-vector joint,
+    the sphere-on-plane contact point and the taxel frame of a 40 000-taxel pad.  Per read-out: the kept taxels in full, the sum of
+    all forces, the number of taxels with a non-zero force and the index of the largest normal force."""
+    sim = redmax.Simulation(xml)
+    nr, nu, nt = sim.ndof_r, sim.ndof_u, sim.ndof_tactile
+    sim.reset(False)
+    A = pad_actions()
+    assert A.shape[1] == nu, "model has ndof_u = %d" % nu
+    n = len(A)
+    reads = list(range(0, n, 5))
+    keep = np.arange(0, nt // 3, TAXEL_STRIDE)
+    out = {"q": np.zeros((n, nr)), "qdot": np.zeros((n, nr)), "tactile_kept": np.zeros((len(reads), len(keep), 3)),
+           "tactile_sum": np.zeros((len(reads), 3)), "tactile_nonzero": np.zeros(len(reads), dtype=np.int64),
+           "tactile_argmax": np.zeros(len(reads), dtype=np.int64)}
+    for i in range(n):
+        sim.set_u(A[i].copy())
+        sim.forward(1, verbose=False, test_derivatives=False)
+        out["q"][i] = np.array(sim.get_q()).copy()
+        out["qdot"][i] = np.array(sim.get_qdot()).copy()
+        if i % 5 == 0:
+            tac = np.array(sim.get_tactile_force_vector(), dtype=np.float64).reshape(-1, 3)
+            k = i // 5
+            out["tactile_kept"][k] = tac[keep]
+            out["tactile_sum"][k] = tac.sum(0)
+            out["tactile_nonzero"][k] = int((np.abs(tac).max(1) > 0).sum())
+            out["tactile_argmax"][k] = int(np.argmax(np.abs(tac[:, 2])))
+    pos = sim.get_tactile_image_pos("pad")
+    out.update({"u": A, "reads": np.array(reads), "kept_taxels": keep, "h": np.float64(sim.options.h), "dims": np.array([nr, nu, 0, nt], dtype=np.int64),
+                "image_pos_first_last": np.array([pos[0], pos[-1]], dtype=np.int64), "source": np.array(source)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--xml", default="envs/assets/pusher/pusher.xml")
-    ap.add_argument("--out", default="diffhand_pusher.npz")
+    ap.add_argument("--model", default="pusher", choices=["pusher", "tactile_pad"],
+                    help="pusher: SURVEY 8c's TactilePush record with gradients; tactile_pad: the RollingBall test_sim_speed sequence (forward)")
+    ap.add_argument("--xml", default=None, help="default: envs/assets/pusher/pusher.xml or assets/tactile_pad/tactile_pad.xml")
+    ap.add_argument("--out", default=None, help="default: diffhand_<model>.npz")
     ap.add_argument("--shim", action="store_true", help="use this repository's redmax_py shim (hook self-test; not a golden vector)")
     a = ap.parse_args()
     if a.shim:
@@ -97,8 +144,10 @@ def main():
         if "tactilesimulation_amd" in (getattr(redmax, "__file__", "") or ""):
             raise SystemExit("this is the shim, not DiffRedMax: pass --shim for a self-test, or fix PYTHONPATH")
         source = "DiffRedMax redmax_py " + str(getattr(redmax, "__version__", "(no version attribute)"))
-    np.savez_compressed(a.out, **capture(redmax, a.xml, source))
-    print("wrote", a.out, os.path.getsize(a.out), "bytes;", source)
+    xml = a.xml or {"pusher": "envs/assets/pusher/pusher.xml", "tactile_pad": "assets/tactile_pad/tactile_pad.xml"}[a.model]
+    out = a.out or "diffhand_%s.npz" % a.model
+    np.savez_compressed(out, **(capture if a.model == "pusher" else capture_pad)(redmax, xml, source))
+    print("wrote", out, os.path.getsize(out), "bytes;", source)
 
 
 if __name__ == "__main__":
