@@ -523,6 +523,11 @@ static int substep(Sim& S, const double* u) {
     if (it == m.max_iter) break;
     for (int k = 0; k < nr; ++k) g[k] = -g[k];
     if (!solve_dense(nr, H, g, dq, false)) break;
+    {                                            // trust region (include/tsim_blob.h TSIM_STEP_MAX)
+      double mx = 0.0;
+      for (int k = 0; k < nr; ++k) mx = std::max(mx, std::fabs(dq[k]));
+      if (mx > TSIM_STEP_MAX) for (int k = 0; k < nr; ++k) dq[k] *= TSIM_STEP_MAX / mx;
+    }
     // Globalisation: backtracking on ||g||. ||g|| has non-smooth local minima next to contact / friction
     // kinks where no short step along the Newton direction reduces it; there the full Newton step is taken anyway (it
     // lands across the kink, from where the iteration normally converges in two or three steps).  A sub-step that needs

@@ -58,6 +58,8 @@ __device__ __forceinline__ void t_sincos(float x, float& s, float& c) { sincosf(
 __device__ __forceinline__ void t_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
 __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double t_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float t_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double t_max(double a, double b) { return fmax(a, b); }
 
 // ------------------------------------------------------------------------------------------------ 3-vectors / 3x3
 template <class T> struct V3 { T x, y, z; };
@@ -259,6 +261,17 @@ template <int LPE, class R> __device__ __forceinline__ R seg_sum(R x) {
   x += dpp_r<0x142, 0xa>(x);   // row_bcast:15    -> rows 1 and 3 add the total of the row below
   x += dpp_r<0x143, 0xc>(x);   // row_bcast:31    -> rows 2 and 3 add the total of rows 0-1; lane 63 has the sum
   return lane_bcast(x, 63);
+}
+// maximum over the LPE lanes of the caller's slot, result in every lane of the slot (x >= 0)
+template <int LPE, class R> __device__ __forceinline__ R seg_max(R x) {
+  x = t_max(x, dpp_r<0xB1, 0xf>(x));
+  x = t_max(x, dpp_r<0x4E, 0xf>(x));
+  x = t_max(x, dpp_r<0x141, 0xf>(x));
+  x = t_max(x, dpp_r<0x140, 0xf>(x));
+  if (LPE == 16) return x;
+  if (LPE == 32) return t_max(x, lane_gather(x, (int)threadIdx.x ^ 16));
+  x = t_max(x, lane_gather(x, (int)threadIdx.x ^ 16));
+  return t_max(x, lane_gather(x, (int)threadIdx.x ^ 32));
 }
 // value of x in lane src (inside the slot; the same for all lanes of a slot) of the caller's slot
 template <int LPE, class R> __device__ __forceinline__ R seg_bcast(R x, int src) {

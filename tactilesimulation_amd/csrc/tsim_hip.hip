@@ -208,6 +208,11 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
       TS_SYNC();
       if (__any(solve)) {
         solve_lanes<R, NRM, LPE, double>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+        {                                      // trust region of the Newton step (include/tsim_blob.h TSIM_STEP_MAX): inactive unless the step is wild
+          const R m = seg_max<LPE>(lane < nr ? t_abs(c.dq[lane]) : R(0));
+          if (solve && lane < nr && m > R(TSIM_STEP_MAX)) c.dq[lane] *= R(TSIM_STEP_MAX) / m;
+          TS_SYNC();
+        }
         if (solve) {
           alpha = R(1); ls = 0;
           if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];

@@ -14,7 +14,10 @@ def _parse_header(path):
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     consts = {}
     for m in re.finditer(r"^#define[ \t]+(TSIM_\w+)[ \t]+(\S+)", txt, flags=re.M):
-        consts[m.group(1)] = int(m.group(2), 0)
+        try:
+            consts[m.group(1)] = int(m.group(2), 0)
+        except ValueError:
+            consts[m.group(1)] = float(m.group(2))          # e.g. TSIM_STEP_MAX
     for m in re.finditer(r"enum\s*\{(.*?)\}", txt, flags=re.S):
         val = -1
         for item in m.group(1).split(","):

@@ -1,0 +1,42 @@
+"""TactileInsertion at the per-GPU batch of BASELINE configs[4] (B = 4096, 14 x 5 sub-steps, grasp-and-drag inputs): how many sub-steps
+end above the Newton tolerance in the fp32 / fp64 kernels, and how far the flagged fp32 rows are from the fp64 ones."""
+import os, sys, json
+import numpy as np, torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_gpu_models import _inputs
+from tactilesimulation_amd.host.batch import BatchSim
+from tactilesimulation_amd.model.compiler import load_model
+from tactilesimulation_amd.workloads import asset
+B, T, S = 4096, 14, 5
+m = load_model(asset("tactile_insertion"))
+q0, u = _inputs("tactile_insertion", m, B, T)
+res = {}
+ro = {}
+for dt in (torch.float32, torch.float64):
+    sim = BatchSim(m, B, dtype=dt, tape_capacity=0)
+    sim.reset(torch.tensor(q0, device="cuda", dtype=dt), None, backward_flag=False)
+    U = torch.tensor(u, device="cuda", dtype=dt).transpose(0, 1).contiguous()
+    per_step = []
+    for t in range(T):
+        o = sim.step(U[t], S)
+        per_step.append(o["status"].clone())
+    st = torch.stack(per_step)                 # [T, B] non-converged sub-steps per env-step
+    ro[dt] = o["q"].double().clone()
+    tot = st.sum(0)
+    res[str(dt)[6:]] = {"envs_flagged": int((tot != 0).sum()), "substeps_flagged": int(tot.sum()), "of_substeps": B * T * S,
+                        "max_per_env": int(tot.max()), "by_env_step": [int(x) for x in (st != 0).sum(1).cpu()]}
+    if dt == torch.float32: flagged = tot != 0
+d = (ro[torch.float32] - ro[torch.float64]).abs().max(1).values
+res["q_fp32_vs_fp64_final"] = {"flagged_max": float(d[flagged].max()) if int(flagged.sum()) else 0.0, "unflagged_max": float(d[~flagged].max()), "unflagged_median": float(d[~flagged].median())}
+print(json.dumps(res, indent=1))
+big = torch.nonzero(d > 1e-3).reshape(-1).cpu().numpy()
+print("envs with |q32 - q64| > 1e-3:", len(big), big[:12], "q64:", [float(ro[torch.float64][e].abs().max()) for e in big[:6]], "q32:", [float(ro[torch.float32][e].abs().max()) for e in big[:6]])
+from oracle.oracle import OracleSim
+for e in list(big[:3]):
+    o = OracleSim(m); o.reset(q0[e])
+    sim = BatchSim(m, 1, dtype=torch.float64, tape_capacity=0); sim.reset(torch.tensor(q0[e:e+1], device="cuda"), None, backward_flag=False)
+    for t in range(T):
+        rc = o.forward(u[e, t], S)
+        g = sim.step(torch.tensor(u[e:e+1, t], device="cuda"), S)
+        q = o.state()[0]
+        print("env", int(e), "t", t, "oracle nonconv", rc, "kernel64 status", int(g["status"][0]), "|q| oracle %.4g kernel %.4g diff %.3g" % (np.abs(q).max(), float(g["q"].abs().max()), np.abs(q - g["q"][0].cpu().numpy()).max()), flush=True)
