@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per episode")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--save-best", default=None, help="torch.save the best policy (lowest loss, as algorithms/gd.py:187-189 keeps it) here")
     args = ap.parse_args()
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -75,6 +76,8 @@ def main():
     rng = np.random.default_rng(args.seed + 1000 * rank)
     q0, goal, dist_ = draw_episode(rng, B, T, dev, dtype)
     gr = None if args.eager else GraphedRollout(env, actor, T, q0, goal, dist_)
+    best = (float("inf"), -1, None)
+    prev_state = {k: v.detach().clone() for k, v in actor.state_dict().items()}
     for epoch in range(args.epochs):
         if args.lr_schedule == "linear":                           # gd.py:146-149
             for g in opt.param_groups:
@@ -88,13 +91,20 @@ def main():
             loss = float(train_epoch_graphed(gr, opt, B * world, grad_clip=args.grad_clip).detach()) / B
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         curve.append({"epoch": epoch, "loss_per_episode": loss, "ms": dt * 1e3, "lr": opt.param_groups[0]["lr"]})
+        if loss < best[0]:                                             # gd.py:187-189: keep the best policy, not the last
+            # (the loss of epoch e belongs to the parameters BEFORE that epoch's update)
+            best = (loss, epoch, prev_state)
+        prev_state = {k: v.detach().clone() for k, v in actor.state_dict().items()}
         if rank == 0:
             print("epoch %3d  loss/episode (rank 0) %10.3f  %6.1f ms  %.2f M env-steps/s (all ranks)" % (epoch, loss, dt * 1e3, B * T * world / dt / 1e6), flush=True)
     if rank == 0 and args.log:
         import json
-        json.dump({"args": vars(args), "world": world, "curve": curve,
+        json.dump({"args": vars(args), "world": world, "curve": curve, "best": {"loss_per_episode": best[0], "epoch": best[1]},
                    "note": "loss = -sum of rewards / episodes of rank 0's batch; every epoch draws new goals, offsets and disturbances"},
                   open(args.log, "w"), indent=1)
+    if rank == 0 and args.save_best and best[2] is not None:
+        torch.save({"actor": best[2], "loss_per_episode": best[0], "epoch": best[1]}, args.save_best)
+        print("best policy: epoch %d, loss/episode %.3f -> %s" % (best[1], best[0], args.save_best))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
