@@ -308,7 +308,7 @@ template <class R> struct Ctx {
   long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
   mutable int nstamp;
 };
-#ifdef TS_FINE_STAMPS      // A/B builds only (tools/gpu_fine_stamps.sh): extra stamps inside the phases
+#ifdef TS_FINE_STAMPS      // A/B builds only (tools/fine_stamps.py): extra stamps inside the phases
 #define TS_STAMP2(c) TS_STAMP(c)
 #else
 #define TS_STAMP2(c) do { } while (0)
@@ -375,9 +375,8 @@ template <class C> __device__ __forceinline__ const int* ts_motor_rec(const C& c
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
 template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, bool stage_cpt, const R* Fenv = nullptr) {
-  // Stage the model's FLOAT tables in LDS (link / dof / motor / pair / sensor records): later reads are ds_read
-  // broadcasts instead of ~500-cycle global loads.  The INT tables stay in global memory on purpose: they are
-  // wave-uniform, so they travel through the scalar cache and all indexing / control flow stays on the SALU.
+  // Stage the model's tables in LDS — the float records (link / dof / motor / pair / sensor), the sweep schedule and the whole
+  // int blob: later reads are ds_read broadcasts instead of ~500-cycle global loads (a lone wavefront cannot hide those).
   const int nfrec = I[TSIM_IH_FOFF_CPT];
   {
     R* mf = lds;
