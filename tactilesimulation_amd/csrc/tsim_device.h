@@ -486,6 +486,18 @@ __host__ __device__ inline unsigned ts_sig_mix(unsigned group, unsigned index, u
 // xh: the same point in double — the signed distance (a small difference of large numbers) is taken from it.
 // branch (diagnostics, tsim_debug_signature): which smooth piece of the law the point is on — bit 0 = sticking, bits 1.. =
 // face of the primitive (cuboid: 2 axis + (negative side); cylinder: 0 side, 1 / 2 caps; plane, sphere: 0).
+// Signed distance of a point to a primitive in the kernel's own precision: a cheap "certainly outside" test in front of contact_law
+// (which measures the distance from a double-precision position): callers skip points whose R-precision distance exceeds
+// TS_FAR_MARGIN, far more than the rounding of an R-precision pose product, so the set of points contact_law accepts is unchanged.
+#define TS_FAR_MARGIN 1e-4
+template <class R>
+__device__ __forceinline__ R prim_distance(int prim, const R* shape, V3<R> x) {
+  if (prim == TSIM_P_PLANE) return x.z;
+  if (prim == TSIM_P_CUBOID) return t_max(t_abs(x.x) - shape[0], t_max(t_abs(x.y) - shape[1], t_abs(x.z) - shape[2]));
+  if (prim == TSIM_P_SPHERE) return t_sqrt(dot3(x, x)) - shape[0];
+  return t_max(t_sqrt(x.x * x.x + x.y * x.y) - shape[0], t_abs(x.z) - shape[1]);        // cylinder: inside iff both are negative
+}
+
 template <class R, bool JAC>
 __device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv, V3<double> xh, int* branch = nullptr) {
   const R kn = kp[0], kt = kp[1], mu = kp[2], kd = kp[3];

@@ -70,6 +70,9 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
           const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
           const R* S = c.PP + (j - j0) * PP_SIZE;
           const M3<R> RPA = ldm(S + PP_RPA);
+          // fp32 kernels: most taxels of a large pad are nowhere near the primitive; decide that from an fp32 position and
+          // skip the double-precision one (a 64-taxel chunk of the 200 x 200 pad is usually all-far: the branch is uniform)
+          if (sizeof(R) == 4 && !(prim_distance<R>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, mulMv(RPA, xa) + ldv(S + PP_PPA)) < R(TS_FAR_MARGIN))) continue;
           const V3<double> xPd = mulMv(ldm(c.PPd + (j - j0) * 12), cvt3<double>(xa)) + ldv(c.PPd + (j - j0) * 12 + 9);
           const V3<R> xP = cvt3<R>(xPd);
           V3<R> F; M3<R> Jx, Jv;
