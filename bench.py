@@ -473,7 +473,7 @@ def readout_leg(tdt, dev, B=256, reps=5):
     ms = min(e[i].elapsed_time(e[i + 1]) for i in range(reps))
     esz = 4 if tdt == torch.float32 else 8
     written = B * sim.ndof_tactile * esz
-    return {"kernel": "k_readout", "workload": "RollingBall tactile_pad.xml, 200 x 200 taxels, %d environments" % B, "ms": ms,
+    return {"kernel": "k_readout + k_taxels (tsim_readout)", "workload": "RollingBall tactile_pad.xml, 200 x 200 taxels, %d environments" % B, "ms": ms,
             "bytes_written": written, "achieved": written / (ms * 1e-3) / 1e9, "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "frac": written / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "taxels_in_contact_max": int((tac.reshape(B, -1, 3)[:, :, 2] != 0).sum(1).max().item())}
 

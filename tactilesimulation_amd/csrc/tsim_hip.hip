@@ -70,9 +70,6 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
           const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
           const R* S = c.PP + (j - j0) * PP_SIZE;
           const M3<R> RPA = ldm(S + PP_RPA);
-          // fp32 kernels: most taxels of a large pad are nowhere near the primitive; decide that from an fp32 position and
-          // skip the double-precision one (a 64-taxel chunk of the 200 x 200 pad is usually all-far: the branch is uniform)
-          if (sizeof(R) == 4 && !(prim_distance<R>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, mulMv(RPA, xa) + ldv(S + PP_PPA)) < R(TS_FAR_MARGIN))) continue;
           const V3<double> xPd = mulMv(ldm(c.PPd + (j - j0) * 12), cvt3<double>(xa)) + ldv(c.PPd + (j - j0) * 12 + 9);
           const V3<R> xP = cvt3<R>(xPd);
           V3<R> F; M3<R> Jx, Jv;
@@ -289,8 +286,18 @@ __global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* 
   }
 }
 
-// ================================================================================================ read-out kernel
-template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R *var_out, *tac_out; int slice; int stage_cpt; };
+// ================================================================================================ read-out kernels
+// get_variables / get_tactile_force_vector on demand (tsim_readout), in two launches:
+//   k_readout   one wavefront per environment: forward kinematics from the taped state, the end-effector variables, and — for the
+//               taxel kernel — the pose record of every (sensor, primitive) combination: pose of the sensor link in the primitive's
+//               frame (R precision and double) and the relative twist there (what pair_stage_value stages in LDS for the in-kernel
+//               read-out of k_forward);
+//   k_taxels    lanes = taxels, nothing else: 3 position constants, an fp32 "certainly outside" test, the double-precision position,
+//               the penalty law, 12 B out (the 9 axis constants only where a force acts).  ~40 registers instead of the 178 the
+//               kinematics need, so 8+ wavefronts per SIMD cover the L2 latency of the constants: this is the one kernel of the path
+//               whose time is memory traffic (RollingBall: 40 000 taxels, 480 KB per environment and read-out).
+enum { TP_R_SIZE = 18, TP_D_SIZE = 12 };
+template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R* var_out; R* poseR; double* poseD; int nspt; int stage_cpt; };
 
 template <class R>
 __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
@@ -304,9 +311,92 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   if (lane < nr) { c.qD[lane] = rec_q(st)[lane]; c.q[lane] = (R)c.qD[lane]; c.qd[lane] = st[rec_qd<R>(nr) + lane]; c.qa[lane] = R(0); }
   TS_SYNC();
   phase1<R, false, true>(c, lane, R(0), R(0), R(0));
-  // high-resolution sensors (RollingBall: 40 000 taxels): blockIdx.y selects a slice of the taxels, so one
-  // environment's read-out spreads over many CUs; 12 B/lane contiguous stores, SoA coalesced loads
-  readout<TS_WAVE>(c, lane, env, true, true, blockIdx.y == 0 && a.var_out != nullptr, a.tac_out != nullptr, a.var_out, a.tac_out, (int)blockIdx.y * a.slice, ((int)blockIdx.y + 1) * a.slice);
+  readout<TS_WAVE>(c, lane, env, true, false, a.var_out != nullptr, false, a.var_out, (R*)nullptr);       // variables only
+  if (!a.poseR) return;
+  int k = 0;
+  for (int s = 0; s < c.nsensor; ++s) {
+    const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
+    for (int j = 0; j < si[TSIM_SI_NSPRIM]; ++j, ++k) {
+      TS_SYNC();
+      pair_stage_value(c, c.I[c.off_sprim + si[TSIM_SI_SPRIM0] + j], 0, lane == 0);
+      TS_SYNC();
+      const size_t rec = (size_t)env * a.nspt + k;
+      if (lane < TP_R_SIZE) a.poseR[rec * TP_R_SIZE + lane] = c.PP[lane];          // PP_RPA (9), PP_PPA (3), PP_WREL (3), PP_VREL (3)
+      if (lane < TP_D_SIZE) a.poseD[rec * TP_D_SIZE + lane] = c.PPd[lane];
+    }
+  }
+}
+
+template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int fstride; const R* poseR; const double* poseD; int nspt; R* tac_out; int slice; };
+
+// Per-block staging of everything k_taxels needs that does not depend on the taxel: the block works on ONE environment, so the sensor
+// ranges, the primitive of every (sensor, primitive) record with its shape, the sensors' penalty parameters and the pose records are
+// put in LDS once; inside the taxel loop the only global accesses left are the taxel's own constants and its 12 output bytes.  (Read
+// from global memory in the loop they are chains of dependent ~600-cycle loads — index -> record -> value — and the loop was exactly
+// that latency: 55 us for 256 x 40 000 taxels.)
+enum { TX_MAXS = 8, TX_MAXK = 24 };
+template <class R>
+__global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
+  const int env = blockIdx.x;
+  const int* I = a.I;
+  const R* F = a.Fenv ? a.Fenv + (size_t)env * a.fstride : a.F;        // this environment's float records (domain randomisation)
+  const int ntax = I[TSIM_IH_NTAXEL], nsensor = I[TSIM_IH_NSENSOR];
+  __shared__ int sEnd[TX_MAXS], sKb[TX_MAXS], sNsp[TX_MAXS], sPrim[TX_MAXK];
+  __shared__ R sSf[TX_MAXS * TSIM_SF_SIZE], sShape[TX_MAXK * 4], sP[TX_MAXK * TP_R_SIZE];
+  __shared__ double sD[TX_MAXK * TP_D_SIZE];
+  {
+    const int off_sensor = I[TSIM_IH_OFF_SENSOR], off_sprim = I[TSIM_IH_OFF_SPRIM], off_pair = I[TSIM_IH_OFF_PAIR];
+    const int foff_sensor = I[TSIM_IH_FOFF_SENSOR], foff_pair = I[TSIM_IH_FOFF_PAIR];
+    if (threadIdx.x == 0) {
+      int kb = 0;
+      for (int s = 0; s < nsensor; ++s) {
+        const int* si = I + off_sensor + s * TSIM_SI_SIZE;
+        sEnd[s] = si[TSIM_SI_TAX0] + si[TSIM_SI_NTAX]; sKb[s] = kb; sNsp[s] = si[TSIM_SI_NSPRIM];
+        for (int j = 0; j < si[TSIM_SI_NSPRIM]; ++j) {
+          const int pk = I[off_sprim + si[TSIM_SI_SPRIM0] + j];
+          sPrim[kb + j] = I[off_pair + pk * TSIM_PI_SIZE + TSIM_PI_PRIM];
+          for (int e = 0; e < 4; ++e) sShape[(kb + j) * 4 + e] = F[foff_pair + pk * TSIM_PF_SIZE + TSIM_PF_SHAPE + e];
+        }
+        kb += si[TSIM_SI_NSPRIM];
+      }
+    }
+    for (int i = threadIdx.x; i < nsensor * TSIM_SF_SIZE; i += 256) sSf[i] = F[foff_sensor + i];
+    for (int i = threadIdx.x; i < a.nspt * TP_R_SIZE; i += 256) sP[i] = a.poseR[(size_t)env * a.nspt * TP_R_SIZE + i];
+    for (int i = threadIdx.x; i < a.nspt * TP_D_SIZE; i += 256) sD[i] = a.poseD[(size_t)env * a.nspt * TP_D_SIZE + i];
+    __syncthreads();
+  }
+  const R* tax = a.F + I[TSIM_IH_FOFF_TAXEL];                          // SoA planes: position (3), axis0, axis1, normal (9); shared
+  R* out = a.tac_out + (size_t)env * 3 * ntax;
+  const int te = min(ntax, ((int)blockIdx.y + 1) * a.slice);
+  for (int t = (int)blockIdx.y * a.slice + (int)threadIdx.x; t < te; t += 256) {
+    int s = 0;                                                         // sensor of taxel t
+    while (s < nsensor - 1 && t >= sEnd[s]) ++s;
+    const int kb = sKb[s], nsp = sNsp[s];
+    const R* sf = sSf + s * TSIM_SF_SIZE;
+    const R* tp = tax + t;
+    const V3<R> xa = mk3<R>(tp[0], tp[ntax], tp[2 * ntax]);
+    V3<R> Fl = zero3<R>();                                             // force on the taxel, sensor-link frame
+    for (int j = 0; j < nsp; ++j) {
+      const int prim = sPrim[kb + j];
+      const R* shape = sShape + (kb + j) * 4;
+      const R* P = sP + (kb + j) * TP_R_SIZE;
+      const double* D = sD + (kb + j) * TP_D_SIZE;
+      const M3<R> RPA = ldm(P);
+      // fp32 kernels: most taxels of a large pad are nowhere near the primitive; decide that from an fp32 position
+      if (sizeof(R) == 4 && !(prim_distance<R>(prim, shape, mulMv(RPA, xa) + ldv(P + 9)) < R(TS_FAR_MARGIN))) continue;
+      const V3<double> xPd = mulMv(ldm(D), cvt3<double>(xa)) + ldv(D + 9);
+      const V3<R> xP = cvt3<R>(xPd);
+      V3<R> Fc; M3<R> Jx, Jv;
+      if (contact_law<R, false>(prim, shape, sf, xP, ldv(P + 15) + cross3(ldv(P + 12), xP), Fc, Jx, Jv, xPd)) Fl = Fl + mulMtv(RPA, Fc);
+    }
+    R o0 = R(0), o1 = R(0), o2 = R(0);
+    if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {                // the nine axis constants only for taxels that carry a force
+      o0 = Fl.x * tp[3 * ntax] + Fl.y * tp[4 * ntax] + Fl.z * tp[5 * ntax];
+      o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
+      o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
+    }
+    out[3 * t] = o0; out[3 * t + 1] = o1; out[3 * t + 2] = o2;
+  }
 }
 
 // ================================================================================================ branch signature
@@ -689,6 +779,7 @@ struct tsim_batch {
   int* evals;                    // residual evaluations of the last forward launch, per env
   int* order; int order_valid;   // block -> env map for the next forward launch (LPT scheduling)
   void* prev; int has_prev;      // BDF2: state before the previous sub-step [B][2 nr]
+  void* poseR; double* poseD; int nspt;   // tsim_readout: pose records [B][nspt] of the (sensor, primitive) combinations (k_readout -> k_taxels)
   int has_exp;                   // model contains a rotation-vector joint
   int t_cur, record;
   int lpe_forced;                // lanes per environment forced by TSIM_LPE (0 = choose from the batch size)
@@ -936,11 +1027,12 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
     const int lpe0 = launch_shape(b).lpe;
     b->stage_cpt = 1;
     if (launch_shape(b).lpe != lpe0) b->stage_cpt = 0;
-  } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0;
+  } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0; b->poseR = nullptr; b->poseD = nullptr; b->nspt = b->I[TSIM_IH_NSPRIM];
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess) {
+      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
+      (b->nspt > 0 && (hipMalloc(&b->poseR, (size_t)B * b->nspt * TP_R_SIZE * b->esz) != hipSuccess || hipMalloc((void**)&b->poseD, (size_t)B * b->nspt * TP_D_SIZE * sizeof(double)) != hipSuccess))) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
   }
@@ -956,7 +1048,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   DeviceGuard guard_(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
   for (void* p : b->pool) (void)hipFree(p);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->order); (void)hipFree(b->prev);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->order); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD);
   delete b;
 }
 
@@ -1066,20 +1158,28 @@ int tsim_get_state(tsim_batch* b, void* q_out, void* qd_out, void* stream) {
 
 int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   TS_DEVICE(b);
-  // taxels per block: every block repeats the environment's forward kinematics (~8 k cycles) before its taxels (~1 k cycles per 64), so
-  // slices should not be short — but a single environment with 40 000 taxels (RollingBall as the reference runs it) wants many blocks,
-  // and large batches want several blocks per SIMD to balance.  Aim at ~8192 blocks in all: 256 taxels per block for B = 1 .. 50 (157
-  // blocks per environment: 14.6 us per read-out instead of 25 with fixed 1024-taxel slices), 1 280 for B = 256, 5 056 for B = 1024.
+  hipStream_t st = (hipStream_t)stream;
+  const bool tac = tac_out && b->ntax > 0 && b->nspt > 0;
+  if (tac && (b->nspt > TX_MAXK || b->I[TSIM_IH_NSENSOR] > TX_MAXS)) return fail("readout: more than " + std::to_string((int)TX_MAXK) + " (sensor, primitive) combinations or " + std::to_string((int)TX_MAXS) + " sensors (k_taxels staging)");
+  // taxels per block of k_taxels: aim at ~8192 blocks in all (several per SIMD at any batch size): 256 for the single environment of
+  // test_sim_speed.py (157 blocks for its 40 000 taxels), 1 280 for B = 256
   const long long want = ((long long)b->ntax * b->B + 8191) / 8192;
-  const int slice = (int)std::max<long long>(256, (want + 63) / 64 * 64);
-  const int ny = tac_out ? (b->ntax + slice - 1) / slice : 1;
-  dim3 grid(b->B, ny > 0 ? ny : 1);
+  const int slice = (int)std::max<long long>(256, (want + 255) / 256 * 256);
+  const dim3 tgrid(b->B, tac ? (b->ntax + slice - 1) / slice : 1);
   if (b->dtype == TSIM_F32) {
-    ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, (float*)tac_out, slice, b->stage_cpt};
-    hipLaunchKernelGGL(k_readout<float>, grid, dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
+    ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, tac ? (float*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
+    hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
+    if (tac) {
+      TaxArgs<float> t{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, (const float*)b->poseR, b->poseD, b->nspt, (float*)tac_out, slice};
+      hipLaunchKernelGGL(k_taxels<float>, tgrid, dim3(256), 0, st, t);
+    }
   } else {
-    ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, (double*)tac_out, slice, b->stage_cpt};
-    hipLaunchKernelGGL(k_readout<double>, grid, dim3(TS_WAVE), lds_bytes_for(b, 1), (hipStream_t)stream, a);
+    ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, tac ? (double*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
+    hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
+    if (tac) {
+      TaxArgs<double> t{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, (const double*)b->poseR, b->poseD, b->nspt, (double*)tac_out, slice};
+      hipLaunchKernelGGL(k_taxels<double>, tgrid, dim3(256), 0, st, t);
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;
