@@ -593,16 +593,27 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
 #pragma unroll
       for (int e = 0; e < 12; ++e) g[e] = R(0);
       bool any_live = false;
+      // the seed and the position of a chunk's taxels are fetched one chunk ahead: a lone wavefront cannot hide the two dependent
+      // global-memory latencies per chunk (seed -> live? -> position) otherwise
+      R nw0 = R(0), nw1 = R(0), nw2 = R(0), nx0 = R(0), nx1 = R(0), nx2 = R(0);
+      if (lane < nt) {
+        const int t = t0 + lane; const R* tp = c.Fg + c.foff_tax + t;
+        nw0 = wtac[3 * t]; nw1 = wtac[3 * t + 1]; nw2 = wtac[3 * t + 2]; nx0 = tp[0]; nx1 = tp[c.ntax]; nx2 = tp[2 * c.ntax];
+      }
       for (int base = 0; base < nt; base += LPE) {
         const bool valid = base + lane < nt;
         const int t = t0 + (valid ? base + lane : 0);
         const R* tp = c.Fg + c.foff_tax + t;
-        R w0 = R(0), w1 = R(0), w2 = R(0);
-        if (valid) { w0 = wtac[3 * t]; w1 = wtac[3 * t + 1]; w2 = wtac[3 * t + 2]; }
+        const R w0 = valid ? nw0 : R(0), w1 = valid ? nw1 : R(0), w2 = valid ? nw2 : R(0);
+        const R x0 = nx0, x1 = nx1, x2 = nx2;
+        if (base + LPE + lane < nt) {
+          const int tn = t0 + base + LPE + lane; const R* tq = c.Fg + c.foff_tax + tn;
+          nw0 = wtac[3 * tn]; nw1 = wtac[3 * tn + 1]; nw2 = wtac[3 * tn + 2]; nx0 = tq[0]; nx1 = tq[c.ntax]; nx2 = tq[2 * c.ntax];
+        }
         bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
         V3<R> xP, F; M3<R> Jx, Jv;
         if (live) {
-          const V3<double> xPd = mulMv(ldm(c.PPd), mk3<double>((double)tp[0], (double)tp[c.ntax], (double)tp[2 * c.ntax])) + ldv(c.PPd + 9);
+          const V3<double> xPd = mulMv(ldm(c.PPd), mk3<double>((double)x0, (double)x1, (double)x2)) + ldv(c.PPd + 9);
           xP = cvt3<R>(xPd);
           live = contact_law<R, true>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
         }
