@@ -334,7 +334,7 @@ template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int
 // put in LDS once; inside the taxel loop the only global accesses left are the taxel's own constants and its 12 output bytes.  (Read
 // from global memory in the loop they are chains of dependent ~600-cycle loads — index -> record -> value — and the loop was exactly
 // that latency: 55 us for 256 x 40 000 taxels.)
-enum { TX_MAXS = 8, TX_MAXK = 24 };
+enum { TX_MAXS = 16, TX_MAXK = 64 };
 template <class R>
 __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
   const int env = blockIdx.x;
