@@ -29,15 +29,17 @@ from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv       
 from tactilesimulation_amd.algorithms.batched_gd import Actor, GraphedRollout, train_epoch, train_epoch_graphed   # noqa: E402
 
 
-def draw_episode(rng, B, T, device, dtype):
-    """q0 [B, 7], goal [B, 3], disturbances [T, B, 2] as in tactile_push_env.py:133-190 (new force every 10 steps, on with p = 0.5)."""
+def draw_episode(rng, B, T, device, dtype, period=1):
+    """q0 [B, 7], goal [B, 3], disturbances [T, B, 2] as in tactile_push_env.py:133-190: a new force on the box, on with p = 0.5, every
+    `period` env-steps.  The reference's line reads "every 10 steps" (`current_step % 10 == 0`, :185) but current_step is never
+    incremented there, so it redraws at every step: period = 1 is the reference's behaviour."""
     q0 = np.zeros((B, 7)); q0[:, 1] = -0.001; q0[:, 4] = rng.uniform(-0.02, 0.02, size=B)
     goal = np.zeros((B, 3))
     goal[:, 0:2] = rng.uniform([0.15, -0.2], [0.25, 0.2], size=(B, 2))
     goal[:, 2] = rng.uniform(goal[:, 1] * math.pi - math.pi / 16.0, goal[:, 1] * math.pi + math.pi / 16.0)
     d = np.zeros((T, B, 2))
-    for t0 in range(0, T, 10):
-        d[t0:t0 + 10] = (rng.uniform(size=(B, 1)) < 0.5) * rng.uniform(-1.0, 1.0, size=(B, 2))
+    for t0 in range(0, T, period):
+        d[t0:t0 + period] = (rng.uniform(size=(B, 1)) < 0.5) * rng.uniform(-1.0, 1.0, size=(B, 2))
     t = lambda a: torch.tensor(a, device=device, dtype=dtype)
     return t(q0), t(goal), t(d)
 
@@ -57,6 +59,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per episode")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--disturbance-period", type=int, default=1, help="env-steps between new random forces on the box (the reference: 1, see draw_episode)")
     ap.add_argument("--save-best", default=None, help="torch.save the best policy (lowest loss, as algorithms/gd.py:187-189 keeps it) here")
     args = ap.parse_args()
 
@@ -74,7 +77,7 @@ def main():
     opt = torch.optim.Adam(actor.parameters(), lr=args.lr, betas=tuple(args.betas))
     curve = []
     rng = np.random.default_rng(args.seed + 1000 * rank)
-    q0, goal, dist_ = draw_episode(rng, B, T, dev, dtype)
+    q0, goal, dist_ = draw_episode(rng, B, T, dev, dtype, args.disturbance_period)
     gr = None if args.eager else GraphedRollout(env, actor, T, q0, goal, dist_)
     best = (float("inf"), -1, None)
     prev_state = {k: v.detach().clone() for k, v in actor.state_dict().items()}
@@ -82,7 +85,7 @@ def main():
         if args.lr_schedule == "linear":                           # gd.py:146-149
             for g in opt.param_groups:
                 g["lr"] = (1e-5 - args.lr) * float(epoch / args.epochs) + args.lr
-        nq0, ngoal, ndist = draw_episode(rng, B, T, dev, dtype)
+        nq0, ngoal, ndist = draw_episode(rng, B, T, dev, dtype, args.disturbance_period)
         q0.copy_(nq0); goal.copy_(ngoal); dist_.copy_(ndist)       # static inputs of the graph
         torch.cuda.synchronize(); t0 = time.perf_counter()
         if gr is None:

@@ -35,6 +35,10 @@ class BatchedTactilePushEnv:
         self.obs_dim, self.act_dim = 3 + 390, 3
         self.dt = self.sim.h * self.frame_skip
         self.current_step = 0
+        # The reference tests `current_step % 10 == 0` before drawing a new disturbance (tactile_push_env.py:185) but never increments
+        # current_step (it is only ever set to 0, :62 and :167), so it draws a new force at EVERY env-step.  1 reproduces that; 10 is
+        # what the line reads like.
+        self.disturbance_period = 1
 
     # ------------------------------------------------------------------ helpers
     def _t(self, a):
@@ -65,7 +69,7 @@ class BatchedTactilePushEnv:
         """u: policy output [B, 3] (pre-tanh). Returns obs [B, 393], reward [B], info dict of reward terms."""
         if disturbance is not None:
             self.external_force = disturbance.to(self.device, self.dtype)
-        elif self.current_step % 10 == 0:                                   # :185-190
+        elif self.current_step % self.disturbance_period == 0:              # :185-190
             on = self._t(self.rng.uniform(0.0, 1.0, size=self.B) < 0.5).unsqueeze(1)
             self.external_force = on * self._t(self.rng.uniform(-1.0, 1.0, size=(self.B, 2)))
         robot_action = PushAction.apply(u, self.external_force)                                    # [tanh(u), force on the box, 0]
