@@ -169,43 +169,31 @@ def test_baseline_worded_sizes_run_and_match_the_oracle(name, B_, T, S, dtype, t
 
 def test_reference_env_call_protocol_replays_on_the_shim():
     """Every call the reference's own DClawRotateEnv makes on its simulator during construction, reset() and three step()s — recorded
-    by running that class against a recording stand-in (tools/make_dclaw_env_fixture.py -> tests/golden/dclaw_env_protocol.json) — is
+    by running that class against a recording stand-in (tools/make_env_protocol_fixtures.py -> tests/golden/dclaw_env_protocol.json) — is
     replayed on this repository's `redmax_py` shim with the recorded argument values: each call is accepted and returns what the
     environment expects (shapes, dtypes, list structure), and the observation it would assemble has the recorded size."""
     import json
     import redmax_py as redmax
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from replay_protocol import replay
     g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dclaw_env_protocol.json")))
     assert g["frame_skip"] == 5 and g["relative_q_scale"] == 0.06 and np.array_equal(np.array(g["dof_limit"]), DOF_LIMIT)
 
-    def dec(a):
-        if isinstance(a, dict) and "values" in a:
-            return np.array(a["values"], dtype=a["dtype"]).reshape(a["shape"])
-        return a
-    sim, seen = None, set()
-    for e in g["log"]:
-        name, args, kw = e["call"], [dec(a) for a in e["args"]], {k: dec(v) for k, v in e["kwargs"].items()}
-        seen.add(name)
-        if name == "Simulation":
-            assert args[0].endswith("dclaw_rotate/dclaw_position_control.xml")
-            sim = redmax.Simulation(_dclaw(tol=1e-8), verbose=kw["verbose"], dtype=torch.float32)
-            assert (sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile) == (10, 9, 12, 2718) and abs(sim.options.h - 5e-3) < 1e-15
-            continue
-        out = getattr(sim, name)(*args, **kw)
-        want = e["returns"]
-        if isinstance(want, dict) and "shape" in want:
-            out = np.asarray(out)
-            assert list(out.shape) == want["shape"] and str(out.dtype) == want["dtype"], (name, out.shape, out.dtype)
-            assert np.all(np.isfinite(out)), name
-        elif isinstance(want, dict) and "list" in want:
-            assert len(out) == want["list"], name
-            if name == "get_tactile_flow_images":                   # (3, 20, 20, 3) after np.array(), dclaw_rotate_env.py:103-105
-                assert np.array(out).shape == (3, 20, 20, 3)
-            else:                                                   # image positions: (row, col) pairs inside the 20 x 20 image
-                assert len(out) == 302 and all(len(p) == 2 and 0 <= p[0] < 20 and 0 <= p[1] < 20 for p in out)
-        else:
-            assert out is None, name
+    def make(path, verbose):
+        assert path.endswith("dclaw_rotate/dclaw_position_control.xml")
+        sim = redmax.Simulation(_dclaw(tol=1e-8), verbose=verbose, dtype=torch.float32)
+        assert (sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile) == (10, 9, 12, 2718) and abs(sim.options.h - 5e-3) < 1e-15
+        return sim
+
+    def on_call(sim, name, out):
+        if name == "get_tactile_flow_images":                       # (3, 20, 20, 3) after np.array(), dclaw_rotate_env.py:103-105
+            assert np.array(out).shape == (3, 20, 20, 3)
+        if name == "get_tactile_image_pos":                         # (row, col) pairs inside the 20 x 20 image
+            assert len(out) == 302 and all(len(p) == 2 and 0 <= p[0] < 20 and 0 <= p[1] < 20 for p in out)
+    sim, seen = replay(make, g["log"], on_call)
     assert {"update_joint_damping", "update_body_size", "update_endeffector_position", "update_joint_location", "set_state_init", "set_u",
-            "forward", "get_qdot", "get_tactile_flow_images", "get_tactile_image_pos"} <= seen
+            "forward", "get_qdot", "get_tactile_flow_images", "get_tactile_image_pos"} <= set(seen)
+    assert sum(seen.values()) == g["calls"]
     # the observation the environment assembles from these getters (dclaw_rotate_env.py:93-118)
     obs = np.concatenate((sim.get_q()[:9], sim.get_variables()[:9], np.array(sim.get_tactile_flow_images()).transpose(0, 3, 1, 2).reshape(-1)))
     assert list(obs.shape) == g["obs_shape_after_reset"] == [9 + 9 + 3 * 3 * 20 * 20]

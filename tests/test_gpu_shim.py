@@ -231,3 +231,30 @@ def test_mis_shaped_inputs_are_rejected(pusher_model):
     with pytest.raises(ValueError):
         sim.backward_steps(5, torch.zeros(7, B, dtype=torch.float64))
     sim.backward_steps(5, torch.zeros(B, 7, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("which,asset_name,sizes", [("stable_grasp", "stable_grasp", (12, 6, 0, 780)), ("insertion", "tactile_insertion", (12, 6, 0, 780))])
+def test_reference_env_call_protocols_replay_on_the_shim(which, asset_name, sizes):
+    """The call protocols of the reference's own StableGraspEnv and TactileInsertionEnv (construction incl. their scripted settling,
+    reset() with the density / contact-parameter randomisers, two step()s = their five-stage grasps through EpisodicSimFunction: ~2 000
+    simulator calls each; recorded against a stand-in by tools/make_env_protocol_fixtures.py) replay on the shim call by call: every call
+    is accepted, returns the recorded shape / dtype, stays finite."""
+    import json
+    import redmax_py as redmax
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.workloads import asset
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from replay_protocol import replay
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", which + "_env_protocol.json")))
+
+    def make(path, verbose):
+        assert path.endswith(asset_name + ".xml")
+        sim = redmax.Simulation(load_model(asset(asset_name)), verbose=verbose, dtype=torch.float64)
+        assert (sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile) == sizes
+        return sim
+    sim, seen = replay(make, g["log"])
+    assert sum(seen.values()) == g["calls"]
+    need = {"stable_grasp": {"update_body_density", "update_body_color", "clearBackwardCache", "set_state_init", "get_tactile_force_vector"},
+            "insertion": {"update_contact_parameters", "update_tactile_parameters", "clearBackwardCache", "set_state_init", "get_tactile_force_vector"}}[which]
+    assert need <= set(seen)
+    assert np.all(np.isfinite(sim.get_q())) and np.abs(sim.get_q()).max() < 5.0
