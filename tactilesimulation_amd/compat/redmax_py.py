@@ -68,6 +68,22 @@ class Simulation:
         self._backward_flag = False
         self._dirty_outputs = True
         self._q = self._qdot = self._var = self._tac = None
+        # forward() I/O: the action goes up and q, qdot, variables (and tactile, unless it is a high-resolution sensor read on demand) come
+        # back through ONE pinned staging buffer each way and one stream synchronisation per call — a B = 1 step is ~70 us of kernel; five
+        # pageable copies with a synchronisation each cost more than that (RollingBall test_sim_speed: 4.7 k -> FPS in BASELINE.md §6)
+        self._lazy_tac = self.ndof_tactile > 4096
+        nr, nv, nt = self.ndof_r, self.ndof_var, (0 if self._lazy_tac else self.ndof_tactile)
+        self._dev_out = torch.empty(1, 2 * nr + nv + nt, device=self._dev, dtype=dtype)
+        self._host_out = torch.empty(1, 2 * nr + nv + nt, dtype=dtype).pin_memory()
+        o = self._dev_out
+        self._out = {"q": o[:, :nr], "qd": o[:, nr:2 * nr], "status": torch.empty(1, device=self._dev, dtype=torch.int32)}
+        if nv:
+            self._out["var"] = o[:, 2 * nr:2 * nr + nv]
+        if nt:
+            self._out["tactile"] = o[:, 2 * nr + nv:]
+        self._host_status = torch.empty(1, dtype=torch.int32).pin_memory()
+        self._dev_u = torch.empty(1, self.ndof_u, device=self._dev, dtype=dtype)
+        self._host_u = torch.empty(1, self.ndof_u, dtype=dtype).pin_memory()
         self.reset(False)
 
     # ------------------------------------------------------------------ helpers
@@ -127,16 +143,25 @@ class Simulation:
         if test_derivatives:
             raise NotImplementedError("test_derivatives: use tests/test_gpu_parity.py (adjoint vs oracle / finite differences)")
         self._sync_model()
-        # high-resolution sensors (RollingBall: 120 000 values) are read out on demand by the sliced read-out kernel
-        # instead of after every step (test_sim_speed.py:79 asks for them every 5th step only)
-        lazy = self.ndof_tactile > 4096
-        out = self._sim.step(self._t(self._u, self.ndof_u, "u"), int(num_steps), want_qd=True, want_tactile=not lazy)
-        st = int(out["status"].item())
+        # high-resolution sensors (RollingBall: 120 000 values) are read out on demand by the read-out kernels instead of after every
+        # step (test_sim_speed.py:79 asks for them every 5th step only)
+        lazy = self._lazy_tac
+        if self._u.size != self.ndof_u:
+            raise RuntimeError("u: expected %d values, got %d" % (self.ndof_u, self._u.size))
+        self._host_u.copy_(torch.from_numpy(self._u).reshape(1, -1))
+        self._dev_u.copy_(self._host_u, non_blocking=True)
+        out = self._sim.step(self._dev_u, int(num_steps), want_qd=True, want_tactile=not lazy, out=self._out)
+        self._host_out.copy_(self._dev_out, non_blocking=True)
+        self._host_status.copy_(out["status"], non_blocking=True)
+        torch.cuda.current_stream(self._dev).synchronize()
+        st = int(self._host_status[0])
         if st & (1 << 30):
             raise RuntimeError("simulation produced non-finite values")
-        self._q, self._qdot = self._np(out["q"]), self._np(out["qd"])
-        self._var = self._np(out["var"]) if "var" in out else np.zeros(0)
-        self._tac = self._np(out["tactile"]) if "tactile" in out else (None if lazy else np.zeros(0))
+        h = self._host_out.numpy()[0].astype(np.float64)            # a fresh float64 array (callers keep what the getters return)
+        nr, nv = self.ndof_r, self.ndof_var
+        self._q, self._qdot = h[:nr], h[nr:2 * nr]
+        self._var = h[2 * nr:2 * nr + nv] if nv else np.zeros(0)
+        self._tac = None if lazy else (h[2 * nr + nv:] if self.ndof_tactile else np.zeros(0))
         self._dirty_outputs = False
         self.last_nonconverged_substeps = st
 
@@ -156,7 +181,11 @@ class Simulation:
         self._refresh()
         if self._tac is None:
             _, tac = self._sim.readout(want_var=False)
-            self._tac = self._np(tac)
+            if getattr(self, "_host_tac", None) is None:
+                self._host_tac = torch.empty(tac.shape, dtype=tac.dtype).pin_memory()
+            self._host_tac.copy_(tac, non_blocking=True)
+            torch.cuda.current_stream(self._dev).synchronize()
+            self._tac = self._host_tac.numpy().reshape(-1).astype(np.float64)
         return self._tac
 
     def get_tactile_image_pos(self, name):
