@@ -133,3 +133,21 @@ def test_on_demand_readout_equals_the_step_outputs(name, dtype):
         assert torch.equal(var, o["var"])
     if name in ("pusher", "tactile_pad", "tactile_insertion"):       # scenarios known to load taxels (the other two compare zeros and variables)
         assert float(tac.abs().max()) > 0, "the scenario never loaded a taxel: nothing was compared"
+
+
+def test_large_batch_long_episode_indices_are_64_bit(pusher_model):
+    """32 768 environments x 100 env-steps (a 4.5 GB tape, 5 GB of tactile output: every per-environment offset beyond 2^32 bytes): eight
+    copies of one 4096-environment batch give eight bit-identical blocks, forward and adjoint, and everything converges."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    T, copies = 100, 8
+    q0, u, _ = push_workload(4096, T, seed=0)
+    B = 4096 * copies
+    sim = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=T * S)
+    sim.reset(torch.tensor(np.tile(q0, (copies, 1)), device="cuda", dtype=torch.float32), None, backward_flag=True)
+    ro = sim.rollout(torch.tensor(np.tile(u, (copies, 1, 1)), device="cuda", dtype=torch.float32).transpose(0, 1).contiguous(), S)
+    assert int((ro["status"] != 0).sum()) == 0
+    du = sim.backward_episode(T, S, *[torch.ones(T, B, d, device="cuda") for d in (7, 6, 390)])
+    q, tac, g = ro["q"].reshape(T, copies, 4096, 7), ro["tactile"].reshape(T, copies, 4096, 390), du.reshape(T, copies, 4096, 6)
+    for c in range(1, copies):
+        assert torch.equal(q[:, 0], q[:, c]) and torch.equal(tac[:, 0], tac[:, c]) and torch.equal(g[:, 0], g[:, c]), c
+    assert float(tac.abs().max()) > 0 and bool(torch.isfinite(g).all())
