@@ -76,6 +76,14 @@ def test_errors_fail_loudly_and_leave_the_batch_usable(pusher_model):
     assert torch.equal(sim.step(torch.tensor(u[:, 0]), S)["q"], a)         # and deterministic after all of that
     with pytest.raises(RuntimeError):
         sim.set_lanes_per_env(48)
+    # empty inputs are refused, not launched
+    with pytest.raises((RuntimeError, ValueError)):
+        BatchSim(pusher_model, 0, dtype=torch.float32)
+    with pytest.raises((RuntimeError, ValueError)):
+        sim.rollout(torch.zeros(0, B, 6, device="cuda"), S)
+    with pytest.raises((RuntimeError, ValueError)):
+        sim.backward_episode(0, S, None, None, None)
+    assert torch.equal(sim.step(torch.tensor(u[:, 1]), S)["q"].isfinite().all(), torch.tensor(True, device="cuda"))
 
 
 def test_non_finite_action_is_confined_to_its_environment(pusher_model):
