@@ -65,10 +65,15 @@ class Actor(torch.nn.Module):
         self._ones = None
         self.defer_weight_grads = False         # GraphedRollout / train_epoch(defer=True) switch this on
         self._sinks = [[] for m in self.mu_net if isinstance(m, torch.nn.Linear)]
+        self._armed = False                     # deferred mode: begin_episode() was called and its gradients were not assembled yet
 
     def forward(self, obs):
         if self._ones is None or self._ones.shape[1] != obs.shape[0] or self._ones.dtype != obs.dtype or self._ones.device != obs.device:
             self._ones = torch.ones(1, obs.shape[0], device=obs.device, dtype=obs.dtype)
+        if self.defer_weight_grads and torch.is_grad_enabled() and not self._armed:
+            raise RuntimeError("Actor is in deferred-weight-gradient mode (GraphedRollout / defer_weight_grads = True): call begin_episode() "
+                               "before the roll-out and assemble_grads() after backward(), or set defer_weight_grads = False — a plain "
+                               "backward() would leave weight.grad / bias.grad empty")
         x, k = obs, 0
         for m in self.mu_net:
             if not isinstance(m, torch.nn.Linear):
@@ -102,6 +107,7 @@ class Actor(torch.nn.Module):
         """Deferred mode: forget the (input, output-gradient) pairs of earlier backward passes."""
         for s in self._sinks:
             s.clear()
+        self._armed = True
 
     def assemble_grads(self, keep=False):
         """Deferred mode, after the episode's backward: weight.grad = sum_t g_t^T x_t as ONE batched GEMM per layer and
@@ -117,6 +123,8 @@ class Actor(torch.nn.Module):
             m.bias.grad = G.sum((0, 1))
             if not keep:
                 sink.clear()
+        if not keep:
+            self._armed = False
 
 
 def rollout_loss(env, actor, horizon, q0=None, goal=None, disturbances=None):
