@@ -275,3 +275,62 @@ def test_config4_config5_per_gpu_share_forward_only_fp32(name, B, T, n_oracle, t
             gq, gt = ro["q"][t, e].double().cpu().numpy(), ro["tactile"][t, e].double().cpu().numpy()
             assert np.abs(gq - q).max() < tq * max(1.0, np.abs(q).max()), (e, t, np.abs(gq - q).max())
             assert np.abs(gt - tac).max() < tt * max(np.abs(tac).max(), 1e-3), (e, t)
+
+
+def test_config3_reward_loss_gradient_as_survey_words_it(pusher_model):
+    """SURVEY.md §8d row 3 literally: L = sum_t [reward_pos + reward_rot + reward_touch] (envs/tactile_push_env.py:206-208) with the goals
+    of the workload, gradient w.r.t. u[B, 100, 6]; fp32 kernels at B = 4096 against the fp64 oracle on a 64-environment subset of the
+    batch, by the survey's metric max_i |g_gpu - g_cpu| / max(|g_cpu|, 1e-12 |g_cpu|_inf) (per environment, scaled by the environment's
+    largest gradient entry) and by the reference's own pair, relative error and cosine (algorithms/gd.py:459-465)."""
+    import math
+    from tactilesimulation_amd.host.batch import BatchSim
+    from oracle.oracle import OracleSim
+    B = 4096
+    q0, u, goal = push_workload(B, T, seed=0)
+    dt = torch.float32
+    sim = BatchSim(pusher_model, B, dtype=dt, tape_capacity=T * S)
+    sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None, backward_flag=True)
+    ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous(), S)
+    assert int((ro["status"] != 0).sum()) == 0
+
+    def seeds(q, var, g):                                       # dL/dq [.., 7], dL/dvar [.., 6] of the three reward terms
+        dq = np.zeros(q.shape); dv = np.zeros(var.shape)
+        dq[..., 3:5] = -200.0 * (q[..., 3:5] - g[..., 0:2])     # -0.01 * 2 (p - g) / 0.01^2
+        dq[..., 6] = -0.2 * (q[..., 6] - g[..., 2]) / (math.pi / 36.0) ** 2
+        d = var[..., 0:3] - var[..., 3:6]
+        dv[..., 0:3], dv[..., 3:6] = -2.0 * d / 0.02 ** 2, 2.0 * d / 0.02 ** 2
+        return dq, dv
+    q_g, v_g = ro["q"].double().cpu().numpy(), ro["var"].double().cpu().numpy()
+    dq, dv = seeds(q_g, v_g, goal[None])
+    du = sim.backward_episode(T, S, torch.tensor(dq, device=DEV, dtype=dt), torch.tensor(dv, device=DEV, dtype=dt), None).double().cpu().numpy()
+    idx = np.arange(5, B, 64)
+    G = np.zeros((T, len(idx), 6)); L_o = np.zeros(len(idx)); sig_o = np.zeros((T * S, len(idx), 2), dtype=np.int64)
+    nthr = max(1, min(len(os.sched_getaffinity(0)), 32, len(idx)))
+
+    def work(i):
+        o = OracleSim(pusher_model)
+        for j in range(i, len(idx), nthr):
+            e = idx[j]
+            o.reset(q0[e], record=True)
+            qs, vs = np.zeros((T, 7)), np.zeros((T, 6))
+            for t in range(T):
+                bad, sg = o.forward_sig(u[e, t], S)
+                assert bad == 0
+                sig_o[t * S:(t + 1) * S, j] = sg
+                qs[t], vs[t] = o.state()[0], o.outputs()[0]
+            sq, sv = seeds(qs, vs, goal[e][None])
+            for t in reversed(range(T)):
+                a = np.zeros((S, 7)); a[-1] = sq[t]
+                b = np.zeros((S, 6)); b[-1] = sv[t]
+                G[t, j] = o.backward_steps(S, a, b, np.zeros((S, 390))).sum(0)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    g = du[:, idx]
+    scale = np.abs(G).max(axis=(0, 2), keepdims=True)
+    survey = (np.abs(g - G) / np.maximum(scale, 1e-12 * scale.max())).max(axis=(0, 2))       # per environment
+    rel = np.linalg.norm((g - G).reshape(T, len(idx), -1).transpose(1, 0, 2).reshape(len(idx), -1), axis=1) / np.linalg.norm(G.transpose(1, 0, 2).reshape(len(idx), -1), axis=1)
+    cos = np.array([float(g[:, j].reshape(-1) @ G[:, j].reshape(-1) / (np.linalg.norm(g[:, j]) * np.linalg.norm(G[:, j]))) for j in range(len(idx))])
+    ok = survey < 1e-4
+    assert ok.sum() >= len(idx) - 4, (np.sort(survey)[-6:], "environments off: %d" % (~ok).sum())     # the few that crossed a kink (§5)
+    assert np.median(survey) < 2e-5 and np.median(rel) < 2e-5 and cos[ok].min() > 1.0 - 1e-8, (np.median(survey), np.median(rel), cos[ok].min())
