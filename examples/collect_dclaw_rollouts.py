@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
-from tactilesimulation_amd.envs.dclaw_rotate import BatchedDClawRotateEnv      # noqa: E402
+from tactilesimulation_amd.envs.dclaw_rotate import BatchedDClawRotateEnv, GraphedCollector      # noqa: E402
 
 
 def main():
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--variants", type=int, default=16, help="pool of randomised models (damping, cap radius, end-effector, location); 0: none")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per collection step")
     a = ap.parse_args()
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -32,17 +33,25 @@ def main():
     env = BatchedDClawRotateEnv(a.batch, device="cuda:%d" % local, dtype=dt, seed=a.seed + rank, variants=a.variants)
     torch.manual_seed(a.seed)
     W = torch.randn(env.obs_dim, env.act_dim, device=env.device, dtype=dt) * 0.02
-    obs = env.reset()
+    policy = lambda obs: torch.tanh(obs @ W) + 0.3 * torch.randn(a.batch, env.act_dim, device=env.device, dtype=dt)
     zero = lambda: torch.zeros((), device=env.device, dtype=torch.long)
     episodes, successes, nonconv = zero(), zero(), zero()
     ret = torch.zeros(a.batch, device=env.device, dtype=dt)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for t in range(a.steps):
-        u = torch.tanh(obs @ W) + 0.3 * torch.randn(a.batch, env.act_dim, device=env.device, dtype=dt)
-        obs, r, done, info = env.step(u)
-        ret += r
-        nonconv += (info["status"] != 0).sum(); episodes += done.sum(); successes += (done & info["success"]).sum()
-        obs = env.reset(done)                                              # only the finished environments start over; no host round trip
+    if a.eager:
+        obs = env.reset()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for t in range(a.steps):
+            obs, r, done, info = env.step(policy(obs))
+            ret += r
+            nonconv += (info["status"] != 0).sum(); episodes += done.sum(); successes += (done & info["success"]).sum()
+            obs = env.reset(done)                                          # only the finished environments start over; no host round trip
+    else:
+        col = GraphedCollector(env, policy)                                # one HIP-graph replay per collection step
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for t in range(a.steps):
+            obs, u, r, done, nxt = col.step()                              # static tensors: a learner would copy them into its roll-out storage
+            ret += r
+            nonconv += (col.status != 0).sum(); episodes += done.sum(); successes += (done & col.success).sum()
     torch.cuda.synchronize(); dt_ = time.perf_counter() - t0
     print("rank %d: %d environments x %d env-steps in %.2f s = %.2f M env-steps/s; %d episodes ended (%d by success), mean return so far %.2f, "
           "non-converged env-steps %d" % (rank, a.batch, a.steps, dt_, a.batch * a.steps / dt_ / 1e6, int(episodes), int(successes), float(ret.mean()), int(nonconv)))

@@ -24,11 +24,15 @@ from ..model import compiler as mc
 from ..workloads import asset
 
 DOF_LIMIT = np.array([[-0.45, 1.35], [-2, 2], [1, 2]] * 3, dtype=np.float64)          # dclaw_rotate_env.py:78-88
+_LIMITS = {}
 
 
 def joint_targets(q, u, relative_q_scale=0.06, limits=DOF_LIMIT):
     """u [B, 9] policy output -> absolute joint targets [B, 9] (relative position control)."""
-    lim = torch.as_tensor(limits, dtype=q.dtype, device=q.device)
+    key = (id(limits), q.dtype, q.device)
+    lim = _LIMITS.get(key)
+    if lim is None:                                                 # once per device / dtype: no host copy in the stepping loop
+        lim = _LIMITS[key] = torch.as_tensor(np.asarray(limits), dtype=q.dtype, device=q.device)
     return torch.minimum(torch.maximum(q[:, :9] + torch.clamp(u, -1.0, 1.0) * relative_q_scale, lim[:, 0]), lim[:, 1])
 
 
@@ -78,7 +82,9 @@ class BatchedDClawRotateEnv:
         self.tables = None
         if variants:
             self._build_variants(int(variants))
-        self.q = self.var = self.flow = None
+        # persistent state buffers, updated in place: a collector's step can be captured in a HIP graph and replayed
+        z = lambda *shape: torch.zeros(*shape, device=self.device, dtype=self.dtype)
+        self.q, self.var, self.flow = z(self.B, 10), z(self.B, 12), z(self.B, 3, 20, 20, 3)
         self.steps = torch.zeros(self.B, device=self.device, dtype=torch.long)
 
     # ------------------------------------------------------------------ domain randomisation (reset-time randomisers)
@@ -99,7 +105,7 @@ class BatchedDClawRotateEnv:
             rows.append(m.F[:n]); self.variant_params.append((damping, radius, dx, dy))
         self._variant_rows = torch.tensor(np.array(rows), device=self.device, dtype=self.dtype)
         self.variant_of = torch.zeros(self.B, device=self.device, dtype=torch.long)
-        self.tables = self._variant_rows[self.variant_of].contiguous()
+        self.tables = self._variant_rows[self.variant_of].contiguous()          # persistent: rewritten in place at every reset
 
     # ------------------------------------------------------------------ read-out helpers
     def flow_images(self, tactile):
@@ -108,9 +114,9 @@ class BatchedDClawRotateEnv:
         return img.reshape(-1, 3, 20, 20, 3)
 
     def _observe(self):
-        self.q, _ = self.sim.get_state()
+        q, _ = self.sim.get_state()
         var, tac = self.sim.readout()
-        self.var, self.flow = var, self.flow_images(tac)
+        self.q.copy_(q); self.var.copy_(var); self.flow.copy_(self.flow_images(tac))
         return observation(self.q, self.var, self.flow)
 
     # ------------------------------------------------------------------ gym-like API, batched
@@ -124,24 +130,61 @@ class BatchedDClawRotateEnv:
         q0[:, :9] += 0.05 * torch.randn(B, 9, device=self.device, dtype=self.dtype, generator=self._gen)
         if self.tables is not None:
             new = torch.randint(0, self._variant_rows.shape[0], (B,), device=self.device, generator=self._gen)
-            self.variant_of = torch.where(m, new, self.variant_of)
-            self.tables = self._variant_rows[self.variant_of].contiguous()
+            self.variant_of.copy_(torch.where(m, new, self.variant_of))
+            self.tables.copy_(self._variant_rows[self.variant_of])
             self.sim.set_env_tables(self.tables)
         if mask is None:
             self.sim.reset(q0, None, backward_flag=False)
         else:
             self.sim.reset_masked(q0, m.to(torch.int32))
-        self.steps = torch.where(m, torch.zeros_like(self.steps), self.steps)
+        self.steps.masked_fill_(m, 0)
         return self._observe()
 
     def step(self, u):
         """u [B, 9] -> obs [B, 3618], reward [B], done [B], info.  Finished environments are NOT reset here (call reset(done))."""
         u = u.to(self.device, self.dtype)
-        flow_prev = self.flow
+        flow_prev = self.flow.clone()
         out = self.sim.step(joint_targets(self.q, u), self.frame_skip)
-        self.q, self.var, self.flow = out["q"], out["var"], self.flow_images(out["tactile"])
+        self.q.copy_(out["q"]); self.var.copy_(out["var"]); self.flow.copy_(self.flow_images(out["tactile"]))
         obs = observation(self.q, self.var, self.flow)
         r, done, success = reward(self.q, self.var, flow_prev, u)
         self.steps += 1
         done = done | (self.steps >= self.max_episode_steps)
         return obs, r, done, {"success": success, "status": out["status"]}
+
+
+class GraphedCollector:
+    """One collection step — policy, env.step, reset of the environments that finished — captured in ONE HIP graph and replayed.  The
+    eager loop issues ~80 small launches per env-step from Python and is host-bound at a few hundred thousand env-steps/s; a replay is one
+    launch (tools/dclaw_graph_collector_probe.py: 0.5 -> 1.8 M env-steps/s at B = 2048, bit-identical transitions).  `policy(obs) -> u`
+    must be capturable torch code (no host round trips; torch.randn with the default generator is fine).  After step(): `obs` holds the
+    observation the policy acted on, `action`, `reward`, `done`, `success` the transition, `next_obs` the observation after the
+    per-environment resets (it is also the next step's input)."""
+
+    def __init__(self, env, policy, warmup=2):
+        self.env, self.policy = env, policy
+        env._gen = None                                            # the default generator is the one graph capture knows how to advance
+        self.next_obs = env.reset().clone()
+        self.obs = torch.empty_like(self.next_obs)
+        side = torch.cuda.Stream(env.device)
+        side.wait_stream(torch.cuda.current_stream(env.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(env.device).wait_stream(side)
+        self.next_obs.copy_(env.reset())
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self._body()
+        self.next_obs.copy_(env.reset())                           # capture does not execute: start from fresh episodes
+
+    def _body(self):
+        self.obs.copy_(self.next_obs)
+        self.action = self.policy(self.obs)
+        _, self.reward, self.done, info = self.env.step(self.action)
+        self.success, self.status = info["success"], info["status"]
+        self.next_obs.copy_(self.env.reset(self.done))
+
+    def step(self):
+        self.graph.replay()
+        return self.obs, self.action, self.reward, self.done, self.next_obs

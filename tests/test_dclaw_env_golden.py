@@ -73,3 +73,40 @@ def test_batched_env_on_the_simulator():
         for k, (r, c) in enumerate(env.model.meta["image_pos"][name]):
             want[s_, r, c] = tac[0].cpu().numpy().reshape(-1, 3)[t0 + k]
     assert np.array_equal(img, want) and [(img[f].sum(-1) > 0).sum() for f in range(3)] == [182, 182, 182]
+
+
+@pytest.mark.gpu
+def test_graphed_collector_equals_the_eager_loop():
+    """The collection step replayed from a HIP graph (policy, env.step, per-environment resets incl. new model variants) yields exactly
+    the transitions of the eager loop: same seeds, same default-generator draws."""
+    from tactilesimulation_amd.envs.dclaw_rotate import BatchedDClawRotateEnv, GraphedCollector
+    B, T = 96, 40
+
+    def run(graphed):
+        env = BatchedDClawRotateEnv(B, dtype=torch.float32, seed=3, variants=4)
+        env.max_episode_steps = 16                                 # so that per-environment resets happen inside the run
+        torch.manual_seed(5)
+        W = torch.randn(env.obs_dim, env.act_dim, device="cuda") * 0.02
+        policy = lambda obs: torch.tanh(obs @ W) + 0.3 * torch.randn(B, 9, device="cuda")
+        out = []
+        if graphed:
+            col = GraphedCollector(env, policy)
+            torch.manual_seed(7); col.next_obs.copy_(env.reset())
+            for t in range(T):
+                o, u, r, d, n = col.step()
+                out.append((o.clone(), u.clone(), r.clone(), d.clone(), n.clone()))
+        else:
+            env._gen = None                                        # both runs are re-seeded right before their first counted reset
+            torch.manual_seed(7); obs = env.reset()
+            for t in range(T):
+                u = policy(obs)
+                o2, r, d, info = env.step(u)
+                n = env.reset(d)
+                out.append((obs.clone(), u.clone(), r.clone(), d.clone(), n.clone()))
+                obs = n
+        return out
+    a, b = run(False), run(True)
+    assert sum(int(x[3].sum()) for x in a) >= 2 * B                  # every environment was reset at least twice
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k, name in enumerate(("obs", "action", "reward", "done", "next_obs")):
+            assert torch.equal(x[k], y[k]), (t, name)
