@@ -1,0 +1,52 @@
+"""Forward-only roll-out collection on the batched TactileInsertion environment — BASELINE configs[4]'s usage: one env-step is one
+insertion attempt (the policy moves the pre-grasp pose, then 45 open-loop sub-steps with six tactile frames run as ONE launch); episodes
+of at most 15 attempts, finished environments restart individually.  The policy here is a random linear map.
+
+    python examples/collect_insertion_rollouts.py --batch 4096 --steps 15 --domain-randomization
+    python -m torch.distributed.run --nproc-per-node 8 examples/collect_insertion_rollouts.py       # 32 768 environments, no collective
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from tactilesimulation_amd.envs.tactile_insertion import BatchedTactileInsertionEnv, EXECUTION_STEPS      # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU (32 768 / 8 in BASELINE configs[4])")
+    ap.add_argument("--steps", type=int, default=15, help="insertion attempts to collect per environment")
+    ap.add_argument("--domain-randomization", action="store_true")
+    ap.add_argument("--reward-type", default="delta", choices=["absolute", "delta"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dt = torch.float32 if a.dtype == "f32" else torch.float64
+    env = BatchedTactileInsertionEnv(a.batch, device="cuda:%d" % local, dtype=dt, seed=a.seed + rank, reward_type=a.reward_type,
+                                     domain_randomization=a.domain_randomization)
+    torch.manual_seed(a.seed)
+    W = torch.randn(env.obs_dim, env.act_dim, device=env.device, dtype=dt) * 0.01
+    obs = env.reset()
+    zero = lambda: torch.zeros((), device=env.device, dtype=torch.long)
+    episodes, successes, nonconv = zero(), zero(), zero()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    done = torch.zeros(a.batch, dtype=torch.bool, device=env.device)
+    for t in range(a.steps):
+        u = torch.tanh(obs @ W) + 0.5 * torch.randn(a.batch, env.act_dim, device=env.device, dtype=dt)
+        obs, r, done, info = env.step(u, reset=done)                       # finished environments start over inside the same launch
+        nonconv += (info["status"] != 0).sum(); episodes += done.sum(); successes += (done & info["success"]).sum()
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    n = a.batch * a.steps
+    print("rank %d: %d environments x %d attempts in %.2f s = %.3f M attempts/s = %.2f M sub-steps/s; %d episodes ended, %d by success, "
+          "environments with a non-converged sub-step: %d" % (rank, a.batch, a.steps, el, n / el / 1e6, n * EXECUTION_STEPS / el / 1e6, int(episodes), int(successes), int(nonconv)))
+
+
+if __name__ == "__main__":
+    main()
