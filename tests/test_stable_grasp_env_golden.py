@@ -1,0 +1,58 @@
+"""StableGrasp environment arithmetic against golden vectors recorded from the REFERENCE's own StableGraspEnv run
+against a scripted simulator (tools/make_stable_grasp_env_fixture.py -> tests/golden/stable_grasp_env.npz).  CPU: the pure functions of
+envs/stable_grasp.py.  GPU: the batched environment on the real simulator."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "stable_grasp_env.npz"))
+t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64)
+
+
+def test_pure_functions_match_the_reference_env():
+    from tactilesimulation_amd.envs import stable_grasp as E
+    n = len(G["u"])
+    assert float(G["action_scale"]) == 0.05 and float(G["grasp_position_bound"]) == 0.11 and all(int(s) == E.CAPTURE_FRAME for s in G["tactile_substeps"].reshape(-1))
+    gp = G["grasp_position"]
+    assert np.abs(E.grasp_position_of_action(t(gp[:n]), t(G["u"][:, 0])).numpy() - gp[1:]).max() < 1e-15
+    # every grasp starts from the state the previous one ended in (the first from the settled reference state), moved to the grasp position
+    prev_end = np.concatenate([G["qpos_init_reference"][None], G["script_qs"][:-1, -1]])
+    start, act = E.grasp_actions(t(prev_end), t(gp))
+    assert np.abs(start.numpy() - G["state_init"]).max() < 1e-15
+    assert act.shape == (180, n + 1, 6) and np.abs(act.permute(1, 0, 2).numpy() - G["actions"]).max() < 1e-15
+    assert np.abs(E.observation(t(G["script_tactile"])).numpy() - G["obs"]).max() < 1e-12
+    r, succ = E.reward_done(t(G["script_qs"][:, E.CAPTURE_FRAME]))
+    assert np.abs(r.numpy() - G["reward"]).max() < 1e-12 and np.array_equal(succ.numpy(), G["success"]) and np.array_equal(G["done"], G["success"])
+    assert G["success"].sum() == 1 and (G["reward"] > -0.1).sum() == 2         # a level, lifted bar; a level bar that was not lifted
+    # the density draw with the reference's generator
+    d = E.draw_block_densities(np.random.RandomState(9))
+    assert [str(x) for x in G["density_names"]] == ["box_%d" % b for b in E.BOX_IDS] and np.abs(d - G["densities"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_batched_env_on_the_simulator():
+    from tactilesimulation_amd.envs import stable_grasp as E
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.model import compiler as mc
+    B = 12
+    env = E.BatchedStableGraspEnv(B, dtype=torch.float64, seed=4, variants=3)
+    obs = env.reset()
+    assert obs.shape == (B, 520) and bool(torch.isfinite(obs).all()) and float(obs.abs().max()) <= 30.0 + 1e-6
+    u = torch.tensor(np.random.default_rng(1).uniform(-1.2, 1.2, size=(B, 1)), device="cuda")
+    q_prev = env.current_q.clone()
+    obs, r, done, info = env.step(u)
+    assert int((info["status"] != 0).sum()) == 0 and bool(torch.isfinite(r).all()) and float(env.grasp_position.abs().max()) <= 0.11 + 1e-12
+    # one environment alone, on the separately compiled model of its variant, gives the same grasp bit for bit
+    e = 7
+    spec = mc.compile_spec(env.model.spec).spec
+    for i, b in enumerate(E.BOX_IDS):
+        mc.edit_spec(spec, "body_density", "box_%d" % b, float(env.variant_densities[int(env.variant_of[e])][i]))
+    one = BatchSim(mc.compile_spec(spec), 1, dtype=torch.float64, tape_capacity=0)
+    start, act = E.grasp_actions(q_prev[e:e + 1], env.grasp_position[e:e + 1])
+    one.reset(start, None, backward_flag=False)
+    ro = one.rollout(act, 1, want_var=False, tactile_mask=env.mask)
+    assert torch.equal(E.observation(ro["tactile"][0])[0], obs[e]) and torch.equal(ro["q"][-1][0], env.current_q[e])
+    # densities matter: variants differ in the tilt of the lifted bar
+    assert float(r.std()) > 0
