@@ -1,33 +1,47 @@
-"""Running mean / variance of a data stream (the reference's utils/running_mean_std.py: observation normalisation of the
-PPO / GD loops when `obs_rms` is on), kept on the device of the batch.  Same update rule (parallel-variance merge of batch
-moments), same float32 state, same normalize() epsilon; golden vectors in tests/golden/policy_and_utils.npz."""
+"""Streaming mean / variance of observations, kept on the device of the batch — what the reference's PPO / GD loops use to normalise
+observations when `obs_rms` is on (its utils/running_mean_std.py; same interface: update / normalize / mean / var / count / to).
+
+State is (count, mean, M2) with M2 the running sum of squared deviations, merged batch-wise by Chan's parallel rule; `var` is derived from
+it.  float32 state and the 1e-5 inside the square root of normalize() follow the reference, so results agree with it to float32 rounding
+(golden vectors: tests/golden/policy_and_utils.npz, tests/test_policy_and_utils.py).  A batched environment feeds it all B observations of
+a step at once.
+"""
 import torch
 
 
 class RunningMeanStd:
     def __init__(self, epsilon=1e-4, shape=(), device="cuda:0"):
+        self.count = float(epsilon)                                   # pseudo-count of the prior (mean 0, variance 1)
         self.mean = torch.zeros(shape, dtype=torch.float32, device=device)
-        self.var = torch.ones(shape, dtype=torch.float32, device=device)
-        self.count = epsilon
+        self._m2 = torch.full(tuple(shape), self.count, dtype=torch.float32, device=device)      # variance 1 x count
+
+    @property
+    def var(self):
+        return self._m2 / self.count
+
+    @var.setter
+    def var(self, v):
+        self._m2 = torch.as_tensor(v, dtype=torch.float32, device=self.mean.device) * self.count
 
     def to(self, device):
-        r = RunningMeanStd(device=device)
-        r.mean, r.var, r.count = self.mean.to(device).clone(), self.var.to(device).clone(), self.count
-        return r
+        other = RunningMeanStd(self.count, tuple(self.mean.shape), device)
+        other.mean, other._m2 = self.mean.to(device).clone(), self._m2.to(device).clone()
+        return other
 
     @torch.no_grad()
-    def update(self, arr):
-        """arr [n, *shape]: one batch of samples (for a batched environment: the observations of all environments)."""
-        self.update_from_moments(arr.mean(dim=0), arr.var(dim=0, unbiased=False), arr.shape[0])
+    def update(self, batch):
+        """batch [n, *shape]: n new samples."""
+        n = batch.shape[0]
+        mu = batch.mean(dim=0)
+        self.update_from_moments(mu, ((batch - mu) ** 2).mean(dim=0), n)
 
     def update_from_moments(self, batch_mean, batch_var, batch_count):
-        delta = batch_mean - self.mean
-        tot = self.count + batch_count
-        m2 = self.var * self.count + batch_var * batch_count + delta.square() * self.count * batch_count / tot
-        self.mean = self.mean + delta * batch_count / tot
-        self.var = m2 / tot
-        self.count = tot
+        total = self.count + batch_count
+        shift = batch_mean - self.mean
+        self._m2 = self._m2 + batch_var * batch_count + shift * shift * (self.count * batch_count / total)
+        self.mean = self.mean + shift * (batch_count / total)
+        self.count = total
 
-    def normalize(self, arr, un_norm=False):
-        s = torch.sqrt(self.var + 1e-5)
-        return arr * s + self.mean if un_norm else (arr - self.mean) / s
+    def normalize(self, x, un_norm=False):
+        scale = (self.var + 1e-5).sqrt()
+        return x * scale + self.mean if un_norm else (x - self.mean) / scale
