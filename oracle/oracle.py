@@ -51,6 +51,8 @@ def lib(native=False):
         L.orc_outputs.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_tape_len.argtypes = [C.c_void_p]
         L.orc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        L.orc_set_solver.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_solver.restype = C.c_int
         L.orc_backward_steps.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
         L.orc_backward_steps.restype = C.c_int
         L.orc_get_adjoint.argtypes = [C.c_void_p, _dp, _dp]
@@ -77,7 +79,10 @@ def _f(a, n=None):
 class OracleSim:
     """One environment, fp64, CPU. Mirrors the stepping/adjoint part of redmax_py.Simulation."""
 
-    def __init__(self, model, native=False):
+    def __init__(self, model, native=False, solver="kernel"):
+        """solver: "kernel" — the Newton globalisation the HIP kernels use (non-monotone steps across kinks, restart, trust
+        region: DESIGN.md §1);  "literal" — Newton + monotone backtracking exactly as the model XML states it
+        (tol / max_iter / max_ls of <solver_option>, nothing else; substep_literal in tsim_oracle.cpp)."""
         self.model = model
         self._L = lib(native)
         self._I = np.ascontiguousarray(model.I, dtype=np.int32)
@@ -88,6 +93,13 @@ class OracleSim:
         self.nr, self.nu = model.ndof_r, model.ndof_u
         self.nvar, self.ntac = model.ndof_var, model.ndof_tactile
         self.h = model.h
+        self.set_solver(solver)
+
+    def set_solver(self, solver):
+        mode = {"kernel": 0, "literal": 1}[solver]
+        if self._L.orc_set_solver(self._h, mode) != 0:
+            raise RuntimeError("oracle: bad solver mode")
+        self.solver = solver
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -143,9 +155,10 @@ class OracleSim:
         return self._L.orc_tape_len(self._h)
 
     def stats(self):
-        out = (C.c_long * 3)()
+        out = (C.c_long * 8)()
         self._L.orc_stats(self._h, out)
-        return {"newton_iters": out[0], "substeps": out[1], "nonconverged": out[2]}
+        return {"newton_iters": out[0], "substeps": out[1], "nonconverged": out[2], "evals": out[3],
+                "kicks": out[4], "restarts": out[5], "trust_region": out[6], "ls_exhausted": out[7]}
 
     def residual(self, q1, q0, qd0, u, which=-1):
         g = np.zeros(self.nr)

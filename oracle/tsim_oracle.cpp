@@ -445,7 +445,9 @@ struct Sim {
   std::vector<Rec> tape;
   std::vector<std::vector<Rec>> cache;
   bool record = false;
-  long newton_iters = 0, substeps = 0, nonconv = 0;
+  int solver = 0;          // 0: the globalisation the HIP kernels use;  1: LITERAL — exactly what the XML states (below)
+  long newton_iters = 0, substeps = 0, nonconv = 0, evals = 0;
+  long kicks = 0, restarts = 0, trust = 0, ls_exhausted = 0;   // how often each globalisation device acted (kernel mode) / a line search ran out (literal mode)
 };
 
 // One implicit step in predictor form (covers BDF1 and BDF2):
@@ -505,6 +507,41 @@ static void eval_g_jac(const Model& m, const double* q1, const double* q0, const
 
 static double norm2(int n, const double* x) { double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return std::sqrt(s); }
 
+
+// LITERAL solver (orc_set_solver(h, 1)): Newton with monotone backtracking exactly as the model file states it and nothing
+// else — `<solver_option tol="1e-8" max_iter="100" max_ls="20"/>` (envs/assets/pusher/pusher.xml:4; the same line in
+// dclaw_position_control.xml, tactile_insertion.xml, stable_grasp.xml): up to max_iter Newton iterations; each halves the
+// step until ||g|| decreases, at most max_ls times; converged when ||g||_2 < tol.  No non-monotone steps, no restart, no trust
+// region, no "100 tol" acceptance: none of the constants of include/tsim_blob.h (TSIM_LS_SHORT / TSIM_KICK_MAX / TSIM_STEP_MAX)
+// is read here.  When no trial of a line search reduces ||g|| the smallest one (alpha = 2^-max_ls) is taken and the iteration
+// goes on — the loop has no exit the XML does not name [CHOICE: DiffRedMax's own behaviour there is unknown, source absent].
+// This mode exists so that the HIP path can be checked against a solver that does NOT share its performance-driven
+// globalisation (tests/test_oracle_literal.py, tests/test_gpu_literal.py).
+static int substep_literal(Sim& S, const double* u, const StepCoef& c, double* q1) {
+  const Model& m = S.m; int nr = m.nr;
+  double g[MAXR], H[MAXR * MAXR], dq[MAXR], qn[MAXR], gn[MAXR];
+  for (int k = 0; k < nr; ++k) q1[k] = c.qpred[k];
+  int it = 0; bool ok = false;
+  for (; it <= m.max_iter; ++it) {
+    eval_g_jac_c(m, q1, c, u, 0, g, H); ++S.evals;
+    const double gnorm = norm2(nr, g);
+    if (gnorm < m.tol) { ok = true; break; }
+    if (!(gnorm == gnorm) || it == m.max_iter) break;
+    for (int k = 0; k < nr; ++k) g[k] = -g[k];
+    if (!solve_dense(nr, H, g, dq, false)) break;
+    double alpha = 1.0;
+    for (int ls = 0;; ++ls) {
+      for (int k = 0; k < nr; ++k) qn[k] = q1[k] + alpha * dq[k];
+      eval_g_c(m, qn, c, u, gn); ++S.evals;
+      if (norm2(nr, gn) < gnorm) break;
+      if (ls >= m.max_ls) { ++S.ls_exhausted; break; }
+      alpha *= 0.5;
+    }
+    for (int k = 0; k < nr; ++k) q1[k] = qn[k];
+  }
+  return ok ? it : -it - 1;
+}
+
 // one implicit sub-step (BDF1, or BDF2 once a previous state exists); returns Newton iterations used, negative if not converged
 static int substep(Sim& S, const double* u) {
   const Model& m = S.m; int nr = m.nr; double h = m.h;
@@ -515,8 +552,12 @@ static int substep(Sim& S, const double* u) {
   for (int k = 0; k < nr; ++k) q1[k] = c.qpred[k];
   int it = 0, kicks = 0; bool ok = false, deep = false;
   static const bool trace = getenv("TSIM_ORACLE_TRACE") != nullptr;
+  if (S.solver == 1) {
+    const int r = substep_literal(S, u, c, q1);
+    ok = r >= 0; it = ok ? r : -r - 1;
+  } else
   for (; it <= m.max_iter; ++it) {
-    eval_g_jac_c(m, q1, c, u, 0, g, H);
+    eval_g_jac_c(m, q1, c, u, 0, g, H); ++S.evals;
     double gnorm = norm2(nr, g);
     if (trace) fprintf(stderr, "  it %d gn %.3e kicks %d deep %d\n", it, gnorm, kicks, (int)deep);
     if (gnorm < m.tol) { ok = true; break; }
@@ -526,7 +567,7 @@ static int substep(Sim& S, const double* u) {
     {                                            // trust region (include/tsim_blob.h TSIM_STEP_MAX)
       double mx = 0.0;
       for (int k = 0; k < nr; ++k) mx = std::max(mx, std::fabs(dq[k]));
-      if (mx > TSIM_STEP_MAX) for (int k = 0; k < nr; ++k) dq[k] *= TSIM_STEP_MAX / mx;
+      if (mx > TSIM_STEP_MAX) { ++S.trust; for (int k = 0; k < nr; ++k) dq[k] *= TSIM_STEP_MAX / mx; }
     }
     // Globalisation: backtracking on ||g||. ||g|| has non-smooth local minima next to contact / friction
     // kinks where no short step along the Newton direction reduces it; there the full Newton step is taken anyway (it
@@ -536,10 +577,10 @@ static int substep(Sim& S, const double* u) {
     double alpha = 1.0; bool accepted = false, kick = false, restart = false;
     for (int ls = 0;; ++ls) {
       for (int k = 0; k < nr; ++k) qn[k] = q1[k] + alpha * dq[k];
-      eval_g_c(m, qn, c, u, gn);
+      eval_g_c(m, qn, c, u, gn); ++S.evals;
       if (norm2(nr, gn) < gnorm) { accepted = true; if (trace) fprintf(stderr, "    accept alpha %.3g\n", alpha); break; }
       if (!deep && ls >= std::min(m.max_ls, TSIM_LS_SHORT)) {
-        if (kicks < TSIM_KICK_MAX) { ++kicks; kick = true; } else { deep = true; restart = true; }
+        if (kicks < TSIM_KICK_MAX) { ++kicks; ++S.kicks; kick = true; } else { deep = true; restart = true; ++S.restarts; }
         break;
       }
       if (ls >= m.max_ls) break;
@@ -634,7 +675,11 @@ void orc_outputs(void* h, double* var, double* tac) {
   if (tac) std::copy(t.begin(), t.begin() + 3 * S.m.ntax, tac);
 }
 int orc_tape_len(void* h) { return (int)((Sim*)h)->tape.size(); }
-void orc_stats(void* h, long* out) { Sim& S = *(Sim*)h; out[0] = S.newton_iters; out[1] = S.substeps; out[2] = S.nonconv; }
+void orc_stats(void* h, long* out) { Sim& S = *(Sim*)h; out[0] = S.newton_iters; out[1] = S.substeps; out[2] = S.nonconv; out[3] = S.evals;
+  out[4] = S.kicks; out[5] = S.restarts; out[6] = S.trust; out[7] = S.ls_exhausted; }
+// 0: globalisation of the HIP kernels (default);  1: literal XML solver (substep_literal above)
+int orc_set_solver(void* h, int mode) { if (mode != 0 && mode != 1) return -1; ((Sim*)h)->solver = mode; return 0; }
+int orc_get_solver(void* h) { return ((Sim*)h)->solver; }
 
 // Adjoint over the newest n taped sub-steps, newest first, continuing the carried adjoint (lam_q, lam_v).
 // df_dq [n*nr], df_dvar [n*3nvar], df_dtac [n*3ntax]: direct partials of the loss w.r.t. the outputs after each of

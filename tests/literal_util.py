@@ -1,0 +1,85 @@
+"""Helpers of the literal-solver tests (test_oracle_literal.py on the CPU, test_gpu_literal.py on the GPU).
+
+The oracle has two Newton drivers (oracle/tsim_oracle.cpp): "kernel" — the globalisation the HIP kernels use (non-monotone steps across
+contact / friction kinks, restart, trust region: DESIGN.md §1) — and "literal" — Newton + monotone backtracking exactly as the model XML
+states it (envs/assets/pusher/pusher.xml:4: tol 1e-8, max_iter 100, max_ls 20), sharing none of the tuned constants.  These helpers
+run the literal solver TEACHER-FORCED: every sub-step starts from the state another solver (the kernel-mode oracle, or the HIP path)
+was in, so a difference in one sub-step is seen as such instead of compounding over the roll-out."""
+import os
+import threading
+
+import numpy as np
+
+
+def run_threads(n_items, work):
+    """work(i, nthr) on min(host threads, n_items) python threads (ctypes releases the GIL inside the oracle)."""
+    nthr = max(1, min(len(os.sched_getaffinity(0)), 32, n_items))
+    err = []
+
+    def guarded(i):
+        try:
+            work(i, nthr)
+        except Exception as ex:          # surface worker failures in the test thread
+            err.append(ex)
+    th = [threading.Thread(target=guarded, args=(i,)) for i in range(nthr)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if err:
+        raise err[0]
+
+
+def literal_substeps(model, q_before, qd_before, u_sub):
+    """One literal sub-step from every given state.  q_before, qd_before [N, nr] (state BEFORE the sub-step), u_sub [N, nu].
+    Returns q1 [N, nr], qd1 [N, nr], converged [N] bool, and the summed solver statistics."""
+    from oracle.oracle import OracleSim
+    N = q_before.shape[0]
+    q1, qd1, ok = np.zeros_like(q_before), np.zeros_like(q_before), np.zeros(N, dtype=bool)
+    stats = []
+
+    def work(i, nthr):
+        o = OracleSim(model, solver="literal")
+        for j in range(i, N, nthr):
+            o.reset(q_before[j], qd_before[j])
+            ok[j] = o.forward(u_sub[j], 1) == 0
+            q1[j], qd1[j] = o.state()
+        stats.append(o.stats())
+    run_threads(N, work)
+    tot = {k: sum(s[k] for s in stats) for k in stats[0]}
+    return q1, qd1, ok, tot
+
+
+def kernel_mode_rollout(model, q0, u, S):
+    """Kernel-mode oracle roll-out that keeps every sub-step's state: q [B, T*S + 1, nr], qd likewise (index 0 = initial state),
+    converged [B, T*S], and per sub-step whether a globalisation device of the kernel-mode solver acted (kick / restart / trust region)."""
+    from oracle.oracle import OracleSim
+    B, T = u.shape[0], u.shape[1]
+    nr = q0.shape[1]
+    q, qd = np.zeros((B, T * S + 1, nr)), np.zeros((B, T * S + 1, nr))
+    ok, acted = np.zeros((B, T * S), dtype=bool), np.zeros((B, T * S), dtype=bool)
+
+    def work(i, nthr):
+        o = OracleSim(model)
+        for e in range(i, B, nthr):
+            o.reset(q0[e])
+            q[e, 0], qd[e, 0] = o.state()
+            for t in range(T):
+                for s in range(S):
+                    a = o.stats()
+                    ok[e, t * S + s] = o.forward(u[e, t], 1) == 0
+                    b = o.stats()
+                    acted[e, t * S + s] = any(b[k] != a[k] for k in ("kicks", "restarts", "trust_region"))
+                    q[e, t * S + s + 1], qd[e, t * S + s + 1] = o.state()
+    run_threads(B, work)
+    return q, qd, ok, acted
+
+
+def compare_with_literal(model, q_traj, qd_traj, u, S):
+    """Teacher-forced comparison of a recorded trajectory (q_traj, qd_traj [B, T*S + 1, nr]; any solver) with the literal solver.
+    Returns dq [B, T*S] = max_k |q1_recorded - q1_literal|, literal-converged [B, T*S], literal statistics."""
+    B, n1, nr = q_traj.shape
+    n = n1 - 1
+    qb, qdb = q_traj[:, :-1].reshape(B * n, nr), qd_traj[:, :-1].reshape(B * n, nr)
+    us = np.repeat(u, S, axis=1).reshape(B * n, -1)
+    q1, _, ok, stats = literal_substeps(model, qb, qdb, us)
+    dq = np.abs(q1.reshape(B, n, nr) - q_traj[:, 1:]).max(axis=2)
+    return dq, ok.reshape(B, n), stats

@@ -30,8 +30,9 @@ def _weights():
     return rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0
 
 
-def _oracle_subset(model, q0, u, idx, weights=None, want_sig=False):
-    """Oracle trajectories (and episode gradients / branch signatures) of the environments idx, on all host threads."""
+def _oracle_subset(model, q0, u, idx, weights=None, want_sig=False, solver="kernel"):
+    """Oracle trajectories (and episode gradients / branch signatures) of the environments idx, on all host threads.
+    solver: the oracle's Newton driver ("kernel": the HIP kernels' globalisation; "literal": the XML's own, test_gpu_literal.py)."""
     from oracle.oracle import OracleSim
     n = len(idx)
     out = {"q": np.zeros((T, n, 7)), "qd": np.zeros((T, n, 7)), "var": np.zeros((T, n, 6)), "tac": np.zeros((T, n, 390)),
@@ -41,7 +42,7 @@ def _oracle_subset(model, q0, u, idx, weights=None, want_sig=False):
 
     def work(i):
         try:
-            o = OracleSim(model)
+            o = OracleSim(model, solver=solver)
             for j in range(i, n, nthr):
                 e = idx[j]
                 o.reset(q0[e], record=weights is not None)
