@@ -54,12 +54,12 @@ PMC_PASSES = [
 ]
 
 
-def algorithmic_bytes(nr, nu, nvar, ntac, S, esz):
+def algorithmic_bytes(nr, nu, nvar, ntac, S, esz, tape=True):
     """per env-step, state on chip across the S sub-steps, model constants batch-shared:
     fwd = esz (nu + nr + nvar + ntac + 2 nr S), bwd = esz (2 nr S + nr + nvar + ntac + nu S)   (1 916 / 2 012 B for fp32
     TactilePush).  As built, the tape holds q as double and the Newton matrix: that is implementation traffic
     and shows in `traffic`, not here."""
-    fwd = esz * (nu + nr + nvar + ntac + 2 * nr * S)
+    fwd = esz * (nu + nr + nvar + ntac + (2 * nr * S if tape else 0))      # forward-only: no tape (1 636 B for fp32 TactilePush)
     bwd = esz * (2 * nr * S + nr + nvar + ntac + nu * S)
     return fwd, bwd
 
@@ -84,19 +84,205 @@ def usable_cores():
     return n
 
 
+WORKLOADS = {
+    # name: (model asset, environments per GPU, env-steps per episode, forward-only, BASELINE.json config)
+    "push": ("pusher", 4096, 100, False, "configs[2]: TactilePush gd_tactile fwd+adjoint, batch 4096 on one MI355X"),
+    "dclaw": ("dclaw_position_control", 2048, 20, True, "configs[3]: D'Claw rotate, 16 384 environments over 8 GPUs = 2048 per GPU, forward-only (PPO roll-out)"),
+    "insertion": ("tactile_insertion", 4096, 9, True, "configs[4]: TactileInsertion, 32 768 environments over 8 GPUs = 4096 per GPU, 45-sub-step episodes, "
+                                                      "forward-only + the 118 296-B policy-gradient all-reduce per episode"),
+}
+
+
+def fatal(msg, rc=2):
+    print("bench.py: " + msg, file=sys.stderr, flush=True)
+    sys.exit(rc)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves — one process per GPU under
+    torch.distributed.run, as the driver does (the reference's only parallel launch is SubprocVecEnv's process-per-worker,
+    externals/pytorch-a2c-ppo-acktr-gail/a2c_ppo_acktr/envs.py:100-108)."""
+    import socket
+    if args.backend == "nccl" and os.environ.get("TSIM_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < args.gpus:
+        fatal("--gpus %d but only %d GPU(s) visible (one process per GPU; TSIM_BENCH_SHARE_GPU=1 with --backend gloo is the 1-GPU plumbing test)"
+              % (args.gpus, torch.cuda.device_count()))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def make_workload(name, B, T, S, rank, dev, tdt):
+    """Synthetic inputs of one BASELINE config, resident in HBM (seed differs per rank so that ranks do different work)."""
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd import workloads as W
+    model = load_model(W.asset(WORKLOADS[name][0]))
+    if name == "push":
+        q0, u, _ = W.push_workload(B, T, seed=rank)
+    elif name == "dclaw":
+        q0, u = W.dclaw_workload(B, T, seed=7 + rank)
+    else:
+        q0, u = W.insertion_workload(B, T, seed=7 + rank)
+    return {"name": name, "model": model, "S": S, "T": T, "B": B,
+            "q0": torch.tensor(q0, device=dev, dtype=tdt), "u": torch.tensor(u, device=dev, dtype=tdt).transpose(0, 1).contiguous()}
+
+
+class Leg:
+    """One workload on one BatchSim: runs env-steps as episodes of <= T (forward all, then backward all) and keeps the HIP-event times
+    of the launches of its timed part."""
+
+    def __init__(self, wl, dev, tdt, forward_only, world=1, backend="nccl"):
+        from tactilesimulation_amd.host.batch import BatchSim
+        self.wl, self.dev, self.tdt, self.forward_only, self.world, self.backend = wl, dev, tdt, forward_only, world, backend
+        B, T, S = wl["B"], wl["T"], wl["S"]
+        self.sim = sim = BatchSim(wl["model"], B, device=str(dev), dtype=tdt, tape_capacity=0 if forward_only else T * S)
+        self.nr, self.nu, self.nvar, self.ntac = sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile
+        one = lambda d, s=1.0: torch.ones(B, d, device=dev, dtype=tdt) * s
+        self.wq, self.wv, self.wt = one(self.nr), (one(self.nvar) if self.nvar else None), one(self.ntac, 100.0)
+        if not forward_only:
+            self.wqT, self.wvT, self.wtT = ((w.unsqueeze(0).expand(T, -1, -1).contiguous() if w is not None else None) for w in (self.wq, self.wv, self.wt))
+        self.grad_buf = torch.zeros(POLICY_GRAD_FLOATS, device=dev, dtype=torch.float32)
+        self.out = {}
+        self.ev = {"fwd": [], "bwd": []}
+
+    def run(self, k_total, timed, launch):
+        sim, wl, T, S, u = self.sim, self.wl, self.wl["T"], self.wl["S"], self.wl["u"]
+        done = bad = 0
+        Ev = lambda: torch.cuda.Event(enable_timing=True)
+        ng = min(6, self.nu)
+        while done < k_total:
+            n = min(T, k_total - done)
+            sim.reset(wl["q0"], None, backward_flag=not self.forward_only)
+            if launch == "episode":
+                e0, e1, e2 = Ev(), Ev(), Ev()
+                e0.record()
+                ro = sim.rollout(u[:n], S)
+                e1.record()
+                status = ro["status"]
+                if not self.forward_only:
+                    du = sim.backward_episode(n, S, self.wqT[:n], self.wvT[:n] if self.wvT is not None else None, self.wtT[:n])
+                    e2.record()
+                    self.grad_buf[:ng] = du.sum((0, 1)).float()[:ng]
+                if timed:
+                    self.ev["fwd"].append((e0, e1, n))
+                    if not self.forward_only:
+                        self.ev["bwd"].append((e1, e2, n))
+            else:
+                for t in range(n):
+                    if timed:
+                        e0, e1 = Ev(), Ev()
+                        e0.record()
+                    sim.step(u[t], S, out=self.out)
+                    if timed:
+                        e1.record()
+                        self.ev["fwd"].append((e0, e1, 1))
+                status = self.out["status"]
+                if not self.forward_only:
+                    for t in reversed(range(n)):
+                        if timed:
+                            e0, e1 = Ev(), Ev()
+                            e0.record()
+                        du = sim.backward_steps(S, self.wq, self.wv, self.wt)
+                        if timed:
+                            e1.record()
+                            self.ev["bwd"].append((e0, e1, 1))
+                    self.grad_buf[:ng] = du[0].sum(0).float()[:ng]
+            bad += int((status != 0).sum().item()) if not timed else 0
+            if self.world > 1:
+                import torch.distributed as dist
+                if self.backend == "nccl":
+                    dist.all_reduce(self.grad_buf)       # GD outer loop: policy-gradient all-reduce over xGMI (RCCL), 118 296 B
+                else:
+                    g = self.grad_buf.cpu(); dist.all_reduce(g); self.grad_buf.copy_(g)
+            done += n
+        return bad
+
+    def ev_stats(self, key):
+        lst = self.ev[key]
+        if not lst:
+            return 0.0, 0.0, 0
+        ms = [a.elapsed_time(b) for a, b, _ in lst]
+        fr = [n for _, _, n in lst]
+        return float(np.mean(ms)), float(sum(ms) / sum(fr)), int(round(np.mean(fr)))
+
+    def roofline(self, esz):
+        """HBM side of the roofline for the dominant kernel of this leg: SURVEY.md §8d's algorithmic bytes over the HIP-event time."""
+        S = self.wl["S"]
+        fb, bb = algorithmic_bytes(self.nr, self.nu, self.nvar, self.ntac, S, esz, tape=not self.forward_only)
+        fwd_ms, fwd_ms_step, fwd_frames = self.ev_stats("fwd")
+        bwd_ms, bwd_ms_step, bwd_frames = self.ev_stats("bwd")
+        dom, dom_ms, dom_bytes, dom_frames = ("k_forward", fwd_ms, fb, fwd_frames) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb, bwd_frames)
+        achieved = dom_bytes * self.wl["B"] * dom_frames / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        return {"bound": "valu-issue latency (one wavefront per SIMD; not HBM: SURVEY.md §0.6) — the HBM figures below are reported as the task asks",
+                "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                "algorithmic_bytes_per_launch": dom_bytes * self.wl["B"] * dom_frames, "env_steps_per_launch": dom_frames,
+                "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb, "source": "SURVEY.md §8d (general formula)"},
+                "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms},
+                "kernel_ms_per_env_step": {"k_forward": fwd_ms_step, "k_backward": bwd_ms_step},
+                "valu": None}, (dom, dom_ms, dom_frames)
+
+
+def sub_record(name, dtype, dev, steps=None, warm=None):
+    """A short N = 1 leg of another BASELINE config (or of the headline workload in another dtype), reported inside the headline's JSON
+    line: value, kernel times by HIP events, HBM roofline from the general formula of SURVEY.md §8d."""
+    asset_, B, T, fwd_only, cfg = WORKLOADS[name]
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    esz = 4 if dtype == "f32" else 8
+    T = min(T, 20) if name == "push" else T
+    wl = make_workload(name, B, T, 5, 0, dev, tdt)
+    leg = Leg(wl, dev, tdt, fwd_only)
+    steps = steps or 2 * T
+    leg.run(warm or T, False, "episode")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    leg.run(steps, True, "episode")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bad = leg.run(T, False, "episode")
+    rl, _ = leg.roofline(esz)
+    info = leg.sim.launch_info()
+    del leg
+    torch.cuda.empty_cache()
+    return {"workload": cfg, "model": asset_, "batch": B, "dtype": dtype, "value": B * steps / dt, "unit": "env-steps/s",
+            "what": ("forward only" if fwd_only else "forward + adjoint") + ", 5 sub-steps per env-step, episodes of %d env-steps, one launch per episode each way" % T,
+            "steps": steps, "ms_per_step": dt / steps * 1e3, "nonconverged_envs": bad, "launch_shape": info, "roofline": rl}
+
+
+def plumbing_only(args, world, rank):
+    """No simulator, no GPU needed: the process group of `--gpus N`, one barrier, one all-reduce of the policy-gradient payload."""
+    import torch.distributed as dist
+    ranks = 1
+    if world > 1:
+        t = torch.ones(POLICY_GRAD_FLOATS, dtype=torch.float32)
+        dist.all_reduce(t)
+        ranks = int(t[0].item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "ranks_in_allreduce": ranks, "backend": args.backend if world > 1 else None,
+                          "allreduce_bytes": 4 * POLICY_GRAD_FLOATS, "value": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--workload", default="push", choices=sorted(WORKLOADS), help="push = the headline (BASELINE configs[2]); dclaw / insertion = "
+                    "configs[3] / [4] at their per-GPU share, forward-only (reported as sub-records of the default N = 1 line too)")
+    ap.add_argument("--batch", type=int, default=None, help="environments per GPU (default: the workload's per-GPU share)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--frame-skip", type=int, default=5)
-    ap.add_argument("--episode", type=int, default=100, help="env-steps per episode (tape length / frame_skip)")
+    ap.add_argument("--episode", type=int, default=None, help="env-steps per episode (tape length / frame_skip; default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic / roofline.valu then "
                     "come from the committed profile of this command, with the source stated)")
     ap.add_argument("--no-closed-loop", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the f64 / dclaw / insertion legs of the N = 1 line")
     ap.add_argument("--pmc-dump", default=None, help="write the counters of the in-run --pmc passes to this JSON file (profiles/)")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] style run (not the headline)")
     ap.add_argument("--launch", default="episode", choices=["episode", "step"],
@@ -108,101 +294,67 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the real multi-GPU path) or gloo (plumbing test: with TSIM_BENCH_SHARE_GPU=1 "
                          "all ranks share cuda:0 and the collectives go through host copies)")
+    ap.add_argument("--plumbing-only", action="store_true", help="set up the ranks of --gpus N, run one all-reduce of the policy-gradient "
+                    "payload, print n_gpus and exit (no simulator; works without a GPU on gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        fatal("--gpus must be >= 1")
+    if args.forward_only and args.workload != "push":
+        fatal("--forward-only is a TactilePush option; dclaw / insertion are forward-only already")
 
+    # ---- ranks: under a launcher WORLD_SIZE is set; a bare `python bench.py --gpus N` starts its own N ranks
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        fatal("--gpus %d but WORLD_SIZE %d: the launcher's rank count and --gpus disagree" % (args.gpus, world))
+    share = os.environ.get("TSIM_BENCH_SHARE_GPU") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if os.environ.get("TSIM_BENCH_SHARE_GPU") == "1":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what this host driver supports (task statement)
+        if share:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
+            if share:
+                fatal("TSIM_BENCH_SHARE_GPU=1 needs --backend gloo (RCCL wants one device per rank)")
+            if torch.cuda.device_count() < world:
+                fatal("--gpus %d but only %d GPU(s) visible" % (world, torch.cuda.device_count()))
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        if dist.get_world_size() != args.gpus:
+            fatal("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    if args.plumbing_only:
+        return plumbing_only(args, world, rank)
+    if not torch.cuda.is_available():
+        fatal("no GPU visible: the HIP path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    ranks_seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t)                                            # the first collective: every rank must be in it
+        ranks_seen = int(t.item())
+        if ranks_seen != args.gpus:
+            fatal("all-reduce saw %d ranks, --gpus %d" % (ranks_seen, args.gpus))
 
-    from tactilesimulation_amd.model.compiler import load_model
-    from tactilesimulation_amd.host.batch import BatchSim
-    from tactilesimulation_amd.workloads import push_workload, PUSHER_BLOB
-
-    model = load_model(PUSHER_BLOB)
-    B, S, T = args.batch, args.frame_skip, args.episode
+    asset_, B_def, T_def, fwd_only_def, cfg_text = WORKLOADS[args.workload]
+    B = args.batch or B_def
+    S, T = args.frame_skip, (args.episode or T_def)
+    forward_only = args.forward_only or fwd_only_def
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
     esz = 4 if args.dtype == "f32" else 8
-    sim = BatchSim(model, B, device=str(dev), dtype=tdt, tape_capacity=T * S)
-    nr, nu, nvar, ntac = sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile
-
-    # synthetic inputs, resident in HBM (seed differs per rank so that ranks do different work)
-    q0_np, u_np, _ = push_workload(B, T, seed=rank)
-    q0 = torch.tensor(q0_np, device=dev, dtype=tdt)
-    u = torch.tensor(u_np, device=dev, dtype=tdt).transpose(0, 1).contiguous()      # [T, B, 6]
-    wq = torch.ones(B, nr, device=dev, dtype=tdt)
-    wv = torch.ones(B, nvar, device=dev, dtype=tdt)
-    wt = torch.ones(B, ntac, device=dev, dtype=tdt) * 100.0
-    wqT, wvT, wtT = (w.unsqueeze(0).expand(T, -1, -1).contiguous() for w in (wq, wv, wt))    # per-frame seeds [T, B, dim]
-    grad_buf = torch.zeros(POLICY_GRAD_FLOATS, device=dev, dtype=torch.float32)
-    out = {}
-    ev = {"fwd": [], "bwd": []}
-
-    def run_steps(k_total, timed, launch):
-        """k_total env-steps as episodes of <= T: forward all, backward all."""
-        done = 0
-        bad = 0
-        Ev = lambda: torch.cuda.Event(enable_timing=True)
-        while done < k_total:
-            n = min(T, k_total - done)
-            sim.reset(q0, None, backward_flag=not args.forward_only)
-            if launch == "episode":
-                e0, e1, e2 = Ev(), Ev(), Ev()
-                e0.record()
-                ro = sim.rollout(u[:n], S)
-                e1.record()
-                status = ro["status"]
-                if not args.forward_only:
-                    du = sim.backward_episode(n, S, wqT[:n], wvT[:n], wtT[:n])
-                    e2.record()
-                    grad_buf[:6] = du.sum((0, 1)).float()[:6] if nu >= 6 else 0.0
-                if timed:
-                    ev["fwd"].append((e0, e1, n))
-                    if not args.forward_only:
-                        ev["bwd"].append((e1, e2, n))
-            else:
-                for t in range(n):
-                    if timed:
-                        e0, e1 = Ev(), Ev()
-                        e0.record()
-                    sim.step(u[t], S, out=out)
-                    if timed:
-                        e1.record()
-                        ev["fwd"].append((e0, e1, 1))
-                status = out["status"]
-                if not args.forward_only:
-                    for t in reversed(range(n)):
-                        if timed:
-                            e0, e1 = Ev(), Ev()
-                            e0.record()
-                        du = sim.backward_steps(S, wq, wv, wt)
-                        if timed:
-                            e1.record()
-                            ev["bwd"].append((e0, e1, 1))
-                    grad_buf[:6] = du[0].sum(0).float()[:6] if nu >= 6 else 0.0
-            bad += int((status != 0).sum().item()) if not timed else 0
-            if world > 1:
-                import torch.distributed as dist
-                if args.backend == "nccl":
-                    dist.all_reduce(grad_buf)       # GD outer loop: policy-gradient all-reduce over xGMI (RCCL)
-                else:
-                    g = grad_buf.cpu(); dist.all_reduce(g); grad_buf.copy_(g)
-            done += n
-        return bad
+    wl = make_workload(args.workload, B, T, S, rank, dev, tdt)
+    model = wl["model"]
+    leg = Leg(wl, dev, tdt, forward_only, world, args.backend)
+    sim = leg.sim
+    nr, nu, nvar, ntac = leg.nr, leg.nu, leg.nvar, leg.ntac
+    run_steps = leg.run
 
     def sync_all():
         torch.cuda.synchronize()
@@ -228,14 +380,8 @@ def main():
         dt = float(tt.item())
 
     # kernel durations of the timed region (HIP events on the launching stream), per launch and per env-step
-    def ev_stats(lst):
-        if not lst:
-            return 0.0, 0.0, 0
-        ms = [a.elapsed_time(b) for a, b, _ in lst]
-        fr = [n for _, _, n in lst]
-        return float(np.mean(ms)), float(sum(ms) / sum(fr)), int(round(np.mean(fr)))
-    fwd_ms, fwd_ms_step, fwd_frames = ev_stats(ev["fwd"])
-    bwd_ms, bwd_ms_step, bwd_frames = ev_stats(ev["bwd"])
+    fwd_ms, fwd_ms_step, fwd_frames = leg.ev_stats("fwd")
+    bwd_ms, bwd_ms_step, bwd_frames = leg.ev_stats("bwd")
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"timed_only": True, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
@@ -249,7 +395,6 @@ def main():
     # second leg, reported next to the headline: the other launch granularity on the same workload (short, after the
     # timed region)
     other = "step" if args.launch == "episode" else "episode"
-    ev_main, ev = ev, {"fwd": [], "bwd": []}
     k_other = min(args.steps, 40)
     run_steps(min(k_other, 5), False, other)
     torch.cuda.synchronize()
@@ -257,39 +402,35 @@ def main():
     run_steps(k_other, False, other)
     torch.cuda.synchronize()
     other_value = B * k_other / (time.perf_counter() - t1)
-    ev = ev_main
 
     # untimed: Newton work statistics (residual evaluations per env-step) of the same workload
-    sim.reset(q0, None, backward_flag=False)
+    sim.reset(wl["q0"], None, backward_flag=False)
     evs = []
+    out = {}
     for t in range(min(T, 30)):
-        sim.step(u[t], S, out=out)
+        sim.step(wl["u"][t], S, out=out)
         evs.append(sim.last_evals())
     evs = np.array(evs)
     status_bad = int((out["status"] != 0).sum().item())
     launch_shape = sim.launch_info()
 
     if rank == 0:
-        fb, bb = algorithmic_bytes(nr, nu, nvar, ntac, S, esz)
-        dom, dom_ms, dom_bytes, dom_frames = ("k_forward", fwd_ms, fb, fwd_frames) if fwd_ms >= bwd_ms else ("k_backward", bwd_ms, bb, bwd_frames)
-        achieved = dom_bytes * B * dom_frames / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        rl, (dom, dom_ms, dom_frames) = leg.roofline(esz)
         value = B * world * args.steps / dt
+        what = "fwd only" if forward_only else "fwd+bwd"
+        label = {"push": "TactilePush", "dclaw": "DClaw rotate", "insertion": "TactileInsertion"}[args.workload]
         res = {
-            "metric": ("env-steps/sec (fwd+bwd) TactilePush batch=%d" % B) if not args.forward_only else ("env-steps/sec (fwd only) TactilePush batch=%d" % B),
+            "metric": "env-steps/sec (%s) %s batch=%d" % (what, label, B),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "TactilePush (pusher.xml, 13x10 taxels, ndof_r 7) gd_tactile fwd+adjoint, frame_skip %d, "
-                                   "batch %d envs/GPU, episodes of %d env-steps" % (S, B, T),
+            "config": {"workload": ("TactilePush (pusher.xml, 13x10 taxels, ndof_r 7) gd_tactile %s, frame_skip %d, batch %d envs/GPU, episodes of %d env-steps"
+                                    % ("fwd+adjoint" if not forward_only else "forward only", S, B, T)) if args.workload == "push" else
+                                   "%s; %s.xml, ndof_r %d, %d tactile values, frame_skip %d, batch %d envs/GPU, episodes of %d env-steps" % (cfg_text, asset_, nr, ntac, S, B, T),
                        "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
-            "roofline": {"bound": "valu-issue latency (one wavefront per SIMD; not HBM: SURVEY.md §0.6) — the HBM figures below are reported as the task asks",
-                         "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "algorithmic_bytes_per_launch": dom_bytes * B * dom_frames, "env_steps_per_launch": dom_frames,
-                         "algorithmic_bytes_per_env_step": {"forward": fb, "backward": bb, "source": "SURVEY.md §8d"},
-                         "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms},
-                         "kernel_ms_per_env_step": {"k_forward": fwd_ms_step, "k_backward": bwd_ms_step},
-                         "valu": None},
+            "ranks": {"world_size": world, "ranks_in_first_allreduce": ranks_seen, "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
+                      "shared_gpu": share},
+            "roofline": rl,
             "launch": {"mode": args.launch,
                        "episode": "tsim_rollout + tsim_backward_episode: one launch each way per episode (EpisodicSimFunction's open-loop episode)",
                        "step": "tsim_step + tsim_backward_steps: one launch per env-step each way (StepSimFunction granularity)",
@@ -300,15 +441,15 @@ def main():
                                             "mean_of_per_step_max": float(evs.max(axis=1).mean()), "max": int(evs.max())},
         }
         # free the batch before the other legs (tape: 0.6 GB) — and so that the profiled child runs see an idle GPU
-        del sim
+        del sim, leg
         torch.cuda.empty_cache()
         if world == 1:
             pmc = None
             if not args.no_pmc:
-                pmc = pmc_passes(args)
-            src = "measured in this run: rocprofv3 --pmc passes of `bench.py --timed-only` with this run's --steps / --batch / --dtype"
+                pmc = pmc_passes(args, B, T)
+            src = "measured in this run: rocprofv3 --pmc passes of `bench.py --timed-only` with this run's --steps / --batch / --dtype / --workload"
             if pmc is None or dom not in pmc:
-                pmc, src = pmc_from_profile(args), "profiles/r02_pmc_%s.json (committed rocprofv3 --pmc run of this command; the in-run passes were skipped or failed)" % args.dtype
+                pmc, src = pmc_from_profile(args, B), "profiles/r02_pmc_%s.json (committed rocprofv3 --pmc run of this command; the in-run passes were skipped or failed)" % args.dtype
             if pmc is not None and dom in pmc:
                 fill_roofline_counters(res["roofline"], pmc[dom], src, B, dom_frames, dom_ms)
                 res["roofline"]["counters_per_launch"] = pmc
@@ -317,7 +458,19 @@ def main():
                                "--steps %d --warmup %d --timed-only` %s B=%d; FETCH_SIZE / WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE under-reports "
                                "wide reads by 2x); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles" % (args.steps, args.steps, args.dtype, B),
                                "frames_per_launch": dom_frames, "per_kernel": pmc}, open(args.pmc_dump, "w"), indent=1)
-            if not args.no_closed_loop and not args.forward_only:
+            if args.workload == "push" and not args.no_sub_records:
+                # the reference's arithmetic type (envs/tactile_push_env.py:29 torch.double) and the other two multi-GPU configs, each a
+                # short leg with its own roofline
+                for key, (nm, dty) in {"f64": ("push", "f64"), "dclaw": ("dclaw", args.dtype), "insertion": ("insertion", args.dtype)}.items():
+                    if key == "f64" and (args.dtype == "f64" or forward_only):
+                        continue
+                    try:
+                        res[key] = sub_record(nm, dty, dev)
+                    except Exception as e:      # the headline must not die with an optional leg
+                        res[key] = {"error": repr(e)}
+                if "f64" in res and "value" in res["f64"]:
+                    res["f64_value"] = res["f64"]["value"]
+            if args.workload == "push" and not args.no_closed_loop and not forward_only:
                 try:
                     res["closed_loop"] = closed_loop_leg(model, B, T, tdt, dev)
                 except Exception as e:      # the headline must not die with an optional leg
@@ -327,7 +480,7 @@ def main():
             except Exception as e:
                 res["readout_hbm"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(model, S, not args.forward_only)
+                res["cpu_baseline"] = cpu_baseline(args.workload, model, S, not forward_only)
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -336,7 +489,7 @@ def main():
 
 
 # ---------------------------------------------------------------------------------------------------- hardware counters
-def pmc_passes(args, kernels=("k_forward", "k_backward")):
+def pmc_passes(args, B, T, kernels=("k_forward", "k_backward")):
     """Counters of the bench kernels, collected by re-running this script's timed region under `rocprofv3 --pmc` (counters
     only, one pass per counter group: FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md §rocprofv3 PMC slots).
     Returns {kernel: {counter: mean per dispatch}} or None."""
@@ -350,8 +503,8 @@ def pmc_passes(args, kernels=("k_forward", "k_backward")):
         for i, counters in enumerate(PMC_PASSES):
             d = os.path.join(tmp, "p%d" % i)
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", str(args.steps), "--warmup", str(args.steps), "--batch", str(args.batch), "--dtype", args.dtype,
-                   "--episode", str(args.episode), "--frame-skip", str(args.frame_skip), "--launch", args.launch, "--timed-only", "--no-pmc",
+                   "--steps", str(args.steps), "--warmup", str(args.steps), "--batch", str(B), "--dtype", args.dtype, "--workload", args.workload,
+                   "--episode", str(T), "--frame-skip", str(args.frame_skip), "--launch", args.launch, "--timed-only", "--no-pmc",
                    "--no-cpu-baseline"] + (["--forward-only"] if args.forward_only else [])
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
             per = {k: {} for k in kernels}
@@ -373,13 +526,13 @@ def pmc_passes(args, kernels=("k_forward", "k_backward")):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_from_profile(args):
+def pmc_from_profile(args, B):
     f = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.dtype)
-    if not (os.path.exists(f) and args.batch == 4096):
+    if not (os.path.exists(f) and B == 4096 and args.workload == "push"):
         return None
     try:
         pj = json.load(open(f))
-        if pj.get("frames_per_launch") != min(args.steps, args.episode):
+        if pj.get("frames_per_launch") != min(args.steps, args.episode or 100):
             return None
         return pj["per_kernel"]
     except Exception:
@@ -479,15 +632,18 @@ def readout_leg(tdt, dev, B=256, reps=5):
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(model, S, with_backward):
+def cpu_baseline(workload, model, S, with_backward):
     """fp64 CPU oracle (oracle/tsim_oracle.cpp — the build's own restatement, kind "port") on a bounded sample of the same
     workload, rebuilt here with -O3 -march=native: one thread, and one oracle instance per USABLE core (affinity mask capped
     by the cgroup CPU quota; environments are independent, ctypes releases the GIL)."""
     import threading
     from oracle.oracle import OracleSim
-    from tactilesimulation_amd.workloads import push_workload
-    nenv, nstep = 8, 100
-    q0, u, _ = push_workload(nenv, nstep, seed=0)
+    from tactilesimulation_amd import workloads as W
+    nstep = {"push": 100, "dclaw": 20, "insertion": 9}[workload]
+    gen = {"push": lambda n, seed: W.push_workload(n, nstep, seed=seed)[:2], "dclaw": lambda n, seed: W.dclaw_workload(n, nstep, seed=7 + seed),
+           "insertion": lambda n, seed: W.insertion_workload(n, nstep, seed=7 + seed)}[workload]
+    nenv = 8
+    q0, u = gen(nenv, 0)
     try:
         o = OracleSim(model, native=True)
         flags = "g++ -O3 -march=native (built on this host)"
@@ -504,7 +660,7 @@ def cpu_baseline(model, S, with_backward):
     single = n / dt1
     nthr = usable_cores()
     per = max(2, int(round(12.0 * single / nstep)))            # ~12 s of CPU work per thread
-    q0m, um, _ = push_workload(per * nthr, nstep, seed=1)
+    q0m, um = gen(per * nthr, 1)
     sims = [OracleSim(model, native=native) for _ in range(nthr)]
     done = [0] * nthr
 
@@ -522,7 +678,7 @@ def cpu_baseline(model, S, with_backward):
     busy = ((c1.user - c0.user) + (c1.system - c0.system)) / dtm      # cores actually kept busy
     what = "fwd+adjoint" if with_backward else "fwd only"
     return {"value": sum(done) / dtm, "unit": "env-steps/s", "cores": nthr, "kind": "port",
-            "sample": "%d threads (usable cores) x %d envs x %d env-steps of the same TactilePush workload, %s, fp64, %s, one oracle "
+            "sample": "%d threads (usable cores) x %d envs x %d env-steps of the same workload, %s, fp64, %s, one oracle "
                       "instance per thread; single thread: %d envs x %d env-steps; mean Newton iterations/sub-step %.2f"
                       % (nthr, per, nstep, what, flags, nenv, nstep, st["newton_iters"] / max(st["substeps"], 1)),
             "single_thread_value": single, "host_cpus": os.cpu_count(), "cores_busy": busy}

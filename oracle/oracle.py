@@ -16,10 +16,22 @@ _libs = {}
 _dp = C.POINTER(C.c_double)
 
 
+def _src_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for p in (os.path.join(_DIR, "tsim_oracle.cpp"), os.path.join(_DIR, "..", "include", "tsim_blob.h"), os.path.join(_DIR, "Makefile")):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    src = os.path.join(_DIR, "tsim_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    """Rebuild when the content hash of the sources differs from the one in the sidecar (not by file times)."""
+    side = _SO + ".buildhash"
+    want = _src_hash()
+    have = open(side).read().strip() if os.path.exists(side) else None
+    if force or not os.path.exists(_SO) or have != want:
         subprocess.check_call(["make", "-C", _DIR, "-s", "-B", "libtsim_oracle.so"])
+        open(side, "w").write(want + "\n")
     return _SO
 
 
@@ -36,8 +48,8 @@ def lib(native=False):
         so = _SO_NATIVE if native else _SO
         if native:
             build_native()
-        elif not os.path.exists(so):
-            build()
+        else:
+            build()         # no-op when the sidecar hash matches the sources
         L = C.CDLL(so)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.POINTER(C.c_int), _dp]

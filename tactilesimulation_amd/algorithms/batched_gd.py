@@ -109,21 +109,24 @@ class Actor(torch.nn.Module):
             s.clear()
         self._armed = True
 
-    def assemble_grads(self, keep=False):
+    def assemble_grads(self, keep=False, pairs=None):
         """Deferred mode, after the episode's backward: weight.grad = sum_t g_t^T x_t as ONE batched GEMM per layer and
-        bias.grad = sum_t sum_b g_t (assigned, not accumulated).  keep=True leaves the parked tensors in place — they are the
-        static buffers of a captured graph, rewritten by every replay.  Runs eagerly, outside any graph."""
+        bias.grad = sum_t sum_b g_t (assigned, not accumulated).  Runs eagerly, outside any graph.
+        pairs: per-layer lists of (x, g) to assemble from INSTEAD of the actor's own sinks — a GraphedRollout passes the static
+        buffers of its captured graph (rewritten by every replay), which it keeps apart from the sinks so that eager backward passes
+        through the same actor can neither add to them nor clear them.  keep=True leaves the actor's sinks as they are."""
         linears = [m for m in self.mu_net if isinstance(m, torch.nn.Linear)]
-        for m, sink in zip(linears, self._sinks):
+        own = pairs is None
+        for m, sink in zip(linears, self._sinks if own else pairs):
             if not sink:
                 m.weight.grad = m.bias.grad = None
                 continue
             X, G = torch.stack([x for x, _ in sink]), torch.stack([g for _, g in sink])        # [T, B, in], [T, B, out]
             m.weight.grad = torch.bmm(G.transpose(1, 2), X).sum(0)
             m.bias.grad = G.sum((0, 1))
-            if not keep:
+            if own and not keep:
                 sink.clear()
-        if not keep:
+        if own and not keep:
             self._armed = False
 
 
@@ -150,8 +153,15 @@ class GraphedRollout:
     def __init__(self, env, actor, horizon, q0, goal, disturbances, warmup=2):
         self.env, self.actor, self.horizon = env, actor, horizon
         self.q0, self.goal, self.dist = q0, goal, disturbances
+        sim = getattr(env, "sim", None)
+        if sim is not None:          # host-side batch state is baked into captured launches: fine for BDF1, not for BDF2's history flag
+            from ..model import blob as _blob
+            if int(sim.model.I[_blob.TSIM_IH_INTEGRATOR]) != 1:
+                raise RuntimeError("GraphedRollout: BDF2 models cannot be captured (the integrator's history flag is host state baked into "
+                                   "the captured launch, and the adjoint is BDF1-only)")
         self.deferred = hasattr(actor, "assemble_grads")      # the weight gradients of all env-steps as one GEMM after the replay
         if self.deferred:
+            was_deferred = actor.defer_weight_grads
             actor.defer_weight_grads = True
         side = torch.cuda.Stream(env.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -177,11 +187,22 @@ class GraphedRollout:
         with torch.cuda.graph(self.graph, stream=side):
             self.loss = rollout_loss(env, actor, horizon, q0=q0, goal=goal, disturbances=disturbances)
             self.loss.backward()
+        if self.deferred:
+            # The (x, g) pairs the captured backward parked are the graph's static buffers: take them out of the actor's sinks and hand
+            # the actor back in the mode it came in.  Left in the sinks they were shared with every later eager pass through the actor:
+            # an eager backward appended its own pairs (the next replay then summed them in: exactly twice the gradient in a CPU
+            # repro) and an eager begin_episode() cleared the graph's (the next replay set every .grad to None and optimizer.step()
+            # silently did nothing) — ADVICE r02.
+            self._pairs = [list(s) for s in actor._sinks]
+            for s in actor._sinks:
+                s.clear()
+            actor._armed = False
+            actor.defer_weight_grads = was_deferred
 
     def replay(self):
         self.graph.replay()
         if self.deferred:
-            self.actor.assemble_grads(keep=True)
+            self.actor.assemble_grads(pairs=self._pairs)
         return self.loss
 
 

@@ -368,34 +368,63 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
   const R* tax = a.F + I[TSIM_IH_FOFF_TAXEL];                          // SoA planes: position (3), axis0, axis1, normal (9); shared
   R* out = a.tac_out + (size_t)env * 3 * ntax;
   const int te = min(ntax, ((int)blockIdx.y + 1) * a.slice);
-  for (int t = (int)blockIdx.y * a.slice + (int)threadIdx.x; t < te; t += 256) {
-    int s = 0;                                                         // sensor of taxel t
-    while (s < nsensor - 1 && t >= sEnd[s]) ++s;
-    const int kb = sKb[s], nsp = sNsp[s];
-    const R* sf = sSf + s * TSIM_SF_SIZE;
-    const R* tp = tax + t;
-    const V3<R> xa = mk3<R>(tp[0], tp[ntax], tp[2 * ntax]);
-    V3<R> Fl = zero3<R>();                                             // force on the taxel, sensor-link frame
-    for (int j = 0; j < nsp; ++j) {
-      const int prim = sPrim[kb + j];
-      const R* shape = sShape + (kb + j) * 4;
-      const R* P = sP + (kb + j) * TP_R_SIZE;
-      const double* D = sD + (kb + j) * TP_D_SIZE;
-      const M3<R> RPA = ldm(P);
-      // fp32 kernels: most taxels of a large pad are nowhere near the primitive; decide that from an fp32 position
-      if (sizeof(R) == 4 && !(prim_distance<R>(prim, shape, mulMv(RPA, xa) + ldv(P + 9)) < R(TS_FAR_MARGIN))) continue;
-      const V3<double> xPd = mulMv(ldm(D), cvt3<double>(xa)) + ldv(D + 9);
-      const V3<R> xP = cvt3<R>(xPd);
-      V3<R> Fc; M3<R> Jx, Jv;
-      if (contact_law<R, false>(prim, shape, sf, xP, ldv(P + 15) + cross3(ldv(P + 12), xP), Fc, Jx, Jv, xPd)) Fl = Fl + mulMtv(RPA, Fc);
-    }
+  // Output: 12 (fp64: 24) bytes per taxel, taxel-major.  Stored by the lane that computed it that is three scalar stores with a 12-byte
+  // lane stride — every store instruction touches 768 bytes to write 256.  Instead each wavefront transposes its 64 x 3 values through a
+  // PRIVATE 192-real LDS tile and writes them as contiguous 16-byte vectors (48 lanes x dwordx4 for fp32).  The tile belongs to one
+  // wavefront, whose DS instructions execute in issue order: no barrier of any kind (the block-wide version with two __syncthreads per
+  // 256 taxels was slower than the scalar stores).
+  constexpr int VEC = 16 / (int)sizeof(R);                             // reals per 16-byte vector
+  typedef R vecR __attribute__((ext_vector_type(VEC)));
+  __shared__ __attribute__((aligned(16))) R sOut[4][3 * TS_WAVE];
+  const int wave = (int)threadIdx.x >> 6, wl = (int)threadIdx.x & (TS_WAVE - 1);
+  for (int base = (int)blockIdx.y * a.slice + wave * TS_WAVE; base < te; base += 256) {
+    const int t = base + wl;
+    const bool valid = t < te;
     R o0 = R(0), o1 = R(0), o2 = R(0);
-    if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {                // the nine axis constants only for taxels that carry a force
-      o0 = Fl.x * tp[3 * ntax] + Fl.y * tp[4 * ntax] + Fl.z * tp[5 * ntax];
-      o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
-      o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
+    if (valid) {
+      int s = 0;                                                       // sensor of taxel t
+      while (s < nsensor - 1 && t >= sEnd[s]) ++s;
+      const int kb = sKb[s], nsp = sNsp[s];
+      const R* sf = sSf + s * TSIM_SF_SIZE;
+      const R* tp = tax + t;
+      const V3<R> xa = mk3<R>(tp[0], tp[ntax], tp[2 * ntax]);
+      V3<R> Fl = zero3<R>();                                           // force on the taxel, sensor-link frame
+      for (int j = 0; j < nsp; ++j) {
+        const int prim = sPrim[kb + j];
+        const R* shape = sShape + (kb + j) * 4;
+        const R* P = sP + (kb + j) * TP_R_SIZE;
+        const double* D = sD + (kb + j) * TP_D_SIZE;
+        const M3<R> RPA = ldm(P);
+        // fp32 kernels: most taxels of a large pad are nowhere near the primitive; decide that from an fp32 position
+        if (sizeof(R) == 4 && !(prim_distance<R>(prim, shape, mulMv(RPA, xa) + ldv(P + 9)) < R(TS_FAR_MARGIN))) continue;
+        const V3<double> xPd = mulMv(ldm(D), cvt3<double>(xa)) + ldv(D + 9);
+        const V3<R> xP = cvt3<R>(xPd);
+        V3<R> Fc; M3<R> Jx, Jv;
+        if (contact_law<R, false>(prim, shape, sf, xP, ldv(P + 15) + cross3(ldv(P + 12), xP), Fc, Jx, Jv, xPd)) Fl = Fl + mulMtv(RPA, Fc);
+      }
+      if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {              // the nine axis constants only for taxels that carry a force
+        o0 = Fl.x * tp[3 * ntax] + Fl.y * tp[4 * ntax] + Fl.z * tp[5 * ntax];
+        o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
+        o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
+      }
     }
-    out[3 * t] = o0; out[3 * t + 1] = o1; out[3 * t + 2] = o2;
+    if (base + TS_WAVE <= te) {                                        // a full tile (wave-uniform): transpose + vector stores
+      R* tile = sOut[wave];
+      tile[3 * wl] = o0; tile[3 * wl + 1] = o1; tile[3 * wl + 2] = o2;
+      TS_SYNC();                                                       // compiler fence only: same wavefront, DS order is issue order
+      R* dst = out + (size_t)3 * base;
+      // 16-byte vector stores where the destination allows it (3 ntax reals per environment: 16-byte aligned rows iff ntax is a
+      // multiple of 4 (fp32) / 2 (fp64)); otherwise dword-aligned rows take 8-byte (fp32: 2 reals) stores
+      if ((reinterpret_cast<size_t>(dst) & 15) == 0) {
+        for (int i = wl; i < 3 * TS_WAVE / VEC; i += TS_WAVE)
+          *reinterpret_cast<vecR*>(dst + i * VEC) = *reinterpret_cast<const vecR*>(tile + i * VEC);
+      } else {
+        for (int i = wl; i < 3 * TS_WAVE; i += TS_WAVE) dst[i] = tile[i];    // contiguous dwords across the lanes: still full lines
+      }
+      TS_SYNC();
+    } else if (valid) {
+      out[3 * t] = o0; out[3 * t + 1] = o1; out[3 * t + 2] = o2;
+    }
   }
 }
 
@@ -1171,6 +1200,8 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   TS_DEVICE(b);
   hipStream_t st = (hipStream_t)stream;
   const bool tac = tac_out && b->ntax > 0 && b->nspt > 0;
+  // taxels that are paired with no primitive (a sensor body without a general_primitive_contact) read zero, as in k_forward's read-out
+  if (tac_out && b->ntax > 0 && b->nspt == 0 && zero_async(tac_out, (size_t)b->B * 3 * b->ntax * b->esz, st)) return 1;
   if (tac && (b->nspt > TX_MAXK || b->I[TSIM_IH_NSENSOR] > TX_MAXS)) return fail("readout: more than " + std::to_string((int)TX_MAXK) + " (sensor, primitive) combinations or " + std::to_string((int)TX_MAXS) + " sensors (k_taxels staging)");
   // taxels per block of k_taxels: aim at ~8192 blocks in all (several per SIMD at any batch size): 256 for the single environment of
   // test_sim_speed.py (157 blocks for its 40 000 taxels), 1 280 for B = 256

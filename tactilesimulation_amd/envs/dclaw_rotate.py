@@ -163,6 +163,13 @@ class GraphedCollector:
 
     def __init__(self, env, policy, warmup=2):
         self.env, self.policy = env, policy
+        # Host-side batch state travels as kernel ARGUMENTS and is frozen at its capture-time value in a replayed graph.  For BDF1
+        # models none of it changes a launch; a BDF2 model's has_prev flag (history of the previous sub-step) would: every replayed
+        # step would silently drop the BDF2 history.  Refuse instead.
+        from ..model import blob as _blob
+        if int(env.sim.model.I[_blob.TSIM_IH_INTEGRATOR]) != 1:
+            raise RuntimeError("GraphedCollector: BDF2 models cannot be captured (the integrator's history flag is host state baked into the "
+                               "captured launch); use the eager loop")
         env._gen = None                                            # the default generator is the one graph capture knows how to advance
         self.next_obs = env.reset().clone()
         self.obs = torch.empty_like(self.next_obs)

@@ -131,7 +131,8 @@ class BatchedStableGraspEnv:
         ro = self.sim.rollout(act, 1, want_var=False, tactile_mask=self.mask)
         self.current_q = ro["q"][-1].clone()
         r, success = reward_done(ro["q"][CAPTURE_FRAME])
-        return observation(ro["tactile"][0]), r, success, ro["status"]
+        self.last_obs = observation(ro["tactile"][0])
+        return self.last_obs, r, success, ro["status"]
 
     def reset(self, mask=None):
         """New episodes for the environments in mask (all when None): a new bar (density variant), grasp position 0, the settled open
@@ -143,8 +144,17 @@ class BatchedStableGraspEnv:
         self.current_q = torch.where(m[:, None], self.q_reference.repeat(self.B, 1), self.current_q)
         self.grasp_position = torch.where(m, torch.zeros_like(self.grasp_position), self.grasp_position)
         self.steps = torch.where(m, torch.zeros_like(self.steps), self.steps)
+        if mask is None or getattr(self, "last_obs", None) is None:
+            obs, _, _, _ = self._grasp()
+            return obs
+        # Only the masked environments take the reset-time grasp (the reference resets one environment at a time,
+        # envs/stable_grasp_env.py:136-163): the others keep the state and the observation their last step() left — the launch runs the
+        # whole batch, its results are kept for the masked rows only.
+        keep_q, keep_obs = self.current_q, self.last_obs
         obs, _, _, _ = self._grasp()
-        return obs
+        self.current_q = torch.where(m[:, None], self.current_q, keep_q)
+        self.last_obs = torch.where(m[:, None], obs, keep_obs)
+        return self.last_obs
 
     def step(self, u):
         """u [B, 1] -> obs [B, 520], reward [B], done [B], info."""

@@ -54,6 +54,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "
                                "g.build()'`). There is no CPU fallback." % LIB_PATH)
+        _check_fresh()
         import torch  # noqa: F401  (loads libamdhip64 first)
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
@@ -66,6 +67,25 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def _check_fresh():
+    """The in-tree library must have been built from the sources it sits next to (content hash in its sidecar, written by
+    __graft_entry__.build()); an A/B library named by TSIM_HIP_LIB is exempt."""
+    if os.environ.get("TSIM_HIP_LIB"):
+        return
+    from . import buildhash
+    root = os.path.abspath(os.path.join(_DIR, "..", ".."))
+    try:
+        import __graft_entry__ as ge
+        srcs = [os.path.join(ge.CSRC, f) for f in ge.HIP_SRCS] + [os.path.join(root, "include", f) for f in ("tsim.h", "tsim_blob.h", "tsim_env.h")]
+        want = buildhash.digest(srcs, ge.HIP_FLAGS)
+    except Exception:          # sources not available (installed without them): nothing to compare with
+        return
+    have = buildhash.read(LIB_PATH)
+    if have != want:
+        raise RuntimeError("%s is stale: it was not built from the sources next to it (sidecar %s, sources %s). Run "
+                           "`python -c 'import __graft_entry__ as g; g.build()'`." % (LIB_PATH, have and have[:12], want[:12]))
 
 
 def check(rc):

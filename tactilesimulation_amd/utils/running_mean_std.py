@@ -11,9 +11,21 @@ import torch
 
 class RunningMeanStd:
     def __init__(self, epsilon=1e-4, shape=(), device="cuda:0"):
-        self.count = float(epsilon)                                   # pseudo-count of the prior (mean 0, variance 1)
+        self._count = float(epsilon)                                  # pseudo-count of the prior (mean 0, variance 1)
         self.mean = torch.zeros(shape, dtype=torch.float32, device=device)
-        self._m2 = torch.full(tuple(shape), self.count, dtype=torch.float32, device=device)      # variance 1 x count
+        self._m2 = torch.full(tuple(shape), self._count, dtype=torch.float32, device=device)     # variance 1 x count
+
+    @property
+    def count(self):
+        return self._count
+
+    @count.setter
+    def count(self, c):
+        """Assigning count keeps `var` (as with the reference's three plain attributes: code that restores mean / var / count from a
+        checkpoint, or the reference's own to(), assigns them in any order)."""
+        c = float(c)
+        self._m2 = self._m2 * (c / self._count)
+        self._count = c
 
     @property
     def var(self):
@@ -40,7 +52,7 @@ class RunningMeanStd:
         shift = batch_mean - self.mean
         self._m2 = self._m2 + batch_var * batch_count + shift * shift * (self.count * batch_count / total)
         self.mean = self.mean + shift * (batch_count / total)
-        self.count = total
+        self._count = float(total)
 
     def normalize(self, x, un_norm=False):
         scale = (self.var + 1e-5).sqrt()

@@ -31,6 +31,38 @@ def push_workload(B, T, seed=0, q_init=None):
     return q0, u, goal
 
 
+def dclaw_workload(B, T, seed=7):
+    """BASELINE configs[3] inputs (D'Claw, dclaw_position_control.xml): q0 [B, 10], u [B, T, 9] absolute joint targets.
+    A grasp of the cap: all three fingertips close on the cylinder and twist it (joint order per finger: base abduction, proximal,
+    distal; limits and relative-target stepping as in envs/dclaw_rotate_env.py:23,86-96,201-207)."""
+    rng = np.random.default_rng(seed)
+    q0 = np.zeros((B, 10)); q0[:, [1, 4, 7]] = 0.1; q0[:, [2, 5, 8]] = 0.97
+    q0[:, :9] += 0.01 * rng.normal(size=(B, 9))
+    goal = np.zeros(9); goal[[0, 3, 6]] = 0.04; goal[[1, 4, 7]] = 0.1; goal[[2, 5, 8]] = 1.1
+    u = np.zeros((B, T, 9))
+    cur = q0[:, :9].copy()
+    for t in range(T):
+        cur = cur + np.clip(goal - cur, -0.02, 0.02) + 0.005 * rng.uniform(-1, 1, size=(B, 9))
+        u[:, t] = cur
+    return q0, u
+
+
+def insertion_workload(B, T, seed=7):
+    """BASELINE configs[4] inputs (tactile_insertion.xml): q0 [B, 12], u [B, T, 6].  Grasp as in envs/tactile_insertion_env.py:126-170
+    (height 0.2, fingers open at -0.03, closing force ramp), then drag the gripped box sideways into the hole walls; T = 9 env-steps of 5
+    sub-steps = the env's 45-sub-step episode (:53)."""
+    rng = np.random.default_rng(seed)
+    q0 = np.zeros((B, 12)); q0[:, 2] = 0.2; q0[:, 4] = -0.03; q0[:, 5] = -0.03
+    q0[:, 6:8] += 5e-4 * rng.normal(size=(B, 2))
+    u = np.zeros((B, T, 6))
+    for t in range(T):
+        a = min(1.0, (t + 1) / 5.0)
+        drift = 0.004 * max(0.0, (t - 5) / 8.0)
+        u[:, t] = np.array([drift, 0.6 * drift, 0.2, 0.05 * max(0.0, (t - 7) / 6.0), a, a]) + \
+            np.concatenate([1e-4 * rng.normal(size=(B, 3)), np.zeros((B, 3))], axis=1)
+    return q0, u
+
+
 import os as _os
 
 ASSETS = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "assets")

@@ -109,9 +109,25 @@ def test_graphed_rollout_matches_eager(pusher_model):
         le = rollout_loss(ref_env, actor, T, q0=q0, goal=goal, disturbances=D)
         ref = torch.autograd.grad(le, [p for p in params if p.requires_grad], allow_unused=True)
         ref = [r for r in ref if r is not None]
+        assert len(got) == len(ref) == 6                       # three weights, three biases (logstd is unused in deterministic mode)
         assert abs(lg - float(le.detach())) < 1e-9 * abs(float(le.detach()))
         for a, b in zip(got, ref):
             assert float((a - b).abs().max()) < 1e-8 * max(float(b.abs().max()), 1.0)
+    # The graph's (x, g) buffers are its own: an eager episode through the same actor in deferred mode — begin_episode()
+    # clears the actor's sinks, backward() fills them, assemble_grads() empties them — neither adds to the next replay nor empties it.
+    assert actor.defer_weight_grads is False and not any(actor._sinks)
+    actor.defer_weight_grads = True
+    actor.begin_episode()
+    rollout_loss(ref_env, actor, T, q0=q0, goal=goal, disturbances=D).backward()
+    actor.assemble_grads()
+    eager = [p.grad.clone() for p in actor.parameters() if p.grad is not None]
+    actor.defer_weight_grads = False
+    gr.replay()
+    again = [p.grad.clone() for p in actor.parameters() if p.grad is not None]
+    assert len(again) == len(got) == len(eager) == 6
+    for a, b, c in zip(again, got, eager):
+        assert torch.equal(a, b)                                # the replay of trial 1, bit for bit
+        assert float((c - b).abs().max()) < 1e-8 * max(float(b.abs().max()), 1.0)
 
 
 def test_batched_gd_training_reduces_the_loss(pusher_model):
@@ -156,7 +172,6 @@ def test_batched_gd_training_reduces_the_loss(pusher_model):
             actor.defer_weight_grads = False                   # the reference gradient: plain autograd, per-step weight gradients
             le = rollout_loss(ref_env, actor, T, q0=q0, goal=goal, disturbances=D)
             ref = torch.autograd.grad(le, [p for _, p in named])
-            actor.defer_weight_grads = True
             # parameter by parameter: the replayed bias gradients of the 64-wide layers were 40-140 % off while the flat
             # gradient's norm hid it (profiles/r02_graph_bias_grad.md); the same episode, weight gradients summed per step (eager) or as one batched GEMM (replay): equal to fp32 rounding
             for (n, _), a, b in zip(named, got, ref):

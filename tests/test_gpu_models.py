@@ -41,33 +41,15 @@ def _inputs(name, m, B_, T):
     rng = np.random.default_rng(7)
     q0c, us, _, _ = CASES[name]
     if name == "dclaw_position_control":
-        # a grasp of the cap: all three fingertips close on the cylinder and twist it (joint order per finger: base
-        # abduction, proximal, distal; limits and relative-target stepping as in envs/dclaw_rotate_env.py:23,86-96,201-207)
-        q0 = np.zeros((B_, 10)); q0[:, [0, 3, 6]] = 0.0; q0[:, [1, 4, 7]] = 0.1; q0[:, [2, 5, 8]] = 0.97
-        q0[:, :9] += 0.01 * rng.normal(size=(B_, 9))
-        goal = np.zeros(9); goal[[0, 3, 6]] = 0.04; goal[[1, 4, 7]] = 0.1; goal[[2, 5, 8]] = 1.1
-        u = np.zeros((B_, T, 9))
-        cur = q0[:, :9].copy()
-        for t in range(T):
-            cur = cur + np.clip(goal - cur, -0.02, 0.02) + 0.005 * rng.uniform(-1, 1, size=(B_, 9))
-            u[:, t] = cur
-        return q0, u
+        from tactilesimulation_amd.workloads import dclaw_workload        # shared with bench.py --workload dclaw
+        return dclaw_workload(B_, T, seed=7)
     if name == "ball_push":
         q0 = np.tile(q0c, (B_, 1)) + 0.02 * rng.normal(size=(B_, 9)) * np.array([0, 0, 0, 0.05, 0.05, 0, 1, 1, 1])
         u = np.stack([[[0.3 * np.sin(t + e), 0.25 * np.cos(t - e), -0.4 + 0.05 * rng.uniform(-1, 1)] for t in range(T)] for e in range(B_)])
         return q0, u
     if name == "tactile_insertion":
-        # grasp as in envs/tactile_insertion_env.py:126-170 (height 0.2, fingers open at -0.03, closing force ramp),
-        # then drag the gripped box sideways into the hole walls
-        q0 = np.zeros((B_, 12)); q0[:, 2] = 0.2; q0[:, 4] = -0.03; q0[:, 5] = -0.03
-        q0[:, 6:8] += 5e-4 * rng.normal(size=(B_, 2))
-        u = np.zeros((B_, T, 6))
-        for t in range(T):
-            a = min(1.0, (t + 1) / 5.0)
-            drift = 0.004 * max(0.0, (t - 5) / 8.0)
-            u[:, t] = np.array([drift, 0.6 * drift, 0.2, 0.05 * max(0.0, (t - 7) / 6.0), a, a]) + \
-                np.concatenate([1e-4 * rng.normal(size=(B_, 3)), np.zeros((B_, 3))], axis=1)
-        return q0, u
+        from tactilesimulation_amd.workloads import insertion_workload    # shared with bench.py --workload insertion
+        return insertion_workload(B_, T, seed=7)
     q0 = np.tile(q0c, (B_, 1)) + 1e-3 * rng.normal(size=(B_, q0c.size)) * (name != "box_rest")
     u = np.stack([[us(rng) for _ in range(T)] for _ in range(B_)]).reshape(B_, T, m.ndof_u)
     return q0, u

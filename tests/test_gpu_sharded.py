@@ -107,3 +107,22 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_batch(tmp_path, dtype, tol):
     err = float((parts[0]["flat"] - g_ref).abs().max()) / float(g_ref.abs().max())
     assert err < tol, err                               # sum over two partial sums vs one sum: round-off only
     assert float(g_ref.abs().max()) > 0
+
+
+def test_bench_gpus_2_self_launched_on_one_gpu():
+    """`python bench.py --gpus 2` with NO launcher (the shape of the driver's N = 1 command with another N): two ranks are started, both
+    run the real simulator (sharing cuda:0, collectives over gloo — the only multi-rank run a 1-GPU box allows) and the line says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TSIM_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--batch", "512",
+                        "--episode", "6", "--no-cpu-baseline", "--no-pmc"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks"]["ranks_in_first_allreduce"] == 2 and j["ranks"]["shared_gpu"] is True
+    assert j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["roofline"]["kernel_ms"]["k_forward"] > 0
