@@ -168,6 +168,28 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes
 /* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */
 int tsim_last_evals(tsim_batch* b, int32_t* host_out);
 
+/* The Newton iteration of a sub-step is the loop the model's <solver_option tol max_iter max_ls> states (envs/assets/pusher/pusher.xml:4)
+ * and nothing else: up to max_iter iterations, each halving its step until ||g|| decreases, at most max_ls times, taking the last trial
+ * if none did; converged when ||g||_2 < tol.  fp64 batches run exactly that by default.  Two options around it, neither of which the
+ * reference has (its arithmetic is fp64 and it runs one environment at a time):
+ *   cross_kinks  (default: 1 for TSIM_F32, 0 for TSIM_F64)  a line search whose max_ls + 1 trials all fail is a non-smooth local minimum
+ *                of ||g|| at a contact / friction kink.  The literal loop gets across it with its 2^-max_ls step and ~150 more
+ *                evaluations in fp64; in fp32 it often does not (step lengths of 1e-6 drown in rounding) and runs to max_iter while the
+ *                rest of the batch waits.  With the option, and only when ||g|| < TSIM_KINK_FACTOR x tol (close to convergence, where the
+ *                Newton step is small), a trial still rejected after TSIM_KINK_LS halvings is followed by the full Newton step across
+ *                the kink, at most TSIM_KINK_MAX times per sub-step: the same root, ~20 evaluations.  Everywhere else the loop is the
+ *                literal one.
+ *   eval_budget  (default 0 = none)  residual evaluations one sub-step may take; a sub-step cut short is flagged in status exactly like
+ *                one that hit max_iter.  For throughput-minded roll-out collection on stiff models (a TactileInsertion grasp can make
+ *                plain backtracking creep for ~2000 evaluations, and a batch waits for its slowest environment).
+ * Host-side only: takes effect with the next launch. */
+#define TSIM_KINK_FACTOR 1000.0
+#define TSIM_KINK_LS 4
+#define TSIM_KINK_MAX 6
+int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget);
+/* largest ||g||_2 any sub-step of the most recent forward launch ended with, per environment (HOST float[B]); synchronises. */
+int tsim_last_gnorm(tsim_batch* b, float* host_out);
+
 const char* tsim_last_error(void);
 
 #ifdef __cplusplus

@@ -36,17 +36,8 @@ enum {
   TSIM_IH_SIZE = 40
 };
 
-/* Newton globalisation constants shared by the kernels and the oracle: backtracking halves the step at
- * most min(max_ls, TSIM_LS_SHORT) times; if no trial reduces ||g||, the full Newton step is taken anyway (non-monotone
- * step across a contact / friction kink), at most TSIM_KICK_MAX times per sub-step; a sub-step that needs more is restarted
- * from the predictor with monotone backtracking down to 2^-max_ls. */
-#define TSIM_LS_SHORT 4
-#define TSIM_KICK_MAX 6
-/* Trust region of one Newton step: a direction whose largest component exceeds TSIM_STEP_MAX (radians / metres per sub-step: 100 rad/s
- * or 100 m/s at h = 5 ms, an order of magnitude beyond anything these models do) is scaled back to it.  Inactive on every converging
- * sub-step; it keeps the non-monotone steps from jumping to the spurious far roots that stiff penalty contact gives the implicit
- * equations (a gripped box "converging" to a state 2.5 turns away at 3 000 rad/s: tools/insertion_env_substeps.py). */
-#define TSIM_STEP_MAX 0.5
+/* The Newton iteration of a sub-step is fully specified by the model's <solver_option>: TSIM_FH_TOL, TSIM_IH_MAX_ITER, TSIM_IH_MAX_LS
+ * (backtracking halvings per iteration).  No other solver constant exists: kernels and oracle run that loop literally. */
 
 /* ---- float header (F[0..TSIM_FH_SIZE)) ---- */
 enum { TSIM_FH_H = 0, TSIM_FH_GX, TSIM_FH_GY, TSIM_FH_GZ, TSIM_FH_TOL, TSIM_FH_SIZE = 8 };

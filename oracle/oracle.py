@@ -91,10 +91,11 @@ def _f(a, n=None):
 class OracleSim:
     """One environment, fp64, CPU. Mirrors the stepping/adjoint part of redmax_py.Simulation."""
 
-    def __init__(self, model, native=False, solver="kernel"):
-        """solver: "kernel" — the Newton globalisation the HIP kernels use (non-monotone steps across kinks, restart, trust
-        region: DESIGN.md §1);  "literal" — Newton + monotone backtracking exactly as the model XML states it
-        (tol / max_iter / max_ls of <solver_option>, nothing else; substep_literal in tsim_oracle.cpp)."""
+    def __init__(self, model, native=False, solver="literal"):
+        """solver: "literal" (default) — Newton + monotone backtracking exactly as the model XML states it (tol / max_iter / max_ls
+        of <solver_option>, nothing else; substep_literal in tsim_oracle.cpp) — the loop the HIP kernels run since round 3;
+        "r02" — the globalisation kernels and oracle shared in rounds 1-2 (non-monotone steps across kinks, restart, trust region),
+        kept only to document what it did (tests/test_oracle_literal.py)."""
         self.model = model
         self._L = lib(native)
         self._I = np.ascontiguousarray(model.I, dtype=np.int32)
@@ -108,7 +109,7 @@ class OracleSim:
         self.set_solver(solver)
 
     def set_solver(self, solver):
-        mode = {"kernel": 0, "literal": 1}[solver]
+        mode = {"r02": 0, "literal": 1}[solver]
         if self._L.orc_set_solver(self._h, mode) != 0:
             raise RuntimeError("oracle: bad solver mode")
         self.solver = solver

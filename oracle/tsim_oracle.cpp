@@ -445,7 +445,7 @@ struct Sim {
   std::vector<Rec> tape;
   std::vector<std::vector<Rec>> cache;
   bool record = false;
-  int solver = 0;          // 0: the globalisation the HIP kernels use;  1: LITERAL — exactly what the XML states (below)
+  int solver = 1;          // 1 (default): LITERAL — exactly what the XML states, and what the HIP kernels run;  0: the round-2 globalisation (legacy, kept to document what it did)
   long newton_iters = 0, substeps = 0, nonconv = 0, evals = 0;
   long kicks = 0, restarts = 0, trust = 0, ls_exhausted = 0;   // how often each globalisation device acted (kernel mode) / a line search ran out (literal mode)
 };
@@ -508,15 +508,24 @@ static void eval_g_jac(const Model& m, const double* q1, const double* q0, const
 static double norm2(int n, const double* x) { double s = 0; for (int i = 0; i < n; ++i) s += x[i] * x[i]; return std::sqrt(s); }
 
 
-// LITERAL solver (orc_set_solver(h, 1)): Newton with monotone backtracking exactly as the model file states it and nothing
+// Constants of the LEGACY (round-2) globalisation only — solver mode 0 below; the literal solver reads none of them.
+#ifndef TSIM_LS_SHORT
+#define TSIM_LS_SHORT 4
+#endif
+#define TSIM_KICK_MAX 6
+#define TSIM_STEP_MAX 0.5
+
+// LITERAL solver (the default, orc_set_solver(h, 1)): Newton with monotone backtracking exactly as the model file states it and nothing
 // else — `<solver_option tol="1e-8" max_iter="100" max_ls="20"/>` (envs/assets/pusher/pusher.xml:4; the same line in
 // dclaw_position_control.xml, tactile_insertion.xml, stable_grasp.xml): up to max_iter Newton iterations; each halves the
 // step until ||g|| decreases, at most max_ls times; converged when ||g||_2 < tol.  No non-monotone steps, no restart, no trust
-// region, no "100 tol" acceptance: none of the constants of include/tsim_blob.h (TSIM_LS_SHORT / TSIM_KICK_MAX / TSIM_STEP_MAX)
-// is read here.  When no trial of a line search reduces ||g|| the smallest one (alpha = 2^-max_ls) is taken and the iteration
+// region, no "100 tol" acceptance: none of the legacy constants above is read here.  When no trial of a line search reduces ||g|| the smallest one (alpha = 2^-max_ls) is taken and the iteration
 // goes on — the loop has no exit the XML does not name [CHOICE: DiffRedMax's own behaviour there is unknown, source absent].
-// This mode exists so that the HIP path can be checked against a solver that does NOT share its performance-driven
-// globalisation (tests/test_oracle_literal.py, tests/test_gpu_literal.py).
+// Since round 3 the HIP kernels run this very loop (k_forward's Newton state machine), so the fp64 kernels take the same iterates.
+// History: rounds 1-2 ran a performance-driven globalisation in kernel AND oracle (mode 0 below: backtracking cut short after 4
+// halvings, then the full Newton step taken anyway, restart, trust region).  Checked against this literal loop in round 3 it turned
+// out to land on ANOTHER ROOT — 0.15 rad / 2 cm away, |g| < tol — on 11 of 4096 TactileInsertion grasps (tests/test_oracle_literal.py
+// keeps one of them as a regression), and was removed from the kernels.
 static int substep_literal(Sim& S, const double* u, const StepCoef& c, double* q1) {
   const Model& m = S.m; int nr = m.nr;
   double g[MAXR], H[MAXR * MAXR], dq[MAXR], qn[MAXR], gn[MAXR];
@@ -564,7 +573,7 @@ static int substep(Sim& S, const double* u) {
     if (it == m.max_iter) break;
     for (int k = 0; k < nr; ++k) g[k] = -g[k];
     if (!solve_dense(nr, H, g, dq, false)) break;
-    {                                            // trust region (include/tsim_blob.h TSIM_STEP_MAX)
+    {                                            // trust region (legacy constant TSIM_STEP_MAX)
       double mx = 0.0;
       for (int k = 0; k < nr; ++k) mx = std::max(mx, std::fabs(dq[k]));
       if (mx > TSIM_STEP_MAX) { ++S.trust; for (int k = 0; k < nr; ++k) dq[k] *= TSIM_STEP_MAX / mx; }
@@ -580,7 +589,7 @@ static int substep(Sim& S, const double* u) {
       eval_g_c(m, qn, c, u, gn); ++S.evals;
       if (norm2(nr, gn) < gnorm) { accepted = true; if (trace) fprintf(stderr, "    accept alpha %.3g\n", alpha); break; }
       if (!deep && ls >= std::min(m.max_ls, TSIM_LS_SHORT)) {
-        if (kicks < TSIM_KICK_MAX) { ++kicks; ++S.kicks; kick = true; } else { deep = true; restart = true; ++S.restarts; }
+        if (kicks < TSIM_KICK_MAX) { ++kicks; ++S.kicks; kick = true; if (trace) { double mx = 0; for (int k = 0; k < nr; ++k) mx = std::max(mx, std::fabs(dq[k])); fprintf(stderr, "KICK it %d gn %.3e step_inf %.3e\n", it, gnorm, mx); } } else { deep = true; restart = true; ++S.restarts; }
         break;
       }
       if (ls >= m.max_ls) break;
@@ -677,7 +686,7 @@ void orc_outputs(void* h, double* var, double* tac) {
 int orc_tape_len(void* h) { return (int)((Sim*)h)->tape.size(); }
 void orc_stats(void* h, long* out) { Sim& S = *(Sim*)h; out[0] = S.newton_iters; out[1] = S.substeps; out[2] = S.nonconv; out[3] = S.evals;
   out[4] = S.kicks; out[5] = S.restarts; out[6] = S.trust; out[7] = S.ls_exhausted; }
-// 0: globalisation of the HIP kernels (default);  1: literal XML solver (substep_literal above)
+// 1 (default): literal XML solver (substep_literal above) = what the HIP kernels run;  0: the round-2 globalisation (legacy)
 int orc_set_solver(void* h, int mode) { if (mode != 0 && mode != 1) return -1; ((Sim*)h)->solver = mode; return 0; }
 int orc_get_solver(void* h) { return ((Sim*)h)->solver; }
 

@@ -130,7 +130,38 @@ template <class T, class U> __device__ __forceinline__ M3<T> ldm_as(const U* p) 
 #pragma unroll
   for (int i = 0; i < 9; ++i) A.m[i] = (T)p[i];
   return A; }
-__device__ __forceinline__ void t_sincos_d(double x, double& s, double& c) { sincos(x, &s, &c); }
+// sin and cos of a joint angle in double, ~45 instructions and branch-free: round-to-nearest multiple of pi/2 removed with three FMAs
+// (pi/2 as a 3 x 53-bit sum: exact enough for |x| < ~1e6 rad, i.e. any joint angle a simulation can reach), fdlibm's kernel
+// polynomials on [-pi/4, pi/4], quadrant fix-up by selects.  Within 1 - 2 ulp of libm.  The library sincos() is several hundred
+// instructions with data-dependent branches (Payne-Hanek path for huge arguments) and sits on the critical path of every
+// evaluation (the revolute step of the pose chain, which a lone wavefront executes serially).  -DTS_LIBM_SINCOS restores it (A/B).
+__device__ __forceinline__ void t_sincos_d(double x, double& s, double& c) {
+#ifdef TS_LIBM_SINCOS
+  sincos(x, &s, &c);
+#else
+  const double kf = rint(x * 6.36619772367581382433e-01);              // 2 / pi
+  double r = fma(-kf, 1.57079632679489655800e+00, x);                  // pi/2 = hi + mid + lo
+  r = fma(-kf, 6.12323399573676603587e-17, r);
+  r = fma(-kf, -1.49738490485916983834e-33, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)kf & 3;
+  const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+#endif
+}
 template <class T> __device__ __forceinline__ S6<T> ld6(const T* p) { return mk6<T>(ldv(p), ldv(p + 3)); }
 template <class T> __device__ __forceinline__ void st6(T* p, S6<T> v) { stv(p, v.a); stv(p + 3, v.l); }
 // p[0..6) += s * v   (read-modify-write of a 6-vector in LDS)
@@ -279,6 +310,13 @@ template <int LPE, class R> __device__ __forceinline__ R seg_bcast(R x, int src)
   return lane_gather(x, ((int)threadIdx.x & ~(LPE - 1)) + src);
 }
 
+// A value that is the same in every lane of the wavefront (model constants read from the staged tables), moved to a scalar
+// register explicitly.  The tables sit in LDS, and what comes back from a ds_read is a vector register the compiler does not
+// always prove uniform: branches on it are then built from exec masks (v_cmp + s_and_saveexec + s_xor + s_or per arm, every arm
+// visited) instead of one s_cbranch — the primitive-type switch of contact_law alone was ~40 such instructions per chunk of contact
+// points.  A lone wavefront pays 4 cycles for every instruction it issues, scalar or vector.
+__device__ __forceinline__ int ts_u(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
 // ------------------------------------------------------------------------------------------------ per-block context
 template <class R> struct Ctx {
   const int* I; const R* F;               // model records (int blob; link / dof / motor / pair / sensor float tables): staged in LDS
@@ -354,11 +392,11 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, i
 // lane k < nr walks only the links of the branch of its own dof k — all branches advance together, and the sweep takes
 // max(branch size) steps instead of nl.
 //   S[0] = number of ints, S[1] = steps, S[2 + l] = branch of lane l (l < 16; -1: lane has no dof),
-//   S[18 + b] = leader lane of branch b, S[34] = number of branches, S[35] = unused,
+//   S[18 + b] = leader lane of branch b, S[34] = number of branches, S[35] = offset of the taxel staging table (ts_tax_table),
 //   S[TS_SCHED_ENT + step * 16 + l] = link visited by lane l at that step | leader << 8 (0: none; the leader lane of a
 //   branch stores the link's value record), then per link 8 ints: parent, joint type, dof0, ndof, ancestor mask, branch.
 // The leaf->root projection (phase 3) uses the same lists backwards, one lane per (direction, branch).
-enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_STAGE_CPT = 35, TS_SCHED_ENT = 36, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
+enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_TAXTAB = 35, TS_SCHED_ENT = 36, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
 __device__ __forceinline__ int ts_sched_rec(const int* S) { return TS_SCHED_ENT + S[1] * 16; }
 // ... followed by a copy of the contact-pair int records (TSIM_PI_*), for the lanes = pairs staging of phase 2
 template <class C> __device__ __forceinline__ const int* ts_pair_rec(const C& c, int pk) {
@@ -371,6 +409,9 @@ template <class C> __device__ __forceinline__ const int* ts_dof_motor(const C& c
   return c.LI + ts_sched_rec(c.LI) + c.nl * TS_LR_SIZE + c.npair * TSIM_PI_SIZE;
 }
 template <class C> __device__ __forceinline__ const int* ts_motor_rec(const C& c, int m) { return ts_dof_motor(c) + 16 + m * TSIM_MI_SIZE; }
+// ... and, last, the taxel staging table of k_taxels (tsim_readout): per sensor 3 ints (end of its taxel range, first (sensor,
+// primitive) record, number of records), then per record 2 ints (primitive type, contact pair)
+__device__ __forceinline__ const int* ts_tax_table(const int* S) { return S + S[TS_SCHED_TAXTAB]; }
 
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
@@ -403,7 +444,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     }
     TS_SYNC();
     c.Fg = F; c.F = mf;
-    c.cpt_lds = ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt) != 0;
+    c.cpt_lds = ts_u(ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt)) != 0;
     c.CPT = F + I[TSIM_IH_FOFF_CPT];
     c.CPTl = (__attribute__((address_space(3))) const R*)(mf + (c.cpt_lds ? I[TSIM_IH_FOFF_CPT] : 0));
     F = mf;

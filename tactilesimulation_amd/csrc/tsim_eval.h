@@ -22,7 +22,7 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
   const int k = lane, nd = c.nd;
   const bool act = TANGENT && lane < c.nr;
   const int* S = c.LI;
-  const int nsteps = S[1], rec0 = ts_sched_rec(S);
+  const int nsteps = ts_u(S[1]), rec0 = TS_SCHED_ENT + nsteps * 16;
   const int l16 = lane & 15;
   const int mybranch = lane < 16 ? S[TS_SCHED_BRANCH + l16] : -1;
   if (act) {                                         // wrench tangents of the links outside this lane's branch start at zero
@@ -287,9 +287,9 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-  const int pt0 = pi[TSIM_PI_PT0], npt = pi[TSIM_PI_NPT];
-  const int prim = pi[TSIM_PI_PRIM];
-  const bool sphere_plane = (pi[TSIM_PI_FLAGS] & 2) != 0;
+  const int pt0 = ts_u(pi[TSIM_PI_PT0]), npt = ts_u(pi[TSIM_PI_NPT]);
+  const int prim = ts_u(pi[TSIM_PI_PRIM]);
+  const bool sphere_plane = (ts_u(pi[TSIM_PI_FLAGS]) & 2) != 0;
   R* S = c.PP + slot * PP_SIZE;
   const M3<double> RPAd = ldm(c.PPd + slot * 12);
   const V3<double> pPAd = ldv(c.PPd + slot * 12 + 9);
@@ -397,10 +397,10 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-  const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB], pt0 = pi[TSIM_PI_PT0], npt = pi[TSIM_PI_NPT];
-  const int prim = pi[TSIM_PI_PRIM];
-  const bool sphere_plane = (pi[TSIM_PI_FLAGS] & 2) != 0;
-  const int anc = anc_of(c.I, c.off_link, la) | anc_of(c.I, c.off_link, lb);
+  const int la = ts_u(pi[TSIM_PI_LINKA]), lb = ts_u(pi[TSIM_PI_LINKB]), pt0 = ts_u(pi[TSIM_PI_PT0]), npt = ts_u(pi[TSIM_PI_NPT]);
+  const int prim = ts_u(pi[TSIM_PI_PRIM]);
+  const bool sphere_plane = (ts_u(pi[TSIM_PI_FLAGS]) & 2) != 0;
+  const int anc = ts_u(anc_of(c.I, c.off_link, la) | anc_of(c.I, c.off_link, lb));
   R* S = c.PP + slot * PP_SIZE;
   const M3<double> RPAd = ldm(c.PPd + slot * 12);
   const V3<double> pPAd = ldv(c.PPd + slot * 12 + 9);
@@ -483,13 +483,13 @@ __device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int
   const int k = lane, nd = c.nd;
   if (k >= c.nr) return;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
-  const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB];
+  const int la = ts_u(pi[TSIM_PI_LINKA]), lb = ts_u(pi[TSIM_PI_LINKB]);
   const R* S = c.PP + slot * PP_SIZE;
   const R* T = c.PT + (slot * nd + k) * PT_SIZE;
   const M3<R> RP = ldm(S + PP_RP);
   const V3<R> pP = ldv(S + PP_PP);
   const S6<R> Ww = wrench_to_world(RP, pP, ld6(S + PP_WN));
-  const R inB = ((anc_of(c.I, c.off_link, lb) >> k) & 1) ? R(1) : R(0);
+  const R inB = ((ts_u(anc_of(c.I, c.off_link, lb)) >> k) & 1) ? R(1) : R(0);
   const S6<R> dWw = wrench_to_world(RP, pP, ld6(T + PT_WN)) + crf(ld6(c.WP + k * 6) * (sq * inB), Ww);
   if (la > 0) {         // link 0 (world-fixed general bodies) takes no wrench
     acc6(c.DT + (la * nd + k) * DT_SIZE + DT_FN, dWw, R(-1));
@@ -526,11 +526,11 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
     TS_SYNC();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
-      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
+      if (ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
     TS_SYNC();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = directions; serial over pairs: two pairs may touch the same link
-      if (c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS] & 1) pair_fold(c, pk, pk - p0, lane, sq);
+      if (ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) pair_fold(c, pk, pk - p0, lane, sq);
     TS_SYNC();
   }
 }
@@ -549,7 +549,7 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   // its parent in registers when the parent is the next link of the lane's sweep (chains); only branching parents go
   // through LDS.
   const int* S = c.LI;
-  const int nsteps = S[1], rec0 = ts_sched_rec(S), ntask = S[TS_SCHED_NB] * nr;
+  const int nsteps = ts_u(S[1]), rec0 = TS_SCHED_ENT + nsteps * 16, ntask = ts_u(S[TS_SCHED_NB]) * nr;
   for (int t0 = 0; t0 < ntask; t0 += LPE) {
     const int t = t0 + lane;
     const bool has = t < ntask;

@@ -50,11 +50,11 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
   for (int s = 0; s < c.nsensor; ++s) {
     const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
     const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
-    const int t0 = si[TSIM_SI_TAX0], nt = si[TSIM_SI_NTAX], sp0 = si[TSIM_SI_SPRIM0], nsp = si[TSIM_SI_NSPRIM];
+    const int t0 = ts_u(si[TSIM_SI_TAX0]), nt = ts_u(si[TSIM_SI_NTAX]), sp0 = ts_u(si[TSIM_SI_SPRIM0]), nsp = ts_u(si[TSIM_SI_NSPRIM]);
     for (int j0 = 0; j0 < nsp || j0 == 0; j0 += TS_PAIR_GROUP) {
       const int je = min(j0 + TS_PAIR_GROUP, nsp);
       TS_SYNC();
-      for (int j = j0; j < je; ++j) pair_stage_value(c, c.I[c.off_sprim + sp0 + j], j - j0, lane == 0);
+      for (int j = j0; j < je; ++j) pair_stage_value(c, ts_u(c.I[c.off_sprim + sp0 + j]), j - j0, lane == 0);
       TS_SYNC();
       // this block's slice [tb, te) of the global taxel range, intersected with the sensor
       const int lo = max(tb, t0) - t0, hi = min(te, t0 + nt) - t0;
@@ -65,15 +65,15 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
         const V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
         V3<R> Fl = zero3<R>();                          // force on the taxel, sensor-link frame
         for (int j = j0; j < je; ++j) {
-          const int pk = c.I[c.off_sprim + sp0 + j];
-          const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+          const int pk = ts_u(c.I[c.off_sprim + sp0 + j]);
+          const int prim = ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_PRIM]);
           const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
           const R* S = c.PP + (j - j0) * PP_SIZE;
           const M3<R> RPA = ldm(S + PP_RPA);
           const V3<double> xPd = mulMv(ldm(c.PPd + (j - j0) * 12), cvt3<double>(xa)) + ldv(c.PPd + (j - j0) * 12 + 9);
           const V3<R> xP = cvt3<R>(xPd);
           V3<R> F; M3<R> Jx, Jv;
-          if (contact_law<R, false>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, ldv(S + PP_VREL) + cross3(ldv(S + PP_WREL), xP), F, Jx, Jv, xPd))
+          if (contact_law<R, false>(prim, pf + TSIM_PF_SHAPE, sf, xP, ldv(S + PP_VREL) + cross3(ldv(S + PP_WREL), xP), F, Jx, Jv, xPd))
             Fl = Fl + mulMtv(RPA, F);
         }
         R* o = tac_out + (size_t)env * 3 * c.ntax + 3 * t;
@@ -100,10 +100,19 @@ template <class R> struct FwdArgs {
   const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
   double* prev; int has_prev;  // state before the previous sub-step [B][2 nr] doubles (BDF2 history across launches)
   int stage_cpt;               // contact-point arrays staged in LDS with the shared tables (sized into the launch's LDS)
+  int cross_kinks;             // full Newton step at an exhausted line search close to convergence (tsim_set_solver_options)
+  int eval_budget;             // residual evaluations a sub-step may take before it is flagged and left (0: the XML's max_iter / max_ls only)
+  float* gnorm;                // [B] largest ||g|| a sub-step of this launch ended with (diagnostics, tsim_last_gnorm)
 };
 
+// -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
+#ifdef TS_WAVES_PER_EU
+#define TS_KLB __launch_bounds__(TS_WAVE, TS_WAVES_PER_EU)
+#else
+#define TS_KLB __launch_bounds__(TS_WAVE)
+#endif
 template <class R, int NRM, bool EXPJ, int LPE>
-__global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
+__global__ void TS_KLB k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   constexpr int NS = TS_WAVE / LPE;
@@ -125,7 +134,8 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
   R* dlbase = c.dq + nr;
   int bad = 0; bool nonfinite = false;
   int evals = 0;
-  const bool bdf2_model = c.I[TSIM_IH_INTEGRATOR] == 2;
+  R gmax = R(0);
+  const bool bdf2_model = ts_u(c.I[TSIM_IH_INTEGRATOR]) == 2;
   bool has_prev = a.has_prev != 0;
   if (bdf2_model && has_prev && lane < nr) {
     c.qm1D[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qm1[lane] = (R)c.qm1D[lane];
@@ -159,49 +169,57 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     const R sq = R(1), sv = c.cv, sa = c.ca;
     if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
     TS_SYNC();
-    // Newton with backtracking, written as a state machine around ONE evaluate call site (code size matters: the
-    // evaluation is ~6k instructions and two inlined copies overflow the instruction cache).  The state is per slot
-    // (identical in all lanes of a slot); a slot that has finished its sub-step keeps evaluating at its final iterate
+    // Newton with backtracking EXACTLY as the model file states it (<solver_option tol max_iter max_ls>, pusher.xml:4): up to max_iter
+    // iterations; each halves the step until ||g|| decreases, at most max_ls times, and takes the last trial if none did; converged when
+    // ||g||_2 < tol.  Nothing else: no non-monotone steps, no restart, no trust region (rounds 1-2 had all three, tuned for the slowest
+    // wavefront; on the stiff TactileInsertion grasp their full Newton step across a kink "converged" to a root 0.15 rad away from the one
+    // plain backtracking reaches — found by the oracle's literal solver in round 3).  The oracle (oracle/tsim_oracle.cpp
+    // substep_literal) is the same loop in fp64; the fp64 kernels take its iterates.
+    // Written as a state machine around ONE evaluate call site (code size matters: the evaluation is ~6k instructions and two inlined
+    // copies overflow the instruction cache): an accepted trial's evaluation is the next iteration's Jacobian evaluation.  The state
+    // is per slot (identical in all lanes of a slot); a slot that has finished its sub-step keeps evaluating at its final iterate
     // (same numbers again) until every slot of the wavefront has finished.
-    // Globalisation: backtracking on ||g||.  ||g|| has non-smooth local minima next to contact /
-    // friction kinks where no short step along the Newton direction reduces it; there the full Newton step is taken
-    // anyway (it lands across the kink, from where the iteration normally converges in two or three steps).  A
-    // sub-step that needs more than TSIM_KICK_MAX such steps (a cycle) is restarted from the predictor with plain
-    // monotone backtracking down to 2^-max_ls, which returns to the last accepted iterate when even that finds no
-    // decrease.
+    // Around that loop, two options (tsim_set_solver_options), both visible to the caller and both OFF for fp64 batches by default —
+    // the fp64 kernels ARE the loop:
+    //  * cross_kinks (fp32 default: on).  ||g|| has non-smooth local minima at contact / friction kinks: the iterate sits on the kink,
+    //    every step along the Newton direction lands on the other piece with a larger ||g||.  The literal loop halves its way down to
+    //    step lengths of 1e-6, takes the last trial anyway (it IS non-monotone there), which puts the iterate just across the kink, and
+    //    converges from the other side — after 130 - 190 evaluations in fp64 (18 of 819 200 TactilePush sub-steps).  In fp32 the
+    //    comparisons at those step lengths drown in rounding: noise-sized "decreases" are accepted for up to max_iter iterations (8 of
+    //    those 18 sub-steps ended non-converged after ~2000 evaluations each, k_forward 5x slower; profiles/r03_solver_probe.md).
+    //    With the option, and ONLY close to convergence (||g|| < TSIM_KINK_FACTOR x tol, where the Newton step is small: <= 1.3e-3 on
+    //    those 18), a trial still rejected after TSIM_KINK_LS halvings is followed by the FULL Newton step across the kink, at most
+    //    TSIM_KINK_MAX times per sub-step: ~20 evaluations, the same root as the literal loop wherever that converges
+    //    (tests/test_gpu_literal.py).  Far from convergence nothing changes: rounds 1-2 took such steps anywhere, and on the stiff
+    //    TactileInsertion grasp (||g|| ~ 1e-3, steps of 0.02 - 0.5) that reached roots 0.15 rad away from the literal one.
+    //  * eval_budget (default 0 = none): an upper bound on the evaluations of one sub-step for throughput-minded roll-out collection;
+    //    a sub-step cut short is flagged non-converged in status.
     R gn = R(0), alpha = R(1);
-    int iter = 0, ls = -1, kicks = 0;          // ls < 0: the evaluation just done is not a line-search trial
-    bool conv = false, forced = false, giving_up = false, deep = false, fin = false;
+    int iter = 0, ls = -1, sub_evals = 0, crossings = 0;       // ls < 0: the evaluation just done is not a line-search trial
+    bool conv = false, fin = false, forced = false;
     while (true) {
       evaluate<R, NRM, EXPJ, LPE>(c, lane, sq, sv, sa);
       const R gnew = block_norm2<LPE>(c.g, nr, lane);
       bool solve = false;
       if (!fin) {
-        ++evals;
-        if (giving_up) { gn = gnew; conv = gn < R(100) * c.tol; fin = true; }      // back at the last accepted iterate
-        else if (ls >= 0 && !forced && !(gnew < gn)) {                             // a rejected line-search trial
-          if (!deep && ls >= min(c.max_ls, TSIM_LS_SHORT)) {
-            if (kicks < TSIM_KICK_MAX) {
-              ++kicks; forced = true;
-              if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-            } else {                           // restart the sub-step, monotone from here on
-              deep = true; iter = 0; ls = -1;
-              if (lane < nr) c.dl[lane] = R(0);
-            }
-          } else if (ls >= c.max_ls) {
-            giving_up = true;
-            if (lane < nr) c.dl[lane] = dlbase[lane];
-          } else {
+        ++evals; ++sub_evals;
+        bool take = false;                     // the point just evaluated becomes the iterate
+        if (ls >= 0 && !forced && !(gnew < gn)) {                                  // a rejected trial
+          if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) {
+            ++crossings; forced = true;        // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
+            if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+          } else if (ls < c.max_ls) {          // halve the step
             alpha *= R(0.5); ++ls;
             if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
-          }
-        } else {
-          if (ls >= 0) ++iter;
+          } else take = true;                  // the literal loop: the last trial is taken anyway
+        } else take = true;                    // the first evaluation of the sub-step, an accepted trial, or the step across a kink
+        if (take) {
           forced = false;
+          if (ls >= 0) ++iter;
           gn = gnew;
           if (!(gn == gn)) { nonfinite = true; fin = true; }
           else if (gn < c.tol) { conv = true; fin = true; }
-          else if (iter >= c.max_iter) fin = true;
+          else if (iter >= c.max_iter || (a.eval_budget > 0 && sub_evals >= a.eval_budget)) fin = true;
           else {
             solve = true;
             if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
@@ -211,11 +229,6 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
       TS_SYNC();
       if (__any(solve)) {
         solve_lanes<R, NRM, LPE, double>(c.H, c.rhs, c.dq, nr, false, lane, solve);
-        {                                      // trust region of the Newton step (include/tsim_blob.h TSIM_STEP_MAX): inactive unless the step is wild
-          const R m = seg_max<LPE>(lane < nr ? t_abs(c.dq[lane]) : R(0));
-          if (solve && lane < nr && m > R(TSIM_STEP_MAX)) c.dq[lane] *= R(TSIM_STEP_MAX) / m;
-          TS_SYNC();
-        }
         if (solve) {
           alpha = R(1); ls = 0;
           if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
@@ -225,6 +238,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
       if (__all(fin)) break;
     }
     if (!conv) ++bad;
+    gmax = t_max(gmax, gn);
     // commit the sub-step: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
     if (a.record && valid) {
       R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
@@ -260,6 +274,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_forward(FwdArgs<R> a) {
     }
     if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
     if (a.evals && lane == 0) a.evals[env] = evals;
+    if (a.gnorm && lane == 0) a.gnorm[env] = (float)gmax;
   }
 }
 
@@ -333,8 +348,13 @@ template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int
 // ranges, the primitive of every (sensor, primitive) record with its shape, the sensors' penalty parameters and the pose records are
 // put in LDS once; inside the taxel loop the only global accesses left are the taxel's own constants and its 12 output bytes.  (Read
 // from global memory in the loop they are chains of dependent ~600-cycle loads — index -> record -> value — and the loop was exactly
-// that latency: 55 us for 256 x 40 000 taxels.)
+// that latency: 55 us for 256 x 40 000 taxels.)  The integer part of the staging (per sensor: end of its taxel range, first record,
+// number of records; per record: primitive type, contact pair) is a MODEL constant: the host builds it once (build_sched, ts_tax_table)
+// so that the prologue is one cooperative copy instead of a serial walk of dependent global loads by thread 0.
 enum { TX_MAXS = 16, TX_MAXK = 64 };
+#ifndef TS_TAX_UNROLL
+#define TS_TAX_UNROLL 2      // taxels per thread and loop iteration: their loads are in flight together (A/B: profiles/r03_readout_ab.md)
+#endif
 template <class R>
 __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
   const int env = blockIdx.x;
@@ -344,87 +364,86 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
   __shared__ int sEnd[TX_MAXS], sKb[TX_MAXS], sNsp[TX_MAXS], sPrim[TX_MAXK];
   __shared__ R sSf[TX_MAXS * TSIM_SF_SIZE], sShape[TX_MAXK * 4], sP[TX_MAXK * TP_R_SIZE];
   __shared__ double sD[TX_MAXK * TP_D_SIZE];
+  __shared__ __attribute__((aligned(16))) R sC[TX_MAXK * 4];          // per record: the primitive's centre in the sensor-link frame, (bounding radius + margin)^2
   {
-    const int off_sensor = I[TSIM_IH_OFF_SENSOR], off_sprim = I[TSIM_IH_OFF_SPRIM], off_pair = I[TSIM_IH_OFF_PAIR];
+    const int* TT = ts_tax_table(I + I[TSIM_IH_NI]);
     const int foff_sensor = I[TSIM_IH_FOFF_SENSOR], foff_pair = I[TSIM_IH_FOFF_PAIR];
-    if (threadIdx.x == 0) {
-      int kb = 0;
-      for (int s = 0; s < nsensor; ++s) {
-        const int* si = I + off_sensor + s * TSIM_SI_SIZE;
-        sEnd[s] = si[TSIM_SI_TAX0] + si[TSIM_SI_NTAX]; sKb[s] = kb; sNsp[s] = si[TSIM_SI_NSPRIM];
-        for (int j = 0; j < si[TSIM_SI_NSPRIM]; ++j) {
-          const int pk = I[off_sprim + si[TSIM_SI_SPRIM0] + j];
-          sPrim[kb + j] = I[off_pair + pk * TSIM_PI_SIZE + TSIM_PI_PRIM];
-          for (int e = 0; e < 4; ++e) sShape[(kb + j) * 4 + e] = F[foff_pair + pk * TSIM_PF_SIZE + TSIM_PF_SHAPE + e];
-        }
-        kb += si[TSIM_SI_NSPRIM];
-      }
-    }
+    for (int i = threadIdx.x; i < nsensor; i += 256) { sEnd[i] = TT[3 * i]; sKb[i] = TT[3 * i + 1]; sNsp[i] = TT[3 * i + 2]; }
+    for (int i = threadIdx.x; i < a.nspt; i += 256) sPrim[i] = TT[3 * nsensor + 2 * i];
+    for (int i = threadIdx.x; i < a.nspt * 4; i += 256) sShape[i] = F[foff_pair + TT[3 * nsensor + 2 * (i >> 2) + 1] * TSIM_PF_SIZE + TSIM_PF_SHAPE + (i & 3)];
     for (int i = threadIdx.x; i < nsensor * TSIM_SF_SIZE; i += 256) sSf[i] = F[foff_sensor + i];
     for (int i = threadIdx.x; i < a.nspt * TP_R_SIZE; i += 256) sP[i] = a.poseR[(size_t)env * a.nspt * TP_R_SIZE + i];
     for (int i = threadIdx.x; i < a.nspt * TP_D_SIZE; i += 256) sD[i] = a.poseD[(size_t)env * a.nspt * TP_D_SIZE + i];
+    __syncthreads();
+    // "Certainly outside" in 7 instructions: a taxel at x_A (sensor-link frame) cannot touch a primitive whose bounding sphere (centre
+    // c_A = -R_PA^T p_PA, radius r_b) it is farther from than r_b + TS_FAR_MARGIN.  Most taxels of a large pad are nowhere near the
+    // primitive, and for them this replaces the rotation into the primitive's frame (12 LDS reads, ~25 instructions); the margin is
+    // far above the rounding of the test, so the set of taxels contact_law accepts is unchanged.  Planes have no bound (radius < 0).
+    for (int k = threadIdx.x; k < a.nspt; k += 256) {
+      const R* P = sP + k * TP_R_SIZE;
+      const V3<R> cA = mulMtv(ldm(P), ldv(P + 9)) * R(-1);
+      const R* sh = sShape + k * 4;
+      const int prim = sPrim[k];
+      R rb = R(-1);
+      if (prim == TSIM_P_SPHERE) rb = sh[0];
+      else if (prim == TSIM_P_CUBOID) rb = t_sqrt(sh[0] * sh[0] + sh[1] * sh[1] + sh[2] * sh[2]);
+      else if (prim == TSIM_P_CYLINDER) rb = t_sqrt(sh[0] * sh[0] + sh[1] * sh[1]);
+      sC[4 * k] = cA.x; sC[4 * k + 1] = cA.y; sC[4 * k + 2] = cA.z;
+      sC[4 * k + 3] = rb < R(0) ? R(-1) : (rb + R(TS_FAR_MARGIN)) * (rb + R(TS_FAR_MARGIN));
+    }
     __syncthreads();
   }
   const R* tax = a.F + I[TSIM_IH_FOFF_TAXEL];                          // SoA planes: position (3), axis0, axis1, normal (9); shared
   R* out = a.tac_out + (size_t)env * 3 * ntax;
   const int te = min(ntax, ((int)blockIdx.y + 1) * a.slice);
-  // Output: 12 (fp64: 24) bytes per taxel, taxel-major.  Stored by the lane that computed it that is three scalar stores with a 12-byte
-  // lane stride — every store instruction touches 768 bytes to write 256.  Instead each wavefront transposes its 64 x 3 values through a
-  // PRIVATE 192-real LDS tile and writes them as contiguous 16-byte vectors (48 lanes x dwordx4 for fp32).  The tile belongs to one
-  // wavefront, whose DS instructions execute in issue order: no barrier of any kind (the block-wide version with two __syncthreads per
-  // 256 taxels was slower than the scalar stores).
-  constexpr int VEC = 16 / (int)sizeof(R);                             // reals per 16-byte vector
-  typedef R vecR __attribute__((ext_vector_type(VEC)));
-  __shared__ __attribute__((aligned(16))) R sOut[4][3 * TS_WAVE];
-  const int wave = (int)threadIdx.x >> 6, wl = (int)threadIdx.x & (TS_WAVE - 1);
-  for (int base = (int)blockIdx.y * a.slice + wave * TS_WAVE; base < te; base += 256) {
-    const int t = base + wl;
-    const bool valid = t < te;
+  // One taxel: its three outputs go out as ONE 12-byte (fp64: 24-byte) store per lane — consecutive lanes, consecutive addresses: a
+  // wavefront's store instruction covers 768 contiguous bytes (global_store_dwordx3 in the ISA).  Routing them through LDS for 16-byte
+  // vectors instead was measured twice and is slower both ways (block-wide with barriers: round 2; wave-private without: round 3,
+  // 2.45 -> 2.12 TB/s on the bench leg, profiles/r03_readout_ab.md).
+  auto taxel = [&](int t, V3<R> xa) {
+    int s = 0;                                                         // sensor of taxel t
+    while (s < nsensor - 1 && t >= sEnd[s]) ++s;
+    const int kb = sKb[s], nsp = sNsp[s];
+    const R* sf = sSf + s * TSIM_SF_SIZE;
+    const R* tp = tax + t;
+    V3<R> Fl = zero3<R>();                                             // force on the taxel, sensor-link frame
+    for (int j = 0; j < nsp; ++j) {
+      const R* Cc = sC + (kb + j) * 4;
+      const V3<R> dc = xa - ldv(Cc);
+      if (Cc[3] >= R(0) && dot3(dc, dc) > Cc[3]) continue;              // outside the primitive's bounding sphere (+ margin)
+      const int prim = sPrim[kb + j];
+      const R* shape = sShape + (kb + j) * 4;
+      const R* P = sP + (kb + j) * TP_R_SIZE;
+      const double* D = sD + (kb + j) * TP_D_SIZE;
+      const M3<R> RPA = ldm(P);
+      // fp32 kernels: the exact shape's distance from an fp32 position, before the double-precision one
+      if (sizeof(R) == 4 && !(prim_distance<R>(prim, shape, mulMv(RPA, xa) + ldv(P + 9)) < R(TS_FAR_MARGIN))) continue;
+      const V3<double> xPd = mulMv(ldm(D), cvt3<double>(xa)) + ldv(D + 9);
+      const V3<R> xP = cvt3<R>(xPd);
+      V3<R> Fc; M3<R> Jx, Jv;
+      if (contact_law<R, false>(prim, shape, sf, xP, ldv(P + 15) + cross3(ldv(P + 12), xP), Fc, Jx, Jv, xPd)) Fl = Fl + mulMtv(RPA, Fc);
+    }
     R o0 = R(0), o1 = R(0), o2 = R(0);
-    if (valid) {
-      int s = 0;                                                       // sensor of taxel t
-      while (s < nsensor - 1 && t >= sEnd[s]) ++s;
-      const int kb = sKb[s], nsp = sNsp[s];
-      const R* sf = sSf + s * TSIM_SF_SIZE;
-      const R* tp = tax + t;
-      const V3<R> xa = mk3<R>(tp[0], tp[ntax], tp[2 * ntax]);
-      V3<R> Fl = zero3<R>();                                           // force on the taxel, sensor-link frame
-      for (int j = 0; j < nsp; ++j) {
-        const int prim = sPrim[kb + j];
-        const R* shape = sShape + (kb + j) * 4;
-        const R* P = sP + (kb + j) * TP_R_SIZE;
-        const double* D = sD + (kb + j) * TP_D_SIZE;
-        const M3<R> RPA = ldm(P);
-        // fp32 kernels: most taxels of a large pad are nowhere near the primitive; decide that from an fp32 position
-        if (sizeof(R) == 4 && !(prim_distance<R>(prim, shape, mulMv(RPA, xa) + ldv(P + 9)) < R(TS_FAR_MARGIN))) continue;
-        const V3<double> xPd = mulMv(ldm(D), cvt3<double>(xa)) + ldv(D + 9);
-        const V3<R> xP = cvt3<R>(xPd);
-        V3<R> Fc; M3<R> Jx, Jv;
-        if (contact_law<R, false>(prim, shape, sf, xP, ldv(P + 15) + cross3(ldv(P + 12), xP), Fc, Jx, Jv, xPd)) Fl = Fl + mulMtv(RPA, Fc);
-      }
-      if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {              // the nine axis constants only for taxels that carry a force
-        o0 = Fl.x * tp[3 * ntax] + Fl.y * tp[4 * ntax] + Fl.z * tp[5 * ntax];
-        o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
-        o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
-      }
+    if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {                // the nine axis constants only for taxels that carry a force
+      o0 = Fl.x * tp[3 * ntax] + Fl.y * tp[4 * ntax] + Fl.z * tp[5 * ntax];
+      o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
+      o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
     }
-    if (base + TS_WAVE <= te) {                                        // a full tile (wave-uniform): transpose + vector stores
-      R* tile = sOut[wave];
-      tile[3 * wl] = o0; tile[3 * wl + 1] = o1; tile[3 * wl + 2] = o2;
-      TS_SYNC();                                                       // compiler fence only: same wavefront, DS order is issue order
-      R* dst = out + (size_t)3 * base;
-      // 16-byte vector stores where the destination allows it (3 ntax reals per environment: 16-byte aligned rows iff ntax is a
-      // multiple of 4 (fp32) / 2 (fp64)); otherwise dword-aligned rows take 8-byte (fp32: 2 reals) stores
-      if ((reinterpret_cast<size_t>(dst) & 15) == 0) {
-        for (int i = wl; i < 3 * TS_WAVE / VEC; i += TS_WAVE)
-          *reinterpret_cast<vecR*>(dst + i * VEC) = *reinterpret_cast<const vecR*>(tile + i * VEC);
-      } else {
-        for (int i = wl; i < 3 * TS_WAVE; i += TS_WAVE) dst[i] = tile[i];    // contiguous dwords across the lanes: still full lines
-      }
-      TS_SYNC();
-    } else if (valid) {
-      out[3 * t] = o0; out[3 * t + 1] = o1; out[3 * t + 2] = o2;
+#ifdef TS_TAX_ZEROS        // A/B only: the store pattern alone (no taxel arithmetic) — the ceiling of this write stream
+    o0 = o1 = o2 = R(0);
+#endif
+    out[3 * t] = o0; out[3 * t + 1] = o1; out[3 * t + 2] = o2;
+  };
+  for (int t = (int)blockIdx.y * a.slice + (int)threadIdx.x; t < te; t += 256 * TS_TAX_UNROLL) {
+    V3<R> xa[TS_TAX_UNROLL];
+#pragma unroll
+    for (int r = 0; r < TS_TAX_UNROLL; ++r) {                          // positions of all of this iteration's taxels first: loads in flight together
+      const int tr = min(t + 256 * r, te - 1);
+      xa[r] = mk3<R>(tax[tr], tax[tr + ntax], tax[tr + 2 * ntax]);
     }
+#pragma unroll
+    for (int r = 0; r < TS_TAX_UNROLL; ++r)
+      if (t + 256 * r < te) taxel(t + 256 * r, xa[r]);
   }
 }
 
@@ -607,10 +626,10 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
   for (int s = 0; s < c.nsensor; ++s) {
     const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
     const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
-    const int t0 = si[TSIM_SI_TAX0], nt = si[TSIM_SI_NTAX], sp0 = si[TSIM_SI_SPRIM0], nsp = si[TSIM_SI_NSPRIM];
+    const int t0 = ts_u(si[TSIM_SI_TAX0]), nt = ts_u(si[TSIM_SI_NTAX]), sp0 = ts_u(si[TSIM_SI_SPRIM0]), nsp = ts_u(si[TSIM_SI_NSPRIM]);
     for (int j = 0; j < nsp; ++j) {
-      const int pk = c.I[c.off_sprim + sp0 + j];
-      const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+      const int pk = ts_u(c.I[c.off_sprim + sp0 + j]);
+      const int prim = ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_PRIM]);
       const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
       TS_SYNC();
       pair_stage_value(c, pk, 0, lane == 0);
@@ -644,7 +663,7 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
         if (live) {
           const V3<double> xPd = mulMv(ldm(c.PPd), mk3<double>((double)x0, (double)x1, (double)x2)) + ldv(c.PPd + 9);
           xP = cvt3<R>(xPd);
-          live = contact_law<R, true>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
+          live = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
         }
         if (!__any(live)) continue;
         any_live = true;
@@ -688,7 +707,7 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
 }
 
 template <class R, int NRM, bool EXPJ, int LPE>
-__global__ void __launch_bounds__(TS_WAVE) k_backward(BwdArgs<R> a) {
+__global__ void TS_KLB k_backward(BwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   constexpr int NS = TS_WAVE / LPE;
@@ -817,6 +836,8 @@ struct tsim_batch {
   void* tape;                    // [(cap+1)][B][rec]
   void *lamq, *lamv;             // carried adjoint [B][nr]
   int* evals;                    // residual evaluations of the last forward launch, per env
+  float* gnorm = nullptr;        // largest ||g|| a sub-step of the last forward launch ended with, per env
+  int cross_kinks = 0, eval_budget = 0;     // tsim_set_solver_options
   int* order; int order_valid;   // block -> env map for the next forward launch (LPT scheduling)
   void* prev; int has_prev;      // BDF2: state before the previous sub-step [B][2 nr]
   void* poseR; double* poseD; int nspt;   // tsim_readout: pose records [B][nspt] of the (sensor, primitive) combinations (k_readout -> k_taxels)
@@ -826,6 +847,7 @@ struct tsim_batch {
   int nsched;                    // ints of the sweep schedule appended to dI
   int stage_cpt;                 // the contact-point arrays are staged in LDS with the shared tables
   int n_simd;                    // SIMDs of the device (CUs x 4)
+  int tax_slots = 0;             // blocks of k_taxels the device holds at once (occupancy x CUs), queried on first use
   size_t esz;
   std::vector<CacheEntry> cache;   // saved tapes, newest last
   std::vector<void*> pool;          // spare tape buffers
@@ -869,6 +891,24 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
     r[TS_LR_NDOF] = li[TSIM_LI_NDOF]; r[TS_LR_ANCMASK] = li[TSIM_LI_ANCMASK]; r[TS_LR_BRANCH] = branch[i];
   }
   for (int e = 0; e < npair * TSIM_PI_SIZE; ++e) S[rec0 + nl * TS_LR_SIZE + e] = I[op + e];      // pair int records
+  {                                                                                              // taxel staging table (k_taxels), offset in S[TS_SCHED_TAXTAB]
+    const int ns_ = I[TSIM_IH_NSENSOR], os = I[TSIM_IH_OFF_SENSOR], osp = I[TSIM_IH_OFF_SPRIM];
+    S[TS_SCHED_TAXTAB] = (int32_t)S.size();
+    int kb = 0;
+    for (int s = 0; s < ns_; ++s) {
+      const int32_t* si = &I[os + s * TSIM_SI_SIZE];
+      S.push_back(si[TSIM_SI_TAX0] + si[TSIM_SI_NTAX]); S.push_back(kb); S.push_back(si[TSIM_SI_NSPRIM]);
+      kb += si[TSIM_SI_NSPRIM];
+    }
+    for (int s = 0; s < ns_; ++s) {
+      const int32_t* si = &I[os + s * TSIM_SI_SIZE];
+      for (int j = 0; j < si[TSIM_SI_NSPRIM]; ++j) {
+        const int pk = I[osp + si[TSIM_SI_SPRIM0] + j];
+        S.push_back(I[op + pk * TSIM_PI_SIZE + TSIM_PI_PRIM]); S.push_back(pk);
+      }
+    }
+    S[0] = (int32_t)S.size();
+  }
   const int dm0 = rec0 + nl * TS_LR_SIZE + npair * TSIM_PI_SIZE;                                 // dof -> motor, motor int records
   for (int j = 0; j < 16; ++j) S[dm0 + j] = -1;
   for (int m = 0; m < nu; ++m) {
@@ -999,6 +1039,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
+  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm;
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
   if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
@@ -1056,6 +1097,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->lpe_forced = 0;
   b->nsched = (int)build_sched(b->I).size();
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
+  b->cross_kinks = dtype == TSIM_F32 ? 1 : 0;
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
@@ -1071,7 +1113,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
+      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->gnorm, (size_t)B * sizeof(float)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
       (b->nspt > 0 && (hipMalloc(&b->poseR, (size_t)B * b->nspt * TP_R_SIZE * b->esz) != hipSuccess || hipMalloc((void**)&b->poseD, (size_t)B * b->nspt * TP_D_SIZE * sizeof(double)) != hipSuccess))) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
@@ -1088,7 +1130,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   DeviceGuard guard_(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
   for (void* p : b->pool) (void)hipFree(p);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->order); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD);
   delete b;
 }
 
@@ -1118,6 +1160,17 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
     if (launch_shape(b).lpe != lpe0) b->stage_cpt = 0;
   }
   (void)old;      // the flag travels with every launch as a kernel argument: nothing on the device to update
+  return 0;
+}
+int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {
+  if (eval_budget < 0) return fail("set_solver_options: negative evaluation budget");
+  b->cross_kinks = cross_kinks != 0;
+  b->eval_budget = eval_budget;
+  return 0;
+}
+int tsim_last_gnorm(tsim_batch* b, float* host_out) {
+  TS_DEVICE(b);
+  if (hipMemcpy(host_out, b->gnorm, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_gnorm: copy failed");
   return 0;
 }
 int tsim_last_evals(tsim_batch* b, int32_t* host_out) {
@@ -1203,10 +1256,22 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   // taxels that are paired with no primitive (a sensor body without a general_primitive_contact) read zero, as in k_forward's read-out
   if (tac_out && b->ntax > 0 && b->nspt == 0 && zero_async(tac_out, (size_t)b->B * 3 * b->ntax * b->esz, st)) return 1;
   if (tac && (b->nspt > TX_MAXK || b->I[TSIM_IH_NSENSOR] > TX_MAXS)) return fail("readout: more than " + std::to_string((int)TX_MAXK) + " (sensor, primitive) combinations or " + std::to_string((int)TX_MAXS) + " sensors (k_taxels staging)");
-  // taxels per block of k_taxels: aim at ~8192 blocks in all (several per SIMD at any batch size): 256 for the single environment of
-  // test_sim_speed.py (157 blocks for its 40 000 taxels), 1 280 for B = 256
-  const long long want = ((long long)b->ntax * b->B + 8191) / 8192;
-  const int slice = (int)std::max<long long>(256, (want + 255) / 256 * 256);
+  // Taxels per block of k_taxels.  A block's prologue (staging the pose records and the model tables of its environment, two barriers)
+  // is a chain of dependent global loads, ~3 us whatever the slice; with many short blocks per SIMD slot the kernel WAS that prologue
+  // (8192 blocks of 5 taxels per thread: 4.6 rounds of ~7 us for 256 x 40 000 taxels).  So: ONE round — as many blocks as the device
+  // holds at once (occupancy x CUs), each with a slice long enough to cover the batch; never less than 256 taxels per block, so the
+  // single environment of test_sim_speed.py still spreads its 40 000 taxels over 157 blocks.
+  int slice;
+  {
+    if (b->tax_slots == 0) {
+      int per_cu = 0;
+      const hipError_t e_ = b->dtype == TSIM_F32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_taxels<float>, 256, 0)
+                                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_taxels<double>, 256, 0);
+      b->tax_slots = (e_ == hipSuccess && per_cu > 0 ? per_cu : 4) * (b->n_simd / 4);
+    }
+    const int per_env = std::max(1, std::min(b->tax_slots / b->B, (b->ntax + 255) / 256));
+    slice = ((b->ntax + per_env - 1) / per_env + 255) / 256 * 256;
+  }
   const dim3 tgrid(b->B, tac ? (b->ntax + slice - 1) / slice : 1);
   if (b->dtype == TSIM_F32) {
     ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, tac ? (float*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};

@@ -250,6 +250,19 @@ class BatchSim:
         capi.check(capi.lib().tsim_last_evals(self._h, out.ctypes.data_as(capi._ip)))
         return out
 
+    def last_gnorm(self):
+        """Largest ||g|| any sub-step of the most recent forward launch ended with, per environment (float32 [B])."""
+        out = np.zeros(self.B, dtype=np.float32)
+        capi.check(capi.lib().tsim_last_gnorm(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def set_solver_options(self, cross_kinks=None, eval_budget=0):
+        """include/tsim.h tsim_set_solver_options: the two options around the XML-stated Newton loop.  cross_kinks None = the library's
+        default (on for fp32 batches, off for fp64 ones, which then run the literal loop)."""
+        if cross_kinks is None:
+            cross_kinks = self.dtype == torch.float32
+        capi.check(capi.lib().tsim_set_solver_options(self._h, int(bool(cross_kinks)), int(eval_budget)))
+
     def set_lanes_per_env(self, lanes):
         """16 / 32 / 64 lanes per environment, 0 = automatic (include/tsim.h tsim_set_lanes_per_env)."""
         capi.check(capi.lib().tsim_set_lanes_per_env(self._h, int(lanes)))

@@ -37,6 +37,8 @@ _SIGS = {
     "tsim_launch_info": (C.c_int, [_vp, _ip]),
     "tsim_set_lanes_per_env": (C.c_int, [_vp, C.c_int]),
     "tsim_last_evals": (C.c_int, [_vp, _ip]),
+    "tsim_set_solver_options": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "tsim_last_gnorm": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "tsim_last_error": (C.c_char_p, []),
     # include/tsim_env.h — TactilePush per-step formulas
     "tsim_push_action": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

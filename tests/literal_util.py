@@ -1,10 +1,11 @@
 """Helpers of the literal-solver tests (test_oracle_literal.py on the CPU, test_gpu_literal.py on the GPU).
 
-The oracle has two Newton drivers (oracle/tsim_oracle.cpp): "kernel" — the globalisation the HIP kernels use (non-monotone steps across
-contact / friction kinks, restart, trust region: DESIGN.md §1) — and "literal" — Newton + monotone backtracking exactly as the model XML
-states it (envs/assets/pusher/pusher.xml:4: tol 1e-8, max_iter 100, max_ls 20), sharing none of the tuned constants.  These helpers
-run the literal solver TEACHER-FORCED: every sub-step starts from the state another solver (the kernel-mode oracle, or the HIP path)
-was in, so a difference in one sub-step is seen as such instead of compounding over the roll-out."""
+The oracle has two Newton drivers (oracle/tsim_oracle.cpp): "literal" (the default) — Newton + monotone backtracking exactly as the
+model XML states it (envs/assets/pusher/pusher.xml:4: tol 1e-8, max_iter 100, max_ls 20), which is also the loop the HIP kernels run
+since round 3 — and "r02", the globalisation kernels and oracle shared in rounds 1-2 (non-monotone steps across contact / friction
+kinks, restart, trust region), kept to document what it did.  These helpers run the literal solver TEACHER-FORCED: every sub-step
+starts from the state another solver (the r02 oracle, or the HIP path) was in, so a difference in one sub-step is seen as such
+instead of compounding over the roll-out."""
 import os
 import threading
 
@@ -48,9 +49,9 @@ def literal_substeps(model, q_before, qd_before, u_sub):
     return q1, qd1, ok, tot
 
 
-def kernel_mode_rollout(model, q0, u, S):
-    """Kernel-mode oracle roll-out that keeps every sub-step's state: q [B, T*S + 1, nr], qd likewise (index 0 = initial state),
-    converged [B, T*S], and per sub-step whether a globalisation device of the kernel-mode solver acted (kick / restart / trust region)."""
+def r02_rollout(model, q0, u, S):
+    """Roll-out by the oracle's legacy r02 solver that keeps every sub-step's state: q [B, T*S + 1, nr], qd likewise (index 0 = initial
+    state), converged [B, T*S], and per sub-step whether one of its globalisation devices acted (kick / restart / trust region)."""
     from oracle.oracle import OracleSim
     B, T = u.shape[0], u.shape[1]
     nr = q0.shape[1]
@@ -58,7 +59,7 @@ def kernel_mode_rollout(model, q0, u, S):
     ok, acted = np.zeros((B, T * S), dtype=bool), np.zeros((B, T * S), dtype=bool)
 
     def work(i, nthr):
-        o = OracleSim(model)
+        o = OracleSim(model, solver="r02")
         for e in range(i, B, nthr):
             o.reset(q0[e])
             q[e, 0], qd[e, 0] = o.state()

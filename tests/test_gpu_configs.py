@@ -30,9 +30,9 @@ def _weights():
     return rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0
 
 
-def _oracle_subset(model, q0, u, idx, weights=None, want_sig=False, solver="kernel"):
+def _oracle_subset(model, q0, u, idx, weights=None, want_sig=False, solver="literal"):
     """Oracle trajectories (and episode gradients / branch signatures) of the environments idx, on all host threads.
-    solver: the oracle's Newton driver ("kernel": the HIP kernels' globalisation; "literal": the XML's own, test_gpu_literal.py)."""
+    solver: the oracle's Newton driver ("literal": the XML's own loop, which the kernels run; "r02": the legacy globalisation)."""
     from oracle.oracle import OracleSim
     n = len(idx)
     out = {"q": np.zeros((T, n, 7)), "qd": np.zeros((T, n, 7)), "var": np.zeros((T, n, 6)), "tac": np.zeros((T, n, 390)),

@@ -1,0 +1,16 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+AB=$PWD/tactilesimulation_amd/csrc/ab
+for tag in base r02; do
+  if [ $tag = base ]; then unset TSIM_HIP_LIB; else export TSIM_HIP_LIB=$AB/libtsim_$tag.so; fi
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ro_$tag -o ro -- python tools/readout_ab.py > gpurun_out/ro_$tag.log 2>&1
+  echo "== readout $tag"; grep dtype gpurun_out/ro_$tag.log
+  f=$(find gpurun_out/ro_$tag -name "*kernel_stats.csv" | head -1); grep -E "k_taxels|k_readout" $f | cut -c1-120
+done
+echo "== k_forward builds"
+for tag in base libm r02 base; do
+  if [ $tag = base ]; then unset TSIM_HIP_LIB; else export TSIM_HIP_LIB=$AB/libtsim_$tag.so; fi
+  echo "-- $tag"; for i in 1 2; do timeout 200 python bench.py --steps 20 --warmup 5 --timed-only --no-pmc 2>/dev/null | tail -1; done
+done
+unset TSIM_HIP_LIB
+echo "== tests"
+timeout 900 python -m pytest tests -m gpu -q -x -s 2>&1 | grep -vE "^$|Warning|warn" | tail -30
