@@ -434,6 +434,48 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
 #endif
     out[3 * t] = o0; out[3 * t + 1] = o1; out[3 * t + 2] = o2;
   };
+  if (nsensor == 1 && a.nspt == 1 && sC[3] >= R(0)) {
+    // One sensor against one bounded primitive (RollingBall's pad and ball, TactilePush's pad and box), in two passes per 1024 taxels:
+    //   pass 1  lanes = taxels: 3 loads, the bounding-sphere test against centre / radius^2 held in registers (7 instructions), zeros
+    //           stored for the taxels outside; the few inside are appended to a list in LDS;
+    //   pass 2  lanes = LISTED taxels: the penalty law, with full wavefronts.
+    // Without the list a wavefront runs the ~1000-instruction law whenever ONE of its 64 taxels is near the primitive — 15 % of the
+    // wavefronts of the RollingBall pad for 5 % of its taxels, and that was the kernel's time (12.4 M vector instructions for
+    // 10.2 M taxels; profiles/r03_readout_ab.md).  A taxel's result does not depend on the lane that computes it: same bits as before.
+    enum { CH = 4 };
+    __shared__ int sList[256 * CH];
+    __shared__ int sCount;
+    const V3<R> cA = ldv(sC);
+    const R r2 = sC[3];
+    const R* px = tax; const R* py = tax + ntax; const R* pz = tax + 2 * ntax;
+    for (int base = (int)blockIdx.y * a.slice; base < te; base += 256 * CH) {
+      if (threadIdx.x == 0) sCount = 0;
+      __syncthreads();
+      V3<R> xa[CH];
+#pragma unroll
+      for (int r = 0; r < CH; ++r) {                                   // all loads of the chunk in flight together
+        const int tr = min(base + (int)threadIdx.x + 256 * r, te - 1);
+        xa[r] = mk3<R>(px[tr], py[tr], pz[tr]);
+      }
+#pragma unroll
+      for (int r = 0; r < CH; ++r) {
+        const int tr = base + (int)threadIdx.x + 256 * r;
+        if (tr < te) {
+          const V3<R> dc = xa[r] - cA;
+          if (dot3(dc, dc) > r2) { out[3 * tr] = R(0); out[3 * tr + 1] = R(0); out[3 * tr + 2] = R(0); }
+          else sList[atomicAdd(&sCount, 1)] = tr;
+        }
+      }
+      __syncthreads();
+      const int n = sCount;
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int tr = sList[i];
+        taxel(tr, mk3<R>(px[tr], py[tr], pz[tr]));
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int t = (int)blockIdx.y * a.slice + (int)threadIdx.x; t < te; t += 256 * TS_TAX_UNROLL) {
     V3<R> xa[TS_TAX_UNROLL];
 #pragma unroll
