@@ -123,9 +123,11 @@ def test_config3_push_b4096_fwd_adjoint_fp32(pusher_model):
     assert np.abs(g["var"] - o["var"]).max() < 5e-6
     assert np.abs(g["tactile"] - o["tac"]).max() < 2e-4 * np.abs(o["tac"]).max()
     same = (sig[:, idx] == o["sig"]).all(axis=(0, 2))            # same contact / friction branches in all 500 sub-steps
-    assert same.sum() >= 60, "more than 4 of 64 environments crossed a kink: %d" % (64 - same.sum())
     dg = du[:, idx].double().cpu().numpy()
     eg = np.abs(dg - o["du"]).max(axis=(0, 2)) / np.abs(o["du"]).max(axis=(0, 2))
+    print("config 3, 64 environments of the 4096 batch vs the oracle: %d on the same branches throughout; gradient error median %.2e, max %.2e (on those: %.2e)"
+          % (same.sum(), np.median(eg), eg.max(), eg[same].max()))
+    assert same.sum() >= 63, "more than 1 of 64 environments crossed a kink: %d" % (64 - same.sum())     # measured: 64 of 64, max error 1.1e-5
     assert eg[same].max() < 1e-4, eg[same].max()                 # BASELINE.json: gradients within 1e-4 rel of the CPU path
 
 
@@ -207,7 +209,12 @@ def test_fp32_gradients_within_1e4_where_branches_agree_b1024(pusher_model):
           "max %.2e | fp64 tol 1e-8 vs 1e-12: flipped %.3f, median %.2e"
           % (flipped, np.median(eg[same]), np.percentile(eg[same], 99), eg[same].max(), eg[~same].max() if (~same).any() else 0.0,
              float((~same_t).mean()), np.median(eg_t[same_t])))
-    assert flipped <= 0.005, flipped
+    # what the optimiser sees: the gradient summed over the batch (the GD loop's all-reduced policy gradient is a linear map of it)
+    gsum64, gsum32 = g64.sum(axis=1), g32.sum(axis=1)
+    batch_err = float(np.abs(gsum32 - gsum64).max() / np.abs(gsum64).max())
+    print("batch-summed gradient, fp32 vs fp64 kernels, %d environments: %.2e" % (B, batch_err))
+    assert batch_err <= 2e-5, batch_err                           # measured 1.9e-6 (round 2, with its own globalisation: 1.1e-4)
+    assert flipped <= 0.002, flipped                              # measured 0 of 1024 (round 2: 0.07 %)
     assert np.percentile(eg[same], 99.5) < 1e-4, np.percentile(eg[same], 99.5)
     assert eg[same].max() < 1e-3, eg[same].max()
     assert np.abs(q64 - q32)[:, same].max() < 2e-5
@@ -333,5 +340,7 @@ def test_config3_reward_loss_gradient_as_survey_words_it(pusher_model):
     rel = np.linalg.norm((g - G).reshape(T, len(idx), -1).transpose(1, 0, 2).reshape(len(idx), -1), axis=1) / np.linalg.norm(G.transpose(1, 0, 2).reshape(len(idx), -1), axis=1)
     cos = np.array([float(g[:, j].reshape(-1) @ G[:, j].reshape(-1) / (np.linalg.norm(g[:, j]) * np.linalg.norm(G[:, j]))) for j in range(len(idx))])
     ok = survey < 1e-4
-    assert ok.sum() >= len(idx) - 4, (np.sort(survey)[-6:], "environments off: %d" % (~ok).sum())     # the few that crossed a kink (§5)
+    print("config 3 reward loss: %d of %d environments within 1e-4 by the survey's metric; median %.2e, max %.2e; gd.py relative error median %.2e"
+          % (ok.sum(), len(idx), np.median(survey), survey.max(), np.median(rel)))
+    assert ok.sum() >= len(idx) - 1, (np.sort(survey)[-6:], "environments off: %d" % (~ok).sum())     # the few that crossed a kink (§5)
     assert np.median(survey) < 2e-5 and np.median(rel) < 2e-5 and cos[ok].min() > 1.0 - 1e-8, (np.median(survey), np.median(rel), cos[ok].min())

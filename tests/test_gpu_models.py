@@ -88,8 +88,11 @@ def _oracle_case(name, m, q0, u, wq, wv, wt, T, S):
 
 @pytest.mark.parametrize("lanes", [64, 32, 16])
 @pytest.mark.parametrize("name", list(CASES))
-@pytest.mark.parametrize("dtype,tq,tg", [(torch.float64, 1e-9, 1e-6), (torch.float32, 5e-4, 2e-2)])
-def test_model_forward_and_adjoint(name, dtype, tq, tg, lanes):
+@pytest.mark.parametrize("dtype,tq,tt,tg", [(torch.float64, 1e-12, 1e-9, 1e-10), (torch.float32, 2e-6, 2e-3, 1e-4)])
+def test_model_forward_and_adjoint(name, dtype, tq, tt, tg, lanes):
+    """All seven models, every launch shape, against the oracle.  The kernels run the oracle's Newton loop (round 3), so the bounds are
+    those of the arithmetic: fp64 round-off (measured: q <= 7e-15, gradients <= 1e-12), fp32 q <= 9e-8 and gradients <= 5.4e-5 — the
+    gradient bound asserted for fp32 is BASELINE.json's 1e-4 on EVERY model (round 2 needed 2e-2 on the stiff ones)."""
     from tactilesimulation_amd.host.batch import BatchSim
     m = _load(name, 1e-13 if dtype == torch.float64 else 1e-8)
     _, _, T, S = CASES[name]
@@ -117,6 +120,10 @@ def test_model_forward_and_adjoint(name, dtype, tq, tg, lanes):
             G[:, t] = du.double().cpu().numpy().sum(1)
     lq, lv = (x.double().cpu().numpy() for x in sim.get_adjoint())
     ref = _oracle_case(name, m, q0, u, wq, wv, wt, T, S)
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-9))
+    print("MEASURED %s %s lanes %d: q %.1e | dL/du %.1e | lam_q %.1e | lam_v %.1e" % (
+        name, str(dtype)[6:], lanes, max(np.abs(outs[t]["q"][e] - ref[e][0][t][0]).max() for e in range(B_) for t in range(T)),
+        max(rel(G[e], ref[e][1]) for e in range(B_)) if nu else 0.0, max(rel(lq[e], ref[e][2]) for e in range(B_)), max(rel(lv[e], ref[e][3]) for e in range(B_))))
     for e in range(B_):
         tr, Go, alq, alv = ref[e]
         for t in range(T):
@@ -127,7 +134,7 @@ def test_model_forward_and_adjoint(name, dtype, tq, tg, lanes):
             if nv:
                 assert np.abs(outs[t]["var"][e] - v).max() <= tq * 10
             if nt:
-                assert np.abs(outs[t]["tactile"][e] - tc).max() <= max(tq * 1e3, 1e-12) * max(np.abs(tc).max(), 1e-3), (name, e, t)
+                assert np.abs(outs[t]["tactile"][e] - tc).max() <= tt * max(np.abs(tc).max(), 1e-3), (name, e, t)
         if nu:
             assert np.abs(G[e] - Go).max() <= tg * max(np.abs(Go).max(), 1e-9), (name, e, np.abs(G[e] - Go).max() / np.abs(Go).max())
         assert np.abs(lq[e] - alq).max() <= tg * max(np.abs(alq).max(), 1e-9), (name, "lam_q")
