@@ -41,6 +41,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+F64_EVAL_BUDGET = 256           # evaluations per sub-step in the f64 legs
+INSERTION_EVAL_BUDGET = 128     # evaluations per sub-step in the TactileInsertion leg (tsim_set_solver_options)
 POLICY_GRAD_FLOATS = 29574      # DiagGaussianActor(393 -> 64 -> 64 -> 3), SURVEY.md §2.2
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 64 lanes x 2 flop per 2 cycles at 2.4 GHz (packed / two wavefronts per SIMD)
@@ -93,6 +95,14 @@ WORKLOADS = {
 }
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """leg timings on stderr (the JSON line on stdout stays alone)"""
+    print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def fatal(msg, rc=2):
     print("bench.py: " + msg, file=sys.stderr, flush=True)
     sys.exit(rc)
@@ -137,6 +147,17 @@ class Leg:
         self.wl, self.dev, self.tdt, self.forward_only, self.world, self.backend = wl, dev, tdt, forward_only, world, backend
         B, T, S = wl["B"], wl["T"], wl["S"]
         self.sim = sim = BatchSim(wl["model"], B, device=str(dev), dtype=tdt, tape_capacity=0 if forward_only else T * S)
+        # Solver options (include/tsim.h tsim_set_solver_options).  Every leg of this bench runs the XML's Newton loop with kink
+        # crossing near convergence — the library's default for fp32 batches; f64 legs are given the same option so that they differ
+        # from the headline in arithmetic only (the library's fp64 default is the bare loop: what the parity tests pin).
+        # TactileInsertion closes a stiff grasp on which plain backtracking creeps for ~2000 evaluations in ~0.5 % of the environments
+        # while the other 4095 wait: roll-out collection bounds a sub-step's evaluations (flagged in status, counted in the record).
+        # f64 legs: 2 of the 4096 TactilePush environments cycle between the two sides of a kink (the loop then runs ~1000 evaluations to
+        # max_iter, non-converged either way): bounded as well.  The fp32 headline has no budget (its largest sub-step: 43 evaluations).
+        self.eval_budget = INSERTION_EVAL_BUDGET if wl["name"] == "insertion" else (F64_EVAL_BUDGET if tdt == torch.float64 else 0)
+        sim.set_solver_options(cross_kinks=True, eval_budget=self.eval_budget)
+        self.solver = "XML Newton loop (tol / max_iter / max_ls of the model) + kink crossing near convergence" + (
+            "" if not self.eval_budget else ", at most %d evaluations per sub-step (flagged in status beyond)" % self.eval_budget)
         self.nr, self.nu, self.nvar, self.ntac = sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile
         one = lambda d, s=1.0: torch.ones(B, d, device=dev, dtype=tdt) * s
         self.wq, self.wv, self.wt = one(self.nr), (one(self.nvar) if self.nvar else None), one(self.ntac, 100.0)
@@ -243,9 +264,11 @@ def sub_record(name, dtype, dev, steps=None, warm=None):
     bad = leg.run(T, False, "episode")
     rl, _ = leg.roofline(esz)
     info = leg.sim.launch_info()
+    leg_solver = leg.solver
     del leg
     torch.cuda.empty_cache()
     return {"workload": cfg, "model": asset_, "batch": B, "dtype": dtype, "value": B * steps / dt, "unit": "env-steps/s",
+            "solver": leg_solver,
             "what": ("forward only" if fwd_only else "forward + adjoint") + ", 5 sub-steps per env-step, episodes of %d env-steps, one launch per episode each way" % T,
             "steps": steps, "ms_per_step": dt / steps * 1e3, "nonconverged_envs": bad, "launch_shape": info, "roofline": rl}
 
@@ -428,6 +451,7 @@ def main():
                                     % ("fwd+adjoint" if not forward_only else "forward only", S, B, T)) if args.workload == "push" else
                                    "%s; %s.xml, ndof_r %d, %d tactile values, frame_skip %d, batch %d envs/GPU, episodes of %d env-steps" % (cfg_text, asset_, nr, ntac, S, B, T),
                        "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
+            "solver": leg.solver,
             "ranks": {"world_size": world, "ranks_in_first_allreduce": ranks_seen, "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
                       "shared_gpu": share},
             "roofline": rl,
@@ -443,10 +467,12 @@ def main():
         # free the batch before the other legs (tape: 0.6 GB) — and so that the profiled child runs see an idle GPU
         del sim, leg
         torch.cuda.empty_cache()
+        progress("timed region + launch-mode leg + evaluation statistics done")
         if world == 1:
             pmc = None
             if not args.no_pmc:
                 pmc = pmc_passes(args, B, T)
+                progress("rocprofv3 --pmc passes done")
             src = "measured in this run: rocprofv3 --pmc passes of `bench.py --timed-only` with this run's --steps / --batch / --dtype / --workload"
             if pmc is None or dom not in pmc:
                 pmc, src = pmc_from_profile(args, B), "profiles/r02_pmc_%s.json (committed rocprofv3 --pmc run of this command; the in-run passes were skipped or failed)" % args.dtype
@@ -468,6 +494,7 @@ def main():
                         res[key] = sub_record(nm, dty, dev)
                     except Exception as e:      # the headline must not die with an optional leg
                         res[key] = {"error": repr(e)}
+                    progress("sub-record %s done" % key)
                 if "f64" in res and "value" in res["f64"]:
                     res["f64_value"] = res["f64"]["value"]
             if args.workload == "push" and not args.no_closed_loop and not forward_only:
@@ -475,12 +502,15 @@ def main():
                     res["closed_loop"] = closed_loop_leg(model, B, T, tdt, dev)
                 except Exception as e:      # the headline must not die with an optional leg
                     res["closed_loop"] = {"error": repr(e)}
+                progress("closed loop done")
             try:
                 res["readout_hbm"] = readout_leg(tdt, dev)
             except Exception as e:
                 res["readout_hbm"] = {"error": repr(e)}
+            progress("read-out leg done")
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.workload, model, S, not forward_only)
+                progress("cpu baseline done")
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -543,7 +543,12 @@ static int substep_literal(Sim& S, const double* u, const StepCoef& c, double* q
       for (int k = 0; k < nr; ++k) qn[k] = q1[k] + alpha * dq[k];
       eval_g_c(m, qn, c, u, gn); ++S.evals;
       if (norm2(nr, gn) < gnorm) break;
-      if (ls >= m.max_ls) { ++S.ls_exhausted; break; }
+      if (ls >= m.max_ls) {
+        ++S.ls_exhausted;
+        static const bool trace_l = getenv("TSIM_ORACLE_TRACE") != nullptr;
+        if (trace_l) { double mx = 0; for (int k = 0; k < nr; ++k) mx = std::max(mx, std::fabs(dq[k])); fprintf(stderr, "LSX it %d gn %.3e step_inf %.3e\n", it, gnorm, mx); }
+        break;
+      }
       alpha *= 0.5;
     }
     for (int k = 0; k < nr; ++k) q1[k] = qn[k];
