@@ -475,7 +475,7 @@ def main():
                 progress("rocprofv3 --pmc passes done")
             src = "measured in this run: rocprofv3 --pmc passes of `bench.py --timed-only` with this run's --steps / --batch / --dtype / --workload"
             if pmc is None or dom not in pmc:
-                pmc, src = pmc_from_profile(args, B), "profiles/r02_pmc_%s.json (committed rocprofv3 --pmc run of this command; the in-run passes were skipped or failed)" % args.dtype
+                pmc, src = pmc_from_profile(args, B), "profiles/r03_pmc_%s.json (committed rocprofv3 --pmc run of this command; the in-run passes were skipped or failed)" % args.dtype
             if pmc is not None and dom in pmc:
                 fill_roofline_counters(res["roofline"], pmc[dom], src, B, dom_frames, dom_ms)
                 res["roofline"]["counters_per_launch"] = pmc
@@ -557,7 +557,7 @@ def pmc_passes(args, B, T, kernels=("k_forward", "k_backward")):
 
 
 def pmc_from_profile(args, B):
-    f = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.dtype)
+    f = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % args.dtype)
     if not (os.path.exists(f) and B == 4096 and args.workload == "push"):
         return None
     try:

@@ -26,11 +26,14 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per collection step")
+    ap.add_argument("--eval-budget", type=int, default=128, help="residual evaluations one sub-step may take before it is flagged and left "
+                    "(include/tsim.h tsim_set_solver_options; 0 = none: with randomised variants a creeping sub-step then stalls the batch)")
     a = ap.parse_args()
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dt = torch.float32 if a.dtype == "f32" else torch.float64
     env = BatchedDClawRotateEnv(a.batch, device="cuda:%d" % local, dtype=dt, seed=a.seed + rank, variants=a.variants)
+    env.sim.set_solver_options(cross_kinks=True, eval_budget=a.eval_budget)
     torch.manual_seed(a.seed)
     W = torch.randn(env.obs_dim, env.act_dim, device=env.device, dtype=dt) * 0.02
     policy = lambda obs: torch.tanh(obs @ W) + 0.3 * torch.randn(a.batch, env.act_dim, device=env.device, dtype=dt)
