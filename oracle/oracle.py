@@ -55,6 +55,7 @@ def lib(native=False):
         L.orc_create.argtypes = [C.POINTER(C.c_int), _dp]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_reset.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.orc_set_prev.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_forward.argtypes = [C.c_void_p, _dp, C.c_int]
         L.orc_forward.restype = C.c_int
         L.orc_forward_sig.argtypes = [C.c_void_p, _dp, C.c_int, C.POINTER(C.c_uint32)]
@@ -123,6 +124,10 @@ class OracleSim:
         q = _f(q, self.nr)
         qd = np.zeros(self.nr) if qd is None else _f(qd, self.nr)
         self._L.orc_reset(self._h, _p(q), _p(qd), int(record))
+
+    def set_prev(self, q_prev, qd_prev):
+        """BDF2 models: the state before the previous sub-step (after reset(); without it the next sub-step is a BDF1 start-up step)."""
+        self._L.orc_set_prev(self._h, _p(_f(q_prev, self.nr)), _p(_f(qd_prev, self.nr)))
 
     def forward(self, u, nsub=1):
         u = _f(u, self.nu)

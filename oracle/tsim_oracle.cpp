@@ -668,6 +668,11 @@ void orc_reset(void* h, const double* q, const double* qd, int record) {
   S.tape.clear(); S.record = record != 0; S.has_prev = false;
   std::fill(S.lam_q.begin(), S.lam_q.end(), 0.0); std::fill(S.lam_v.begin(), S.lam_v.end(), 0.0);
 }
+// BDF2 models: the state before the previous sub-step (teacher-forced replays start in the middle of a roll-out); call after orc_reset
+void orc_set_prev(void* h, const double* qm1, const double* qdm1) {
+  Sim& S = *(Sim*)h;
+  S.qm1.assign(qm1, qm1 + S.m.nr); S.qdm1.assign(qdm1, qdm1 + S.m.nr); S.has_prev = true;
+}
 // nsub implicit sub-steps with u held; returns number of non-converged sub-steps
 int orc_forward(void* h, const double* u, int nsub) {
   Sim& S = *(Sim*)h; int bad = 0;

@@ -346,12 +346,18 @@ template <class R> struct Ctx {
   long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
   mutable int nstamp;
 };
+#ifdef TS_ISA_MARKS        // static analysis only (tools/isa_phases.py): every stamp site becomes a unique s_sleep marker in the ISA
+#define TS_MARK_(n) asm volatile("s_sleep %0" ::"n"(n) : "memory")
+#define TS_STAMP(c) TS_MARK_(__COUNTER__ + 20)
+#define TS_STAMP2(c) TS_MARK_(__COUNTER__ + 20)
+#else
 #ifdef TS_FINE_STAMPS      // A/B builds only (tools/fine_stamps.py): extra stamps inside the phases
 #define TS_STAMP2(c) TS_STAMP(c)
 #else
 #define TS_STAMP2(c) do { } while (0)
 #endif
 #define TS_STAMP(c) do { if ((c).stamps) { if (threadIdx.x == 0 && (c).nstamp < 32) (c).stamps[(c).nstamp] = clock64(); (c).nstamp++; } } while (0)
+#endif
 
 // LDS reals of one environment's state (host and device must agree)
 __host__ __device__ inline int ts_lds_env_doubles(int nl, int nr) { return 4 * nr + (nl + 1) * 12 + TS_PAIR_GROUP * 12; }

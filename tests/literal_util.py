@@ -29,8 +29,9 @@ def run_threads(n_items, work):
         raise err[0]
 
 
-def literal_substeps(model, q_before, qd_before, u_sub):
-    """One literal sub-step from every given state.  q_before, qd_before [N, nr] (state BEFORE the sub-step), u_sub [N, nu].
+def literal_substeps(model, q_before, qd_before, u_sub, q_prev=None, qd_prev=None, has_prev=None):
+    """One literal sub-step from every given state.  q_before, qd_before [N, nr] (state BEFORE the sub-step), u_sub [N, nu]; BDF2 models:
+    q_prev, qd_prev [N, nr] = the state one sub-step earlier, used where has_prev [N] holds (elsewhere the sub-step is the BDF1 start-up).
     Returns q1 [N, nr], qd1 [N, nr], converged [N] bool, and the summed solver statistics."""
     from oracle.oracle import OracleSim
     N = q_before.shape[0]
@@ -41,6 +42,8 @@ def literal_substeps(model, q_before, qd_before, u_sub):
         o = OracleSim(model, solver="literal")
         for j in range(i, N, nthr):
             o.reset(q_before[j], qd_before[j])
+            if has_prev is not None and has_prev[j]:
+                o.set_prev(q_prev[j], qd_prev[j])
             ok[j] = o.forward(u_sub[j], 1) == 0
             q1[j], qd1[j] = o.state()
         stats.append(o.stats())
@@ -74,13 +77,18 @@ def r02_rollout(model, q0, u, S):
     return q, qd, ok, acted
 
 
-def compare_with_literal(model, q_traj, qd_traj, u, S):
+def compare_with_literal(model, q_traj, qd_traj, u, S, bdf2=False):
     """Teacher-forced comparison of a recorded trajectory (q_traj, qd_traj [B, T*S + 1, nr]; any solver) with the literal solver.
     Returns dq [B, T*S] = max_k |q1_recorded - q1_literal|, literal-converged [B, T*S], literal statistics."""
     B, n1, nr = q_traj.shape
     n = n1 - 1
     qb, qdb = q_traj[:, :-1].reshape(B * n, nr), qd_traj[:, :-1].reshape(B * n, nr)
     us = np.repeat(u, S, axis=1).reshape(B * n, -1)
-    q1, _, ok, stats = literal_substeps(model, qb, qdb, us)
+    prev = {}
+    if bdf2:                                    # the state one sub-step earlier (none before the first sub-step: BDF1 start-up)
+        qp, qdp = np.concatenate([q_traj[:, :1], q_traj[:, :-2]], axis=1), np.concatenate([qd_traj[:, :1], qd_traj[:, :-2]], axis=1)
+        hp = np.ones((B, n), dtype=bool); hp[:, 0] = False
+        prev = dict(q_prev=qp.reshape(B * n, nr), qd_prev=qdp.reshape(B * n, nr), has_prev=hp.reshape(B * n))
+    q1, _, ok, stats = literal_substeps(model, qb, qdb, us, **prev)
     dq = np.abs(q1.reshape(B, n, nr) - q_traj[:, 1:]).max(axis=2)
     return dq, ok.reshape(B, n), stats

@@ -29,7 +29,7 @@ DEV = "cuda:0"
 S = 5
 
 
-def _hip_substep_states(model, q0, u, dt, lanes=0):
+def _hip_substep_states(model, q0, u, dt, lanes=0, S=5):
     """Roll the batch out one sub-step per launch and keep every state: q, qd [B, T*S + 1, nr] (float64 copies) and, per sub-step,
     whether the kernel flagged it as not converged: bad [B, T*S]."""
     from tactilesimulation_amd.host.batch import BatchSim
@@ -57,20 +57,35 @@ CASES = [
     ("pusher", 4096, 100, 64, 1e-9, 4e-6),                  # configs[2]: gd_tactile fwd + adjoint, B = 4096
     ("dclaw_position_control", 2048, 12, 16, 1e-9, 4e-6),   # configs[3]: 16 384 over 8 GPUs
     ("tactile_insertion", 4096, 14, 32, 1e-8, 4e-6),        # configs[4]: 32 768 over 8 GPUs
+    ("stable_grasp", 3, 41, 3, 1e-8, 1e-5),                 # the env's five-stage grasp episode (envs/stable_grasp_env.py:197-246), one sub-step per frame
+    ("tactile_pad", 1, 350, 1, 1e-8, 2e-5),                 # configs[0]: the RollingBall test_sim_speed.py sequence — BDF2, rotation-vector joint
 ]
+SUBSTEPS = {"stable_grasp": 1, "tactile_pad": 1}
+
+
+def _case_inputs(name, m, B, T):
+    if name == "pusher":
+        return push_workload(B, T, seed=0)[:2]                 # exactly what bench.py feeds rank 0
+    if name == "stable_grasp":
+        from test_gpu_rollout import _grasp_actions
+        q0 = np.zeros((B, 12)); q0[:, 2] = 0.2; q0[:, 4] = q0[:, 5] = -0.03
+        return q0, np.stack([_grasp_actions(g, q0[e]) for e, g in enumerate([0.0, 0.02, -0.035][:B])], axis=0)
+    if name == "tactile_pad":
+        from test_gpu_rollingball import _actions
+        return np.zeros((B, 9)), np.tile(_actions()[None], (B, 1, 1))
+    from test_gpu_models import _inputs
+    return _inputs(name, m, B, T)                              # the inputs of test_gpu_configs.py's config-4 / config-5 tests
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("name,B,T,n_sub,tol64,tol32", CASES)
 def test_every_substep_lands_on_the_literal_solvers_root(name, B, T, n_sub, tol64, tol32, dtype):
-    from test_gpu_models import _inputs
     m = load_model(asset(name))
-    if name == "pusher":
-        q0, u, _ = push_workload(B, T, seed=0)                 # exactly what bench.py feeds rank 0
-    else:
-        q0, u = _inputs(name, m, B, T)                         # the inputs of test_gpu_configs.py's config-4 / config-5 tests
+    S = SUBSTEPS.get(name, 5)
+    q0, u = _case_inputs(name, m, B, T)
+    assert u.shape[:2] == (B, T)
     dt = torch.float64 if dtype == "f64" else torch.float32
-    q, qd, bad, info = _hip_substep_states(m, q0, u, dt)
+    q, qd, bad, info = _hip_substep_states(m, q0, u, dt, S=S)
     if name == "pusher" and dtype == "f32":
         assert info["lanes_per_env"] == 16 and info["blocks"] == 1024, info          # the instantiation bench.py times
     flagged = np.nonzero(bad.any(axis=1))[0]
@@ -78,8 +93,9 @@ def test_every_substep_lands_on_the_literal_solvers_root(name, B, T, n_sub, tol6
     # a few environments of the 4096 flag a sub-step of the closing phase (status; test_gpu_configs.py bounds their number) — those
     # environments are IN the subset below, so what the literal solver makes of the very sub-steps the kernels give up on is on record.
     assert len(flagged) <= (0 if name != "tactile_insertion" else B // 100), "%d environments flagged a sub-step" % len(flagged)
-    idx = np.unique(np.concatenate([np.linspace(0, B - 1, n_sub).astype(int), flagged[:16]]))
-    dq, ok_l, st = compare_with_literal(m, q[idx], qd[idx], u[idx], S)
+    idx = np.unique(np.concatenate([np.linspace(0, B - 1, n_sub).astype(int), flagged[:16]])).astype(int)
+    import tactilesimulation_amd.model.blob as Bl
+    dq, ok_l, st = compare_with_literal(m, q[idx], qd[idx], u[idx], S, bdf2=int(m.I[Bl.TSIM_IH_INTEGRATOR]) == 2)
     ok_k = ~bad[idx]
     tol = tol64 if dtype == "f64" else tol32
     both = ok_l & ok_k
