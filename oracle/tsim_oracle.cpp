@@ -437,10 +437,11 @@ static bool solve_dense(int n, const double* A, const double* b, double* x, bool
 }
 
 // ------------------------------------------------------------------------------------------ simulation object
-struct Rec { std::vector<double> q0, qd0, q1, qd1, u; bool bdf2 = false; };
+struct Rec { std::vector<double> q0, qd0, q1, qd1, u, qm1, qdm1; bool bdf2 = false; };
 struct Sim {
   Model m;
   std::vector<double> q, qd, u, lam_q, lam_v, qm1, qdm1;   // qm1 / qdm1: state before the last sub-step (BDF2)
+  std::vector<double> lam_q1, lam_v1;                       // BDF2 adjoint: what later sub-steps already contributed to the state one step further back
   bool has_prev = false;
   std::vector<Rec> tape;
   std::vector<std::vector<Rec>> cache;
@@ -455,17 +456,25 @@ struct Sim {
 //   BDF1: qpred = q0 + h qd0, qdpred = qd0, cv = 1/h, ca = 1/h^2            (g = h^2 r, RedMax BDF1)
 //   BDF2: qpred = 4/3 q0 - 1/3 q_1 + 8/9 h qd0 - 2/9 h qd_1, qdpred = (3 qpred - 4 q0 + q_1)/(2h),
 //         cv = 3/(2h), ca = 9/(4h^2)                                        (RedMax BDF2; first step after reset: BDF1)
-struct StepCoef { double qpred[MAXR], qdpred[MAXR], cv, ca; };
+struct StepCoef {
+  double qpred[MAXR], qdpred[MAXR], cv, ca;
+  // d qpred / d (q0, qd0, q_1, qd_1) and d qdpred / d (the same): multiples of the identity (adjoint: eval_g_jac_c which = 1, 2, 4, 5)
+  double dqp[4], dqdp[4];
+};
 static void make_coef(const Model& m, const double* q0, const double* qd0, const double* qm1, const double* qdm1, StepCoef& c) {
   double h = m.h;
   if (qm1) {
     c.cv = 1.5 / h; c.ca = 2.25 / (h * h);
+    c.dqp[0] = 4.0 / 3; c.dqp[1] = 8.0 / 9 * h; c.dqp[2] = -1.0 / 3; c.dqp[3] = -2.0 / 9 * h;
+    c.dqdp[0] = (3 * c.dqp[0] - 4) / (2 * h); c.dqdp[1] = 3 * c.dqp[1] / (2 * h); c.dqdp[2] = (3 * c.dqp[2] + 1) / (2 * h); c.dqdp[3] = 3 * c.dqp[3] / (2 * h);
     for (int k = 0; k < m.nr; ++k) {
       c.qpred[k] = 4.0 / 3 * q0[k] - 1.0 / 3 * qm1[k] + 8.0 / 9 * h * qd0[k] - 2.0 / 9 * h * qdm1[k];
       c.qdpred[k] = (3 * c.qpred[k] - 4 * q0[k] + qm1[k]) / (2 * h);
     }
   } else {
     c.cv = 1.0 / h; c.ca = 1.0 / (h * h);
+    c.dqp[0] = 1.0; c.dqp[1] = h; c.dqp[2] = c.dqp[3] = 0.0;
+    c.dqdp[0] = 0.0; c.dqdp[1] = 1.0; c.dqdp[2] = c.dqdp[3] = 0.0;
     for (int k = 0; k < m.nr; ++k) { c.qpred[k] = q0[k] + h * qd0[k]; c.qdpred[k] = qd0[k]; }
   }
 }
@@ -475,7 +484,7 @@ static void eval_g_c(const Model& m, const double* q1, const StepCoef& c, const 
   residual<double>(m, q1, qd, qa, u, g, L);
   for (int k = 0; k < m.nr; ++k) g[k] /= c.ca;
 }
-// which: 0 = d/dq1 (total), 1 = d/dq0 (total, BDF1 only), 2 = d/dqd0 (BDF1 only), 3 = d/du ;  J[row*ncol+col]
+// which: 0 = d/dq1, 1 = d/dq0, 2 = d/dqd0, 3 = d/du, 4 = d/dq_1, 5 = d/dqd_1 (BDF2 history) — q1 held fixed for 1, 2, 4, 5 ;  J[row*ncol+col]
 static void eval_g_jac_c(const Model& m, const double* q1, const StepCoef& c, const double* u, int which, double* g, double* J) {
   int nr = m.nr, ncol = which == 3 ? m.nu : nr;
   double h = m.h;
@@ -488,9 +497,11 @@ static void eval_g_jac_c(const Model& m, const double* q1, const StepCoef& c, co
     for (int d = 0; d < nd; ++d) {
       int k = c0 + d;
       if (which == 0) { q[k].d[d] = 1.0; qd[k].d[d] = c.cv; qa[k].d[d] = c.ca; }
-      else if (which == 1) { qd[k].d[d] = -c.cv; qa[k].d[d] = -c.ca; }                  // qpred = q0 + h qd0, qdpred = qd0
-      else if (which == 2) { qd[k].d[d] = 1.0 - c.cv * h; qa[k].d[d] = -c.ca * h; }
-      else uu[k].d[d] = 1.0;
+      else if (which == 3) uu[k].d[d] = 1.0;
+      else {                                                  // through the predictor: qd = qdpred + cv (q1 - qpred), qdd = ca (q1 - qpred)
+        const int w = which == 1 ? 0 : which == 2 ? 1 : which == 4 ? 2 : 3;
+        qd[k].d[d] = c.dqdp[w] - c.cv * c.dqp[w]; qa[k].d[d] = -c.ca * c.dqp[w];
+      }
     }
     residual<Dual>(m, q, qd, qa, uu, r, L);
     for (int i = 0; i < nr; ++i) { g[i] = r[i].v / c.ca; for (int d = 0; d < nd; ++d) J[i * ncol + c0 + d] = r[i].d[d] / c.ca; }
@@ -610,6 +621,7 @@ static int substep(Sim& S, const double* u) {
   if (S.record) {
     Rec r; r.q0.assign(q0, q0 + nr); r.qd0.assign(qd0, qd0 + nr); r.q1.assign(q1, q1 + nr); r.u.assign(u, u + m.nu);
     r.qd1.assign(qd1, qd1 + nr); r.bdf2 = bdf2;
+    if (bdf2) { r.qm1 = S.qm1; r.qdm1 = S.qdm1; }
     S.tape.push_back(r);
   }
   S.qm1.assign(q0, q0 + nr); S.qdm1.assign(qd0, qd0 + nr); S.has_prev = true;
@@ -667,6 +679,7 @@ void orc_reset(void* h, const double* q, const double* qd, int record) {
   for (int k = 0; k < S.m.nr; ++k) { S.q[k] = q[k]; S.qd[k] = qd[k]; }
   S.tape.clear(); S.record = record != 0; S.has_prev = false;
   std::fill(S.lam_q.begin(), S.lam_q.end(), 0.0); std::fill(S.lam_v.begin(), S.lam_v.end(), 0.0);
+  std::fill(S.lam_q1.begin(), S.lam_q1.end(), 0.0); std::fill(S.lam_v1.begin(), S.lam_v1.end(), 0.0);
 }
 // BDF2 models: the state before the previous sub-step (teacher-forced replays start in the middle of a roll-out); call after orc_reset
 void orc_set_prev(void* h, const double* qm1, const double* qdm1) {
@@ -706,36 +719,52 @@ int orc_get_solver(void* h) { return ((Sim*)h)->solver; }
 int orc_backward_steps(void* h, int n, const double* df_dq, const double* df_dvar, const double* df_dtac, double* df_du) {
   Sim& S = *(Sim*)h; const Model& m = S.m; int nr = m.nr, nu = m.nu;
   if ((int)S.tape.size() < n) return -1;
-  double hh = m.h;
-  std::vector<double> g(nr), H(nr * nr), Jq0(nr * nr), Jv0(nr * nr), Ju(nr * std::max(nu, 1)), rhs(nr), z(nr);
+  if ((int)S.lam_q1.size() != nr) { S.lam_q1.assign(nr, 0.0); S.lam_v1.assign(nr, 0.0); }
+  std::vector<double> g(nr), H(nr * nr), J[4], Ju(nr * std::max(nu, 1)), rhs(nr), z(nr);
+  for (auto& j : J) j.assign(nr * nr, 0.0);
+  static const int which_of[4] = {1, 2, 4, 5};      // d/dq0, d/dqd0, d/dq_1, d/dqd_1
   for (int j = n - 1; j >= 0; --j) {
     Rec& r = S.tape.back();
-    if (r.bdf2) return -3;      // adjoint of BDF2 steps is not implemented (the reference's BDF2 model is forward-only)
+    // One sub-step in predictor form (make_coef): the new state (q1, qd1 = qdpred + cv (q1 - qpred)) depends on the history
+    // p = (q0, qd0, q_1, qd_1) through g(q1; p, u) = 0 and through qd1's explicit dependence on p.  (lam_q, lam_v): total derivative of
+    // the loss w.r.t. (q1, qd1) with everything later accounted for.  All Jacobians by dual numbers; nothing here uses the identities
+    // the kernels use (H = K + (cv R_v + ca M) / ca, ...), so the GPU adjoint test also verifies those.
+    StepCoef c; make_coef(m, r.q0.data(), r.qd0.data(), r.bdf2 ? r.qm1.data() : nullptr, r.bdf2 ? r.qdm1.data() : nullptr, c);
     for (int k = 0; k < nr; ++k) S.lam_q[k] += df_dq ? df_dq[j * nr + k] : 0.0;
     output_vjp(m, r.q1.data(), r.qd1.data(), df_dvar ? df_dvar + (size_t)j * 3 * m.nvar : nullptr,
                df_dtac ? df_dtac + (size_t)j * 3 * m.ntax : nullptr, S.lam_q.data(), S.lam_v.data());
-    eval_g_jac(m, r.q1.data(), r.q0.data(), r.qd0.data(), r.u.data(), 0, g.data(), H.data());
-    eval_g_jac(m, r.q1.data(), r.q0.data(), r.qd0.data(), r.u.data(), 1, g.data(), Jq0.data());
-    eval_g_jac(m, r.q1.data(), r.q0.data(), r.qd0.data(), r.u.data(), 2, g.data(), Jv0.data());
-    if (nu > 0) eval_g_jac(m, r.q1.data(), r.q0.data(), r.qd0.data(), r.u.data(), 3, g.data(), Ju.data());
-    for (int k = 0; k < nr; ++k) rhs[k] = S.lam_q[k] + S.lam_v[k] / hh;
+    eval_g_jac_c(m, r.q1.data(), c, r.u.data(), 0, g.data(), H.data());
+    const int nhist = r.bdf2 ? 4 : 2;
+    for (int w = 0; w < nhist; ++w) eval_g_jac_c(m, r.q1.data(), c, r.u.data(), which_of[w], g.data(), J[w].data());
+    if (nu > 0) eval_g_jac_c(m, r.q1.data(), c, r.u.data(), 3, g.data(), Ju.data());
+    for (int k = 0; k < nr; ++k) rhs[k] = S.lam_q[k] + c.cv * S.lam_v[k];               // d qd1 / d q1 = cv
     if (!solve_dense(nr, H.data(), rhs.data(), z.data(), true)) return -2;
-    for (int c = 0; c < nu; ++c) { double s = 0; for (int i = 0; i < nr; ++i) s += Ju[i * nu + c] * z[i]; df_du[j * nu + c] = -s; }
-    std::vector<double> lq(nr), lv(nr);
-    for (int c = 0; c < nr; ++c) {
-      double sq = 0, sv = 0;
-      for (int i = 0; i < nr; ++i) { sq += Jq0[i * nr + c] * z[i]; sv += Jv0[i * nr + c] * z[i]; }
-      lq[c] = -sq - S.lam_v[c] / hh; lv[c] = -sv;
+    for (int cc = 0; cc < nu; ++cc) { double s = 0; for (int i = 0; i < nr; ++i) s += Ju[i * nu + cc] * z[i]; df_du[j * nu + cc] = -s; }
+    std::vector<double> out[4];
+    for (int w = 0; w < 4; ++w) {
+      out[w].assign(nr, 0.0);
+      if (w >= nhist) continue;
+      const double dv = c.dqdp[w] - c.cv * c.dqp[w];                                     // explicit d qd1 / d p_w (q1 held)
+      for (int cc = 0; cc < nr; ++cc) {
+        double s = 0;
+        for (int i = 0; i < nr; ++i) s += J[w][i * nr + cc] * z[i];
+        out[w][cc] = -s + dv * S.lam_v[cc];
+      }
     }
-    S.lam_q = lq; S.lam_v = lv;
+    // the state one step back (q0, qd0) also carries what LATER sub-steps contributed to it as THEIR q_1 / qd_1
+    for (int k = 0; k < nr; ++k) {
+      S.lam_q[k] = out[0][k] + S.lam_q1[k]; S.lam_v[k] = out[1][k] + S.lam_v1[k];
+      S.lam_q1[k] = out[2][k]; S.lam_v1[k] = out[3][k];
+    }
     // restore the simulator state to the start of this sub-step (so outputs()/forward() stay consistent)
     S.q = r.q0; S.qd = r.qd0;
+    if (r.bdf2) { S.qm1 = r.qm1; S.qdm1 = r.qdm1; S.has_prev = true; } else S.has_prev = false;
     S.tape.pop_back();
   }
   return 0;
 }
 void orc_get_adjoint(void* h, double* lam_q, double* lam_v) { Sim& S = *(Sim*)h; for (int k = 0; k < S.m.nr; ++k) { lam_q[k] = S.lam_q[k]; lam_v[k] = S.lam_v[k]; } }
-void orc_clear_adjoint(void* h) { Sim& S = *(Sim*)h; std::fill(S.lam_q.begin(), S.lam_q.end(), 0.0); std::fill(S.lam_v.begin(), S.lam_v.end(), 0.0); }
+void orc_clear_adjoint(void* h) { Sim& S = *(Sim*)h; std::fill(S.lam_q.begin(), S.lam_q.end(), 0.0); std::fill(S.lam_v.begin(), S.lam_v.end(), 0.0); std::fill(S.lam_q1.begin(), S.lam_q1.end(), 0.0); std::fill(S.lam_v1.begin(), S.lam_v1.end(), 0.0); }
 
 // diagnostics for the tests: residual g and Jacobian `which` at an arbitrary point
 void orc_residual(void* h, const double* q1, const double* q0, const double* qd0, const double* u, int which, double* g, double* J) {

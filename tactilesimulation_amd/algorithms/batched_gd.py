@@ -158,7 +158,7 @@ class GraphedRollout:
             from ..model import blob as _blob
             if int(sim.model.I[_blob.TSIM_IH_INTEGRATOR]) != 1:
                 raise RuntimeError("GraphedRollout: BDF2 models cannot be captured (the integrator's history flag is host state baked into "
-                                   "the captured launch, and the adjoint is BDF1-only)")
+                                   "the captured launch)")
         self.deferred = hasattr(actor, "assemble_grads")      # the weight gradients of all env-steps as one GEMM after the replay
         if self.deferred:
             was_deferred = actor.defer_weight_grads

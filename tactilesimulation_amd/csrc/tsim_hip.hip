@@ -136,10 +136,18 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   int evals = 0;
   R gmax = R(0);
   const bool bdf2_model = ts_u(c.I[TSIM_IH_INTEGRATOR]) == 2;
-  bool has_prev = a.has_prev != 0;
+  // BDF2 history (the state before the previous sub-step).  While recording it is tape record t0 - 1 — so taped sub-step t is a BDF2
+  // step exactly when t >= 2, which is what the adjoint kernel assumes (also after the tape was swapped by the backward cache);
+  // without a tape it is the batch's `prev` buffer.
+  bool has_prev = a.record ? a.t0 >= 1 : a.has_prev != 0;
   if (bdf2_model && has_prev && lane < nr) {
-    c.qm1D[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qm1[lane] = (R)c.qm1D[lane];
-    c.qdm1[lane] = (R)a.prev[(size_t)env * 2 * nr + nr + lane];
+    if (a.record) {
+      const R* pr = a.tape + ((size_t)(a.t0 - 1) * a.B + env) * REC;
+      c.qm1D[lane] = rec_q(pr)[lane]; c.qm1[lane] = (R)c.qm1D[lane]; c.qdm1[lane] = pr[rec_qd<R>(nr) + lane];
+    } else {
+      c.qm1D[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qm1[lane] = (R)c.qm1D[lane];
+      c.qdm1[lane] = (R)a.prev[(size_t)env * 2 * nr + nr + lane];
+    }
   }
   TS_SYNC();
   // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
@@ -763,6 +771,13 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   init_world(c, lane, LPE);
   if (a.cyc && blockIdx.x == 0) c.stamps = a.cyc;
   if (lane < nr) { c.lamq[lane] = a.lamq[(size_t)env * nr + lane]; c.lamv[lane] = a.lamv[(size_t)env * nr + lane]; }
+  // BDF2 models: taped sub-step t >= 2 is a BDF2 step (the first one after a reset is the BDF1 start-up, k_forward).  Its new state
+  // depends on the TWO states before it, so next to the adjoint of the state one step back (lamq, lamv) the kernel carries what later
+  // sub-steps already contributed to the state two steps back (lq1, lv1: one value per lane, in registers; second half of the buffers).
+  const bool bdf2_model = ts_u(c.I[TSIM_IH_INTEGRATOR]) == 2;
+  const size_t half = (size_t)a.B * nr;
+  R lq1 = R(0), lv1 = R(0);
+  if (bdf2_model && lane < nr) { lq1 = a.lamq[half + (size_t)env * nr + lane]; lv1 = a.lamv[half + (size_t)env * nr + lane]; }
   TS_SYNC();
   R du_frame = R(0);
   // The tape record of sub-step t (q1, qd1, u, H) and the state before it (q, qd of record t - 1) are fetched ONE ITERATION AHEAD
@@ -771,21 +786,26 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   // q1, qd1 of the next iteration, so each iteration fetches u, H of record t - 1 and q, qd of record t - 2.)
   constexpr int NHL = (NRM * NRM + LPE - 1) / LPE;
   const int oqd = rec_qd<R>(nr), oH = rec_H<R>(nr), ou = rec_u<R>(nr);
-  double pq1 = 0.0, pq0 = 0.0; R pqd1 = R(0), pqd0 = R(0), pu = R(0), pH[NHL];
+  double pq1 = 0.0, pq0 = 0.0; R pqd1 = R(0), pqd0 = R(0), pqdm = R(0), pu = R(0), pH[NHL];     // pqdm: qd two records back (BDF2)
   {
     const R* r1 = a.tape + ((size_t)a.t_end * a.B + env) * REC;
     const R* r0 = a.tape + ((size_t)(a.t_end - 1) * a.B + env) * REC;
     if (lane < nr) { pq1 = rec_q(r1)[lane]; pqd1 = r1[oqd + lane]; pq0 = rec_q(r0)[lane]; pqd0 = r0[oqd + lane]; }
+    if (bdf2_model && a.t_end >= 2 && lane < nr) pqdm = a.tape[((size_t)(a.t_end - 2) * a.B + env) * REC + oqd + lane];
     if (lane < nu) pu = r1[ou + lane];
 #pragma unroll
     for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; pH[i] = e < nr * nr ? r1[oH + e] : R(0); }
   }
   for (int j = a.n - 1; j >= 0; --j) {
     const int t = a.t_end - (a.n - 1 - j);
+    const bool bdf2 = bdf2_model && t >= 2;
+    c.cv = bdf2 ? R(1.5) / c.h : R(1) / c.h;
+    c.ca = bdf2 ? R(2.25) / (c.h * c.h) : R(1) / (c.h * c.h);
     if (lane < nr) {
       c.qD[lane] = pq1; c.q[lane] = (R)pq1; c.q0[lane] = (R)pq0; c.qd0[lane] = pqd0;
-      c.qd[lane] = pqd1;                              // taped (q1 - q0)/h
-      c.qa[lane] = (pqd1 - pqd0) / c.h;               // discrete acceleration, no position cancellation
+      c.qd[lane] = pqd1;                              // taped velocity of the new state
+      // discrete acceleration from the taped velocities, no position cancellation: BDF1 (qd1 - qd0) / h, BDF2 (3 qd1 - 4 qd0 + qd_1) / 2h
+      c.qa[lane] = bdf2 ? (R(3) * pqd1 - R(4) * pqd0 + pqdm) / (R(2) * c.h) : (pqd1 - pqd0) / c.h;
     }
     if (lane < nu) c.u[lane] = pu;
 #pragma unroll
@@ -796,6 +816,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
       const R* r0 = a.tape + ((size_t)(t - 2) * a.B + env) * REC;
       pq1 = pq0; pqd1 = pqd0;
       if (lane < nr) { pq0 = rec_q(r0)[lane]; pqd0 = r0[oqd + lane]; }
+      if (bdf2_model && t >= 3 && lane < nr) pqdm = a.tape[((size_t)(t - 3) * a.B + env) * REC + oqd + lane];
       if (lane < nu) pu = r1[ou + lane];
 #pragma unroll
       for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; pH[i] = e < nr * nr ? r1[oH + e] : R(0); }
@@ -817,7 +838,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
                       (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr);
     }
     TS_STAMP(c);
-    if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.lamv[lane] / c.h;
+    if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.cv * c.lamv[lane];      // d qd1 / d q1 = cv
     TS_SYNC();
     solve_lanes<R, NRM, LPE>(H2, c.rhs, c.z, nr, true, lane);
     TS_STAMP(c);
@@ -830,8 +851,20 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     if (lane < nr) {
       R yq = R(0);
       for (int i = 0; i < nr; ++i) yq += c.z[i] * c.H[i * nr + lane];
-      c.lamq[lane] -= yq;
-      c.lamv[lane] = c.h * ym;
+      if (!bdf2) {                                    // BDF1: new state from (q0, qd0) only
+        c.lamq[lane] = c.lamq[lane] - yq + lq1;       // lq1, lv1: what a later BDF2 step put on this sub-step's (q0, qd0) as ITS (q_1, qd_1)
+        c.lamv[lane] = c.h * ym + lv1;
+        lq1 = R(0); lv1 = R(0);
+      } else {
+        // BDF2 in predictor form: with a_w = d qd1 / d p_w and dqp_w = d qpred / d p_w for p = (q0, qd0, q_1, qd_1),
+        //   -(dg/dp_w)^T z + a_w lam_v = a_w (lam_v - R_v^T z / ca) + dqp_w M z ,   R_v^T z / ca = (rhs - K^T z - M z) / cv
+        // (H = K + (cv R_v + ca M) / ca; rhs = H^T z).  a = (-2/h, 0, 1/2h, 0), dqp = (4/3, 8h/9, -1/3, -2h/9).
+        const R d = c.lamv[lane] - (c.rhs[lane] - yq - ym) / c.cv;
+        const R o0 = R(-2) / c.h * d + R(4.0 / 3) * ym, o1 = R(8.0 / 9) * c.h * ym;
+        const R o2 = R(0.5) / c.h * d - R(1.0 / 3) * ym, o3 = R(-2.0 / 9) * c.h * ym;
+        c.lamq[lane] = o0 + lq1; c.lamv[lane] = o1 + lv1;
+        lq1 = o2; lv1 = o3;
+      }
     }
     if (lane < nu && valid) {
       const int* mi = ts_motor_rec(c, lane);
@@ -839,7 +872,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
       R dtu;
       if (mi[TSIM_MI_CTRL] == 0) dtu = (c.u[lane] >= R(-1) && c.u[lane] <= R(1)) ? R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]) : R(0);
       else dtu = mf[TSIM_MF_P];
-      const R du = c.h * c.h * c.z[mi[TSIM_MI_DOF]] * dtu;
+      const R du = c.z[mi[TSIM_MI_DOF]] * dtu / c.ca;         // -(dg/du)^T z, g = r / ca
       if (!a.frames) a.df_du[((size_t)env * a.n + j) * nu + lane] = du;
       else {
         du_frame += du;
@@ -848,7 +881,10 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     }
     TS_SYNC();
   }
-  if (lane < nr && valid) { a.lamq[(size_t)env * nr + lane] = c.lamq[lane]; a.lamv[(size_t)env * nr + lane] = c.lamv[lane]; }
+  if (lane < nr && valid) {
+    a.lamq[(size_t)env * nr + lane] = c.lamq[lane]; a.lamv[(size_t)env * nr + lane] = c.lamv[lane];
+    if (bdf2_model) { a.lamq[half + (size_t)env * nr + lane] = lq1; a.lamv[half + (size_t)env * nr + lane] = lv1; }
+  }
 }
 
 // ================================================================================================ host side
@@ -876,7 +912,8 @@ struct tsim_batch {
   int* dI; void* dF;             // model on device (dF in the batch's real type)
   void* dFenv; int nfrec;        // optional per-environment float tables [B][nfrec] (domain randomisation)
   void* tape;                    // [(cap+1)][B][rec]
-  void *lamq, *lamv;             // carried adjoint [B][nr]
+  void *lamq, *lamv;             // carried adjoint [2][B][nr]: of the state the next adjoint sub-step starts from, and (BDF2) what later
+                                 // sub-steps already contributed to the state one step further back
   int* evals;                    // residual evaluations of the last forward launch, per env
   float* gnorm = nullptr;        // largest ||g|| a sub-step of the last forward launch ended with, per env
   int cross_kinks = 0, eval_budget = 0;     // tsim_set_solver_options
@@ -1154,14 +1191,14 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0; b->poseR = nullptr; b->poseD = nullptr; b->nspt = b->I[TSIM_IH_NSPRIM];
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
-      hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->gnorm, (size_t)B * sizeof(float)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
+      hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)2 * B * nr * b->esz) != hipSuccess ||
+      hipMalloc(&b->lamv, (size_t)2 * B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->gnorm, (size_t)B * sizeof(float)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
       (b->nspt > 0 && (hipMalloc(&b->poseR, (size_t)B * b->nspt * TP_R_SIZE * b->esz) != hipSuccess || hipMalloc((void**)&b->poseD, (size_t)B * b->nspt * TP_D_SIZE * sizeof(double)) != hipSuccess))) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
   }
-  if (hipMemset(b->tape, 0, tape_bytes) != hipSuccess || hipMemset(b->lamq, 0, (size_t)B * nr * b->esz) != hipSuccess ||
-      hipMemset(b->lamv, 0, (size_t)B * nr * b->esz) != hipSuccess) { tsim_batch_destroy(b); return fail("hipMemset failed"); }
+  if (hipMemset(b->tape, 0, tape_bytes) != hipSuccess || hipMemset(b->lamq, 0, (size_t)2 * B * nr * b->esz) != hipSuccess ||
+      hipMemset(b->lamv, 0, (size_t)2 * B * nr * b->esz) != hipSuccess) { tsim_batch_destroy(b); return fail("hipMemset failed"); }
   if (upload_model(b, nullptr)) { tsim_batch_destroy(b); return 1; }
   *out = b;
   return 0;
@@ -1248,7 +1285,7 @@ int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag
   if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_set_state<float>, dim3(grd), dim3(blk), 0, st, (float*)b->tape, (const float*)q0, (const float*)qd0, b->B, b->nr, b->rec);
   else hipLaunchKernelGGL(k_set_state<double>, dim3(grd), dim3(blk), 0, st, (double*)b->tape, (const double*)q0, (const double*)qd0, b->B, b->nr, b->rec);
   HIPCHK(hipGetLastError());
-  if (zero_async(b->lamq, (size_t)b->B * b->nr * b->esz, st) || zero_async(b->lamv, (size_t)b->B * b->nr * b->esz, st)) return 1;
+  if (zero_async(b->lamq, (size_t)2 * b->B * b->nr * b->esz, st) || zero_async(b->lamv, (size_t)2 * b->B * b->nr * b->esz, st)) return 1;
   b->t_cur = 0; b->record = backward_flag ? 1 : 0; b->order_valid = 0; b->has_prev = 0;
   return 0;
 }
@@ -1336,7 +1373,6 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
 
 int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream) {
   if (!b->record) return fail("backward_steps: reset(backward_flag=True) was not called");
-  if (b->I[TSIM_IH_INTEGRATOR] != 1) return fail("backward_steps: the adjoint is implemented for BDF1 models only (the reference's BDF2 model, tactile_pad.xml, is forward-only)");
   if (n <= 0 || n > b->t_cur) return fail("backward_steps: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
   if (!df_du && b->nu > 0) return fail("backward_steps: df_du is null");
   if (seed_mode != 0 && seed_mode != 1) return fail("backward_steps: bad seed_mode");
@@ -1364,7 +1400,6 @@ int tsim_rollout(tsim_batch* b, const void* u, int num_frames, int num_steps, co
 
 int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const int32_t* tactile_slot, const void* df_dq, const void* df_dvar, const void* df_dtac, void* df_du, void* stream) {
   if (!b->record) return fail("backward_episode: reset(backward_flag=True) was not called");
-  if (b->I[TSIM_IH_INTEGRATOR] != 1) return fail("backward_episode: the adjoint is implemented for BDF1 models only (the reference's BDF2 model, tactile_pad.xml, is forward-only)");
   if (num_frames <= 0 || num_steps <= 0) return fail("backward_episode: num_frames and num_steps must be positive");
   const long long n = (long long)num_frames * num_steps;
   if (n > b->t_cur) return fail("backward_episode: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
@@ -1417,7 +1452,7 @@ int tsim_cache_pop(tsim_batch* b, void* stream) {
   b->pool.push_back(b->tape);                 // stream order keeps earlier kernels on the old buffer safe: it is only
   b->tape = e.buf;                            // handed out again by a later save on the same stream
   b->t_cur = e.len; b->record = e.record; b->has_prev = 0; b->order_valid = 0;
-  if (zero_async(b->lamq, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream) || zero_async(b->lamv, (size_t)b->B * b->nr * b->esz, (hipStream_t)stream)) return 1;
+  if (zero_async(b->lamq, (size_t)2 * b->B * b->nr * b->esz, (hipStream_t)stream) || zero_async(b->lamv, (size_t)2 * b->B * b->nr * b->esz, (hipStream_t)stream)) return 1;
   return 0;
 }
 int tsim_cache_clear(tsim_batch* b) {

@@ -226,3 +226,60 @@ def test_exponential_joint_newton_matrix_is_exact():
     # translational columns, so those are compared loosely; the rotation-vector columns (the new joint) must be exact
     assert np.abs(H[:, 6:9] - Hfd[:, 6:9]).max() < 1e-6 * np.abs(H).max()
     assert np.abs(H - Hfd).max() < 2e-2 * np.abs(H).max()
+
+
+@pytest.mark.parametrize("name,nsub0,T", [("pusher", 60, 8), ("ball_push", 12, 8)])
+def test_bdf2_adjoint_matches_finite_differences(name, nsub0, T):
+    """The oracle's adjoint of BDF2 sub-steps (round 3; the reference's only BDF2 model, tactile_pad.xml, is never differentiated —
+    examples/RollingBallExp/test_sim_speed.py:51 — so the integrator is forced on two models that are): first recorded sub-step BDF1
+    (start-up), the rest BDF2; dL/du of every sub-step and dL/dqd0 against central differences of the roll-out itself."""
+    import os
+    import tactilesimulation_amd.model.blob as Bl
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.workloads import push_workload, PUSHER_BLOB
+    from oracle.oracle import OracleSim
+    here = os.path.dirname(os.path.abspath(__file__))
+    m = load_model(PUSHER_BLOB if name == "pusher" else os.path.join(here, "models", name + ".xml"))
+    m.F[Bl.TSIM_FH_TOL] = 1e-13
+    m.I[Bl.TSIM_IH_INTEGRATOR] = 2
+    rng = np.random.default_rng(0)
+    if name == "pusher":
+        q0, u, _ = push_workload(1, 40, seed=5)
+        u = np.repeat(u[0], 5, axis=0)                                    # one action per sub-step
+    else:
+        q0 = np.array([[0, 0, 0, 0, 0, 0, 0.3, -0.2, 0.5]], dtype=np.float64)
+        u = np.stack([[0.3 * np.sin(t), 0.25 * np.cos(t), -0.4] for t in range(40)])
+    o = OracleSim(m)
+    o.reset(q0[0])
+    for t in range(nsub0):                                                # into the contact phase
+        assert o.forward(u[t], 1) == 0
+    qs, qds = o.state()
+    U, W = u[nsub0:nsub0 + T].copy(), rng.normal(size=(T, m.ndof_r))
+
+    def loss(qd0_, U_):
+        o.reset(qs, qd0_, record=False)
+        L = 0.0
+        for t in range(T):
+            assert o.forward(U_[t], 1) == 0
+            L += W[t] @ o.state()[0]
+        return L
+    o.reset(qs, qds, record=True)
+    for t in range(T):
+        o.forward(U[t], 1)
+    G = np.zeros((T, m.ndof_u))
+    for t in reversed(range(T)):
+        G[t] = o.backward_steps(1, W[t][None])[0]
+    _, lv = o.adjoint()
+    eps = 1e-6
+    Gfd, lvf = np.zeros_like(G), np.zeros(m.ndof_r)
+    for t in range(T):
+        for k in range(m.ndof_u):
+            Up, Um = U.copy(), U.copy()
+            Up[t, k] += eps; Um[t, k] -= eps
+            Gfd[t, k] = (loss(qds, Up) - loss(qds, Um)) / (2 * eps)
+    for k in range(m.ndof_r):
+        e = np.zeros(m.ndof_r); e[k] = eps
+        lvf[k] = (loss(qds + e, U) - loss(qds - e, U)) / (2 * eps)
+    assert np.abs(Gfd).max() > 1e-3
+    assert np.abs(G - Gfd).max() < 1e-6 * np.abs(Gfd).max(), np.abs(G - Gfd).max() / np.abs(Gfd).max()
+    assert np.abs(lv - lvf).max() < 1e-6 * np.abs(lvf).max(), np.abs(lv - lvf).max() / np.abs(lvf).max()
