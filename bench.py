@@ -502,6 +502,10 @@ def main():
                     res["closed_loop"] = closed_loop_leg(model, B, T, tdt, dev)
                 except Exception as e:      # the headline must not die with an optional leg
                     res["closed_loop"] = {"error": repr(e)}
+                try:
+                    res["closed_loop_fused"] = closed_loop_fused_leg(model, B, T, tdt, dev)
+                except Exception as e:
+                    res["closed_loop_fused"] = {"error": repr(e)}
                 progress("closed loop done")
             try:
                 res["readout_hbm"] = readout_leg(tdt, dev)
@@ -626,6 +630,39 @@ def closed_loop_leg(model, B, T, tdt, dev, epochs=3):
                    "gradient normalise + clip + Adam; one HIP graph replay per episode",
            "loss_per_episode": [float(l) / B for l in losses]}
     del gr, env
+    torch.cuda.empty_cache()
+    return res
+
+
+def closed_loop_fused_leg(model, B, T, tdt, dev, epochs=3):
+    """The same GD epoch with the policy INSIDE the simulator's episode launches (envs/push_closed_loop.FusedPushEpisode,
+    include/tsim_env.h tsim_push_closed_rollout / _backward): one launch each way per episode, so no env-step waits for the batch's
+    slowest environment; reward, its partials and the weight-gradient GEMMs stay in torch.  Same episode data, same optimiser, same
+    cold start as closed_loop_leg; the two legs' gradients agree (tests/test_gpu_closed_loop.py)."""
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode, train_epoch_fused
+    from tactilesimulation_amd.algorithms.batched_gd import Actor
+    env = BatchedTactilePushEnv(model, B, device=str(dev), dtype=tdt, gradient=True, seed=0, tape_steps=T)
+    env.reset()
+    q0, goal = env.q0.clone(), env.goal.clone()
+    rng = np.random.default_rng(1)
+    dist_ = torch.tensor(rng.uniform(-1, 1, size=(T, B, 2)) * (rng.uniform(size=(T, B, 1)) < 0.5), device=dev, dtype=tdt)
+    torch.manual_seed(0)
+    actor = Actor(dtype=tdt).to(dev)
+    opt = torch.optim.Adam(actor.parameters(), lr=5e-3, betas=(0.7, 0.95))          # cfg/gd_tactile.yaml
+    ep = FusedPushEpisode(env, actor, T)
+    train_epoch_fused(ep, opt, q0, goal, dist_, B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = [train_epoch_fused(ep, opt, q0, goal, dist_, B).detach().clone() for _ in range(epochs)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bad = int((ep.status != 0).sum().item())
+    res = {"value": B * T * epochs / dt, "unit": "env-steps/s", "s_per_epoch": dt / epochs, "epochs": epochs, "horizon": T, "batch": B,
+           "what": "closed GD epoch with the policy (393-64-64-3 ELU MLP, observation, action mapping) evaluated inside the simulator's episode "
+                   "launches: one launch each way per episode; reward partials and weight-gradient GEMMs in torch; normalise + clip + Adam",
+           "loss_per_episode": [float(l) / B for l in losses], "nonconverged_envs_last_epoch": bad}
+    del ep, env
     torch.cuda.empty_cache()
     return res
 

@@ -36,6 +36,35 @@ int tsim_push_observe_backward(int B, int ntac, int dtype, const void* q, const 
                                const void* d_obs, const void* d_rew, long long d_rew_stride,
                                void* dq, void* dvar, void* dtac, void* du, void* stream);
 
+/* ---- The closed loop in ONE launch each way (BASELINE config 3 as cfg/gd_tactile.yaml runs it) -------------------------------------
+ * algorithms/gd.py:224-259 alternates policy and env-step: obs -> DiagGaussianActor mean (utils/model.py:123-151: 393 -> 64 -> 64 -> 3, ELU)
+ * -> action -> StepSimFunction.  One launch per env-step makes every env-step wait for the slowest environment of the batch; here the
+ * observation, the MLP and the action mapping of an environment run inside ITS slot of the episode launch, between two frames
+ * (csrc/tsim_policy_push.h), and their reverse inside the episode's adjoint launch.  Weight layouts (device, the batch's dtype):
+ *   W1T [393][64], W2T [64][64]   layer weights transposed (input-major);   W3 [3][64], b1 [64], b2 [64], b3 [3] as torch stores them
+ *   W1p [64][w1_stride]           layer-1 weights as torch stores them, rows padded to w1_stride >= 393, a multiple of 4 (backward only)
+ *   W2  [64][64]                  layer-2 weights as torch stores them (backward only)                                              */
+typedef struct tsim_push_policy {
+  const void *W1T, *b1, *W2T, *b2, *W3, *b3, *W1p, *W2;
+  int w1_stride;
+} tsim_push_policy;
+
+/* Forward: num_frames env-steps of num_steps sub-steps from the batch's current state; frame f acts with
+ *   action_f = [tanh(policy(obs_f)), dist[f][env][0:2], 0],  obs_f = [goal in the gripper frame of the state before the frame, tactile frame before it]
+ * (tac0 [B][390]: the tactile frame at the current state, tsim_readout).  Outputs per frame [T][B][.]: q, qd (may be NULL), var, tac (required:
+ * it feeds the next observation), and the policy's records u (3, pre-tanh), gl (3, goal part of the observation), h1, h2 (64, ELU outputs). */
+int tsim_push_closed_rollout(tsim_batch* b, const tsim_push_policy* pol, const void* goal, const void* dist, const void* tac0,
+                             int num_frames, int num_steps, void* q_out, void* qd_out, void* var_out, void* tac_out,
+                             void* u_out, void* gl_out, void* h1_out, void* h2_out, int32_t* status, void* stream);
+/* Backward of that episode: df_dq / df_dvar [T][B][.] direct partials of the loss w.r.t. the frames' outputs (NULL = none), du_direct [T][B][3]
+ * its direct partial w.r.t. the policy outputs (the reward's action term), the forward records, -> per frame the gradients w.r.t. the layers'
+ * pre-activations g1, g2 [T][B][64], g3 [T][B][3] (weight gradients: dW_l = sum_t g_l[t]^T x_l[t], assembled by the caller as batched GEMMs),
+ * dobs_tac [T][B][390] (workspace and result: gradient w.r.t. the tactile part of frame f's observation), df_du [T][B][6] or NULL.
+ * The dependence of the FIRST observation on the initial state is not propagated (tsim_get_adjoint excludes it). */
+int tsim_push_closed_backward(tsim_batch* b, const tsim_push_policy* pol, const void* goal, int num_frames, int num_steps,
+                              const void* df_dq, const void* df_dvar, const void* du_direct, const void* u_out, const void* h1_out, const void* h2_out,
+                              void* g1_out, void* g2_out, void* g3_out, void* dobs_tac, void* df_du, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,3 +125,98 @@ extern "C" int tsim_push_observe_backward(int B, int ntac, int dtype, const void
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+
+// ================================================================================================ closed loop in one launch each way
+// (tsim_policy_push.h: the policy between the frames of k_forward / k_backward)
+template <class R>
+static PushPolicy<R> make_push_policy(const tsim_push_policy* p) {
+  PushPolicy<R> P;
+  memset(&P, 0, sizeof(P));
+  P.W1T = (const R*)p->W1T; P.b1 = (const R*)p->b1; P.W2T = (const R*)p->W2T; P.b2 = (const R*)p->b2; P.W3 = (const R*)p->W3; P.b3 = (const R*)p->b3;
+  P.W1p = (const R*)p->W1p; P.W2 = (const R*)p->W2; P.w1s = p->w1_stride;
+  return P;
+}
+static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, int num_frames, int num_steps, const char* who) {
+  if (!b || !pol) return fail(std::string(who) + ": null batch / policy");
+  if (b->nr != 7 || b->nu != 6 || 3 * b->ntax != PP_NTAC || b->nvar != 2 || b->has_exp) return fail(std::string(who) + ": not the TactilePush model (ndof_r 7, ndof_u 6, 130 taxels, 2 end-effector points)");
+  if (num_frames <= 0 || num_steps <= 0) return fail(std::string(who) + ": num_frames and num_steps must be positive");
+  if (!pol->W1T || !pol->b1 || !pol->W2T || !pol->b2 || !pol->W3 || !pol->b3) return fail(std::string(who) + ": policy weights missing");
+  if (b->dFenv) return fail(std::string(who) + ": per-environment tables are not supported in the closed-loop launch");
+  return 0;
+}
+#define TS_LAUNCH_POLICY(KERNEL, R, b, st, a) do {                                                                                   \
+    const LaunchShape L = launch_shape(b);                                                                                           \
+    if (L.lpe == 64) hipLaunchKernelGGL((KERNEL<R, 8, false, 64, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                  \
+    else if (L.lpe == 32) hipLaunchKernelGGL((KERNEL<R, 8, false, 32, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);             \
+    else hipLaunchKernelGGL((KERNEL<R, 8, false, 16, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                              \
+  } while (0)
+
+template <class R>
+static int push_closed_rollout_t(tsim_batch* b, const tsim_push_policy* pol, const void* goal, const void* dist, const void* tac0, int nframes, int nsub,
+                                 void* q_out, void* qd_out, void* var_out, void* tac_out, void* u_out, void* gl_out, void* h1_out, void* h2_out, int32_t* status, hipStream_t st) {
+  FwdArgs<R> a;
+  memset(&a, 0, sizeof(a));
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = nullptr; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = nullptr;
+  a.tape = (R*)b->tape; a.u = nullptr;
+  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = nullptr;
+  a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
+  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm;
+  a.pol = make_push_policy<R>(pol);
+  a.pol.goal = (const R*)goal; a.pol.dist = (const R*)dist; a.pol.tac0 = (const R*)tac0;
+  a.pol.u_out = (R*)u_out; a.pol.gl_out = (R*)gl_out; a.pol.h1_out = (R*)h1_out; a.pol.h2_out = (R*)h2_out;
+  TS_LAUNCH_POLICY(k_forward, R, b, st, a);
+  HIPCHK(hipGetLastError());
+  b->order_valid = 0;
+  return 0;
+}
+
+extern "C" int tsim_push_closed_rollout(tsim_batch* b, const tsim_push_policy* pol, const void* goal, const void* dist, const void* tac0,
+                                        int num_frames, int num_steps, void* q_out, void* qd_out, void* var_out, void* tac_out,
+                                        void* u_out, void* gl_out, void* h1_out, void* h2_out, int32_t* status, void* stream) {
+  if (int rc = push_closed_check(b, pol, num_frames, num_steps, "push_closed_rollout")) return rc;
+  if (!goal || !dist || !tac0 || !tac_out || !u_out || !gl_out || !h1_out || !h2_out) return fail("push_closed_rollout: null pointer (goal, dist, tac0, tac_out and the policy records are required)");
+  if (b->record && b->t_cur + (long long)num_frames * num_steps > b->cap) return fail("push_closed_rollout: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
+  TS_DEVICE(b);
+  int rc = b->dtype == TSIM_F32 ? push_closed_rollout_t<float>(b, pol, goal, dist, tac0, num_frames, num_steps, q_out, qd_out, var_out, tac_out, u_out, gl_out, h1_out, h2_out, status, (hipStream_t)stream)
+                                : push_closed_rollout_t<double>(b, pol, goal, dist, tac0, num_frames, num_steps, q_out, qd_out, var_out, tac_out, u_out, gl_out, h1_out, h2_out, status, (hipStream_t)stream);
+  if (rc) return rc;
+  if (b->record) b->t_cur += num_frames * num_steps;
+  b->has_prev = 1;
+  return 0;
+}
+
+template <class R>
+static int push_closed_backward_t(tsim_batch* b, const tsim_push_policy* pol, const void* goal, int nframes, int nsub, const void* df_dq, const void* df_dvar,
+                                  const void* du_direct, const void* u_out, const void* h1_out, const void* h2_out, void* g1_out, void* g2_out, void* g3_out,
+                                  void* dobs_tac, void* df_du, hipStream_t st) {
+  BwdArgs<R> a;
+  memset(&a, 0, sizeof(a));
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = nullptr; a.fstride = b->nfrec; a.B = b->B; a.n = nframes * nsub; a.t_end = b->t_cur; a.seed_stride = nsub; a.frames = 1; a.tac_slot = nullptr;
+  a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = nullptr;
+  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = nullptr;
+  a.pol = make_push_policy<R>(pol);
+  a.pol.goal = (const R*)goal; a.pol.du_direct = (const R*)du_direct;
+  a.pol.u_out = (R*)u_out; a.pol.h1_out = (R*)h1_out; a.pol.h2_out = (R*)h2_out;
+  a.pol.g1_out = (R*)g1_out; a.pol.g2_out = (R*)g2_out; a.pol.g3_out = (R*)g3_out; a.pol.dobs_tac = (R*)dobs_tac;
+  TS_LAUNCH_POLICY(k_backward, R, b, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int tsim_push_closed_backward(tsim_batch* b, const tsim_push_policy* pol, const void* goal, int num_frames, int num_steps,
+                                         const void* df_dq, const void* df_dvar, const void* du_direct, const void* u_out, const void* h1_out, const void* h2_out,
+                                         void* g1_out, void* g2_out, void* g3_out, void* dobs_tac, void* df_du, void* stream) {
+  if (int rc = push_closed_check(b, pol, num_frames, num_steps, "push_closed_backward")) return rc;
+  if (!pol->W1p || !pol->W2 || pol->w1_stride < PP_OBS || pol->w1_stride % 4) return fail("push_closed_backward: W1p [64][w1_stride >= 393, multiple of 4] and W2 are required");
+  if (!b->record) return fail("push_closed_backward: reset(backward_flag=True) was not called");
+  const long long n = (long long)num_frames * num_steps;
+  if (n > b->t_cur) return fail("push_closed_backward: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
+  if (!goal || !du_direct || !u_out || !h1_out || !h2_out || !g1_out || !g2_out || !g3_out || !dobs_tac) return fail("push_closed_backward: null pointer");
+  TS_DEVICE(b);
+  int rc = b->dtype == TSIM_F32 ? push_closed_backward_t<float>(b, pol, goal, num_frames, num_steps, df_dq, df_dvar, du_direct, u_out, h1_out, h2_out, g1_out, g2_out, g3_out, dobs_tac, df_du, (hipStream_t)stream)
+                                : push_closed_backward_t<double>(b, pol, goal, num_frames, num_steps, df_dq, df_dvar, du_direct, u_out, h1_out, h2_out, g1_out, g2_out, g3_out, dobs_tac, df_du, (hipStream_t)stream);
+  if (rc) return rc;
+  b->t_cur -= (int)n;
+  return 0;
+}

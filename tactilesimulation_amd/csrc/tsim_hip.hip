@@ -19,6 +19,7 @@
 #include <vector>
 #include "../../include/tsim.h"
 #include "tsim_eval.h"
+#include "tsim_policy_push.h"
 
 
 // tape record per (sub-step, env), in reals: q[nr] as DOUBLE (the pose chain is double also in the fp32 kernels),
@@ -103,6 +104,7 @@ template <class R> struct FwdArgs {
   int cross_kinks;             // full Newton step at an exhausted line search close to convergence (tsim_set_solver_options)
   int eval_budget;             // residual evaluations a sub-step may take before it is flagged and left (0: the XML's max_iter / max_ls only)
   float* gnorm;                // [B] largest ||g|| a sub-step of this launch ended with (diagnostics, tsim_last_gnorm)
+  PushPolicy<R> pol;           // POLICY instantiations only (tsim_push_closed_rollout): the TactilePush policy between the frames
 };
 
 // -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
@@ -111,7 +113,7 @@ template <class R> struct FwdArgs {
 #else
 #define TS_KLB __launch_bounds__(TS_WAVE)
 #endif
-template <class R, int NRM, bool EXPJ, int LPE>
+template <class R, int NRM, bool EXPJ, int LPE, bool POLICY = false>
 __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
@@ -155,6 +157,15 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   for (int f = 0; f < a.nframes; ++f) {
   {
     R uv = R(0);
+    if (POLICY) {
+      // closed loop: the action comes from the policy, evaluated by this slot on the observation the previous frame left
+      // (tsim_policy_push.h).  The tactile frame was written by this slot: make the stores visible to its own loads first.
+      __threadfence();
+      const R* tprev = f == 0 ? a.pol.tac0 + (size_t)env * PP_NTAC : a.tac_out + ((size_t)(f - 1) * a.B + env) * PP_NTAC;
+      push_policy_forward<LPE>(c, lane, valid, a.pol, (size_t)f * a.B + env, env, tprev);
+      TS_SYNC();
+      if (lane < nu) uv = c.u[lane];
+    } else
     if (lane < nu) { uv = a.u[((size_t)f * a.B + env) * nu + lane]; c.u[lane] = uv; }
     // a NaN / inf control would be clamped away silently by the motor law's fmin / fmax: flag it (status bit 30) instead
     if (seg_sum<LPE>((uv - uv == R(0)) ? R(0) : R(1)) > R(0)) nonfinite = true;
@@ -624,6 +635,7 @@ template <class R> struct BwdArgs {
   R *lamq, *lamv, *df_du;
   int stage_cpt;
   long long* cyc;         // diagnostics: shader-clock stamps of the first sub-steps of wavefront 0 (tsim_debug_stamps), or null
+  PushPolicy<R> pol;      // POLICY instantiations only (tsim_push_closed_backward)
 };
 
 // (M z)_j for lane j, M = sum_i J_i^T I_i J_i:  lanes = links form f_i = I_i (sum_{k above i} W_k z_k) in the (idle) pair-staging
@@ -756,7 +768,7 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
   TS_SYNC();
 }
 
-template <class R, int NRM, bool EXPJ, int LPE>
+template <class R, int NRM, bool EXPJ, int LPE, bool POLICY = false>
 __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
@@ -780,6 +792,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   if (bdf2_model && lane < nr) { lq1 = a.lamq[half + (size_t)env * nr + lane]; lv1 = a.lamv[half + (size_t)env * nr + lane]; }
   TS_SYNC();
   R du_frame = R(0);
+  R pol_dq = R(0); bool pol_have = false;      // POLICY: what the NEXT frame's observation put on this frame's final state (q[0..2]; tactile: pol.dobs_tac)
   // The tape record of sub-step t (q1, qd1, u, H) and the state before it (q, qd of record t - 1) are fetched ONE ITERATION AHEAD
   // into registers: a lone wavefront cannot hide the ~2 x 1.5 k cycles of HBM latency of dependent loads at the top of every
   // sub-step, but the loads for the next sub-step fly during the whole of this one.  (Record t - 1 supplies q0, qd0 now and
@@ -833,9 +846,11 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
       const int tslot = (a.frames && a.tac_slot) ? a.tac_slot[fr] : 0;
       const size_t sot = (a.frames && a.tac_slot) ? (size_t)max(tslot, 0) * a.B + env : so;
       if (a.df_dq && lane < nr) c.lamq[lane] += a.df_dq[so * nr + lane];
+      if (POLICY && pol_have && lane < 3) c.lamq[lane] += pol_dq;        // goal part of the next frame's observation
       TS_SYNC();
-      output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr,
-                      (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr);
+      const R* wtac_ = (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr;
+      if (POLICY) wtac_ = pol_have ? a.pol.dobs_tac + ((size_t)(fr + 1) * a.B + env) * PP_NTAC : nullptr;   // tactile part (frame fr + 1's observation)
+      output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, wtac_);
     }
     TS_STAMP(c);
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.cv * c.lamv[lane];      // d qd1 / d q1 = cv
@@ -866,18 +881,29 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
         lq1 = o2; lv1 = o3;
       }
     }
-    if (lane < nu && valid) {
+    if (lane < nu) {
       const int* mi = ts_motor_rec(c, lane);
       const R* mf = c.F + c.foff_motor + lane * TSIM_MF_SIZE;
       R dtu;
       if (mi[TSIM_MI_CTRL] == 0) dtu = (c.u[lane] >= R(-1) && c.u[lane] <= R(1)) ? R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]) : R(0);
       else dtu = mf[TSIM_MF_P];
       const R du = c.z[mi[TSIM_MI_DOF]] * dtu / c.ca;         // -(dg/du)^T z, g = r / ca
-      if (!a.frames) a.df_du[((size_t)env * a.n + j) * nu + lane] = du;
+      if (!a.frames) { if (valid) a.df_du[((size_t)env * a.n + j) * nu + lane] = du; }
       else {
         du_frame += du;
-        if (j % a.seed_stride == 0) { a.df_du[((size_t)(j / a.seed_stride) * a.B + env) * nu + lane] = du_frame; du_frame = R(0); }
+        if (j % a.seed_stride == 0 && valid && a.df_du) a.df_du[((size_t)(j / a.seed_stride) * a.B + env) * nu + lane] = du_frame;
       }
+    }
+    if (a.frames && j % a.seed_stride == 0) {              // a frame is undone
+      if (POLICY) {
+        // ... and so is the policy call in front of it: dL/d(action) -> MLP -> observation -> the state / tactile frame before it
+        TS_SYNC();
+        const int fr0 = j / a.seed_stride;
+        pol_dq = push_policy_backward<LPE>(c, lane, valid, a.pol, (size_t)fr0 * a.B + env, env, du_frame, (double)c.q0[0]);
+        pol_have = true;
+        __threadfence();                                   // dobs_tac is read back by this slot as the previous frame's tactile seed
+      }
+      du_frame = R(0);
     }
     TS_SYNC();
   }

@@ -44,9 +44,16 @@ _SIGS = {
     "tsim_push_action": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "tsim_push_action_backward": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "tsim_push_observe": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_push_closed_rollout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tsim_push_closed_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tsim_push_observe_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = sorted(_SIGS)
+
+
+class PushPolicyStruct(C.Structure):
+    """include/tsim_env.h tsim_push_policy"""
+    _fields_ = [(n, C.c_void_p) for n in ("W1T", "b1", "W2T", "b2", "W3", "b3", "W1p", "W2")] + [("w1_stride", C.c_int)]
 
 
 def lib():

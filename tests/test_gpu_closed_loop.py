@@ -1,0 +1,88 @@
+"""The closed loop in one launch each way (include/tsim_env.h tsim_push_closed_rollout / tsim_push_closed_backward, csrc/tsim_policy_push.h)
+against the loop it replaces: algorithms/batched_gd.rollout_loss on BatchedTactilePushEnv — observation, policy, action mapping and
+env-step as separate launches per env-step with torch autograd in between (itself pinned to the reference's TactilePushEnv and GD class on
+golden vectors: tests/test_env_golden.py, tests/test_gd_loop_golden.py).  Same episode, same policy: the loss, every frame's state and
+policy output, and the gradient of every policy parameter must agree."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _episode(B, T, seed):
+    rng = np.random.default_rng(seed)
+    q0 = np.zeros((B, 7)); q0[:, 1] = -0.001; q0[:, 4] = rng.uniform(-0.02, 0.02, size=B)
+    goal = np.zeros((B, 3)); goal[:, 0:2] = rng.uniform([0.15, -0.2], [0.25, 0.2], size=(B, 2))
+    goal[:, 2] = rng.uniform(goal[:, 1] * np.pi - np.pi / 16.0, goal[:, 1] * np.pi + np.pi / 16.0)
+    dist = rng.uniform(-1.0, 1.0, size=(T, B, 2)) * (rng.uniform(size=(T, B, 1)) < 0.5)
+    return q0, goal, dist
+
+
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-3)])
+def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes):
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode
+    from tactilesimulation_amd.algorithms.batched_gd import Actor, rollout_loss
+    B, T = 10, 12                                                    # a batch that is no multiple of the slots per wavefront
+    q0, goal, dist = (torch.tensor(a, device="cuda", dtype=dtype) for a in _episode(B, T, 3))
+    torch.manual_seed(1)
+    actor = Actor(dtype=dtype).cuda()
+    with torch.no_grad():                                            # a policy that acts (the initial one outputs ~0)
+        for p in actor.parameters():
+            p.mul_(3.0)
+    # ---- the per-step loop with autograd
+    env = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T)
+    env.sim.set_lanes_per_env(lanes)
+    obs = env.reset(q0, goal)
+    qs, us, total = [], [], obs.new_zeros(())
+    for t in range(T):
+        u = actor(obs)
+        obs, rew, info = env.step(u, dist[t])
+        total = total - rew.sum()
+        qs.append(info["q"].detach().clone()); us.append(u.detach().clone())
+    named = [(n, p) for n, p in actor.named_parameters() if n != "logstd"]
+    ref = torch.autograd.grad(total, [p for _, p in named])
+    # ---- the fused episode
+    env2 = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T)
+    env2.sim.set_lanes_per_env(lanes)
+    ep = FusedPushEpisode(env2, actor, T)
+    loss = ep.rollout(q0, goal, dist)
+    assert int((ep.status != 0).sum()) == 0
+    ep.backward()
+    assert env2.sim.tape_len() == 0
+    q_ref, u_ref = torch.stack(qs), torch.stack(us)
+    assert float((ep.q - q_ref).abs().max()) < tol_q
+    assert float((ep.u - u_ref).abs().max()) < 50 * tol_q * max(1.0, float(u_ref.abs().max()))
+    assert abs(float(loss) - float(total)) < 100 * tol_q * abs(float(total))
+    for (n, p), r in zip(named, ref):
+        err = float((p.grad - r).norm()) / max(float(r.norm()), 1e-30)
+        assert err < tol_g, (n, err)
+    assert float(torch.stack([r.norm() for r in ref]).min()) > 0.0   # every parameter does get a gradient
+
+
+def test_fused_epoch_b4096_trains_and_matches_the_graphed_loop(pusher_model):
+    """B = 4096 fp32, the bench's closed-loop leg: the fused episode's policy gradient equals the graphed per-step loop's on the same
+    episode, and three Adam epochs reduce the loss."""
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode, train_epoch_fused
+    from tactilesimulation_amd.algorithms.batched_gd import Actor, rollout_loss
+    B, T, dt = 4096, 20, torch.float32
+    q0, goal, dist = (torch.tensor(a, device="cuda", dtype=dt) for a in _episode(B, T, 5))
+    torch.manual_seed(0)
+    actor = Actor(dtype=dt).cuda()
+    env = BatchedTactilePushEnv(pusher_model, B, dtype=dt, gradient=True, seed=0, tape_steps=T)
+    total = rollout_loss(env, actor, T, q0=q0, goal=goal, disturbances=dist)
+    named = [(n, p) for n, p in actor.named_parameters() if n != "logstd"]
+    ref = torch.autograd.grad(total, [p for _, p in named])
+    env2 = BatchedTactilePushEnv(pusher_model, B, dtype=dt, gradient=True, seed=0, tape_steps=T)
+    ep = FusedPushEpisode(env2, actor, T)
+    loss = ep.rollout(q0, goal, dist)
+    ep.backward()
+    assert abs(float(loss) - float(total)) < 1e-4 * abs(float(total))
+    for (n, p), r in zip(named, ref):
+        assert float((p.grad - r).norm()) <= 2e-3 * float(r.norm()), (n, float((p.grad - r).norm()) / float(r.norm()))
+    opt = torch.optim.Adam(actor.parameters(), lr=5e-3, betas=(0.7, 0.95))
+    losses = [float(train_epoch_fused(ep, opt, q0, goal, dist, B)) / B for _ in range(4)]
+    assert losses[-1] < losses[0], losses
