@@ -8,8 +8,9 @@ Simulation; here they are one batch per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
            examples/train_tactile_push_gd_batched.py --batch 4096 --epochs 20                      # 8 GPUs, RCCL over xGMI
 
-Per epoch and rank: one episode of `--batch` environments (policy -> env-step -> ... -> BPTT through the simulator),
-replayed from ONE HIP graph (`--eager` for the plain loop); the ranks exchange only the flat policy gradient (118 KB), once
+Per epoch and rank: one episode of `--batch` environments (policy -> env-step -> ... -> BPTT through the simulator) with the
+policy evaluated INSIDE the simulator's episode launches (one launch each way per episode, envs/push_closed_loop.py; `--graphed`: one launch
+per env-step replayed from ONE HIP graph, `--eager`: the plain loop); the ranks exchange only the flat policy gradient (118 KB), once
 per epoch.  Every epoch draws new goals / box offsets / disturbances per environment (envs/tactile_push_env.py:133-190) and
 writes them into the graph's static inputs.  The model path defaults to the compiled TactilePush model of the test fixtures;
 pass the reference's envs/assets/pusher/pusher.xml to compile it afresh.
@@ -27,6 +28,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv                      # noqa: E402
 from tactilesimulation_amd.algorithms.batched_gd import Actor, GraphedRollout, train_epoch, train_epoch_graphed   # noqa: E402
+from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode, train_epoch_fused          # noqa: E402
 
 
 def draw_episode(rng, B, T, device, dtype, period=1):
@@ -57,7 +59,8 @@ def main():
     ap.add_argument("--grad-clip", type=float, default=1.0)
     ap.add_argument("--log", default=None, help="write the loss curve (JSON) here")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per episode")
+    ap.add_argument("--eager", action="store_true", help="plain python loop, one launch per env-step")
+    ap.add_argument("--graphed", action="store_true", help="one launch per env-step, the episode replayed from one HIP graph (algorithms/batched_gd.GraphedRollout)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--disturbance-period", type=int, default=1, help="env-steps between new random forces on the box (the reference: 1, see draw_episode)")
     ap.add_argument("--save-best", default=None, help="torch.save the best policy (lowest loss, as algorithms/gd.py:187-189 keeps it) here")
@@ -78,7 +81,8 @@ def main():
     curve = []
     rng = np.random.default_rng(args.seed + 1000 * rank)
     q0, goal, dist_ = draw_episode(rng, B, T, dev, dtype, args.disturbance_period)
-    gr = None if args.eager else GraphedRollout(env, actor, T, q0, goal, dist_)
+    gr = GraphedRollout(env, actor, T, q0, goal, dist_) if args.graphed else None
+    ep = FusedPushEpisode(env, actor, T) if not (args.eager or args.graphed) else None
     best = (float("inf"), -1, None)
     prev_state = {k: v.detach().clone() for k, v in actor.state_dict().items()}
     for epoch in range(args.epochs):
@@ -88,7 +92,9 @@ def main():
         nq0, ngoal, ndist = draw_episode(rng, B, T, dev, dtype, args.disturbance_period)
         q0.copy_(nq0); goal.copy_(ngoal); dist_.copy_(ndist)       # static inputs of the graph
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        if gr is None:
+        if ep is not None:
+            loss = float(train_epoch_fused(ep, opt, q0, goal, dist_, B * world, grad_clip=args.grad_clip).detach()) / B
+        elif gr is None:
             loss = train_epoch(env, actor, opt, T, B * world, grad_clip=args.grad_clip, q0=q0, goal=goal, disturbances=dist_)
         else:
             loss = float(train_epoch_graphed(gr, opt, B * world, grad_clip=args.grad_clip).detach()) / B
