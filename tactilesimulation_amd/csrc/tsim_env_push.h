@@ -167,7 +167,7 @@ static int push_closed_rollout_t(tsim_batch* b, const tsim_push_policy* pol, con
   a.pol.u_out = (R*)u_out; a.pol.gl_out = (R*)gl_out; a.pol.h1_out = (R*)h1_out; a.pol.h2_out = (R*)h2_out;
   TS_LAUNCH_POLICY(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
-  b->order_valid = 0;
+  b->order_valid = 0; pose_invalidate(b, st);
   return 0;
 }
 

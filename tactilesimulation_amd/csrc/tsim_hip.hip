@@ -91,6 +91,7 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
 }
 
 // ================================================================================================ forward kernel
+enum { TP_R_SIZE = 18, TP_D_SIZE = 12 };      // pose record of a (sensor, primitive) combination: R part, double part (k_readout)
 template <class R> struct FwdArgs {
   const int* I; const R* F; const R* Fenv; int fstride;
   int B, nsub, record, t0;
@@ -105,6 +106,7 @@ template <class R> struct FwdArgs {
   int eval_budget;             // residual evaluations a sub-step may take before it is flagged and left (0: the XML's max_iter / max_ls only)
   float* gnorm;                // [B] largest ||g|| a sub-step of this launch ended with (diagnostics, tsim_last_gnorm)
   PushPolicy<R> pol;           // POLICY instantiations only (tsim_push_closed_rollout): the TactilePush policy between the frames
+  R* poseR = nullptr; double* poseD = nullptr; int nspt = 0;   // large pads: pose records of the final state for tsim_readout's k_taxels (see k_readout)
 };
 
 // -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
@@ -285,6 +287,26 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
                (a.tac_out && tslot >= 0) ? a.tac_out + (size_t)tslot * a.B * 3 * c.ntax : nullptr);
   TS_SYNC();
   }
+  if (a.poseR) {
+    // Large pads are read out on demand (tsim_readout), by a kernel whose lanes are taxels and which needs, per (sensor, primitive)
+    // combination, the pose of the sensor link in the primitive's frame and the relative twist there.  The link records in LDS are those
+    // of the state this launch ends in: leave the pose records here and the read-out needs no kinematics kernel of its own.
+    int k = 0;
+    for (int s = 0; s < c.nsensor; ++s) {
+      const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
+      const int nsp = ts_u(si[TSIM_SI_NSPRIM]), sp0 = ts_u(si[TSIM_SI_SPRIM0]);
+      for (int j = 0; j < nsp; ++j, ++k) {
+        TS_SYNC();
+        pair_stage_value(c, ts_u(c.I[c.off_sprim + sp0 + j]), 0, lane == 0);
+        TS_SYNC();
+        const size_t rec = (size_t)env * a.nspt + k;
+        if (valid) {
+          for (int e = lane; e < TP_R_SIZE; e += LPE) a.poseR[rec * TP_R_SIZE + e] = c.PP[e];
+          if (lane < TP_D_SIZE) a.poseD[rec * TP_D_SIZE + lane] = c.PPd[lane];
+        }
+      }
+    }
+  }
   if (valid) {
     if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1D[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = (double)c.qdm1[lane]; }
     if (!a.record) {
@@ -330,7 +352,6 @@ __global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* 
 //               the penalty law, 12 B out (the 9 axis constants only where a force acts).  ~40 registers instead of the 178 the
 //               kinematics need, so 8+ wavefronts per SIMD cover the L2 latency of the constants: this is the one kernel of the path
 //               whose time is memory traffic (RollingBall: 40 000 taxels, 480 KB per environment and read-out).
-enum { TP_R_SIZE = 18, TP_D_SIZE = 12 };
 template <class R> struct ReadArgs { const int* I; const R* F; const R* Fenv; int fstride; int B, t0; const R* tape; R* var_out; R* poseR; double* poseD; int nspt; int stage_cpt; };
 
 template <class R>
@@ -952,12 +973,21 @@ struct tsim_batch {
   int nsched;                    // ints of the sweep schedule appended to dI
   int stage_cpt;                 // the contact-point arrays are staged in LDS with the shared tables
   int n_simd;                    // SIMDs of the device (CUs x 4)
+  int pose_valid = 0;            // the pose records are those of the current state (left by the last forward launch)
+  int pose_off = 0;              // a launch of this batch was captured in a HIP graph: replays change the state behind the host's back, no reuse
   int tax_slots = 0;             // blocks of k_taxels the device holds at once (occupancy x CUs), queried on first use
   size_t esz;
   std::vector<CacheEntry> cache;   // saved tapes, newest last
   std::vector<void*> pool;          // spare tape buffers
   long long* bwd_stamps = nullptr;  // diagnostics (tsim_debug_stamps)
 };
+// The state changed other than by a forward launch (or is about to, in a captured graph): tsim_readout recomputes the kinematics.
+static void pose_invalidate(tsim_batch* b, hipStream_t st) {
+  b->pose_valid = 0;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) b->pose_off = 1;
+}
+
 
 // sweep schedule of the link tree (layout: ts_sched in tsim_device.h)
 static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
@@ -1137,6 +1167,15 @@ static LaunchShape launch_shape(const tsim_batch* b) {
     else TS_LAUNCH_L(KERNEL, R, 16, L, st, a);                                                                           \
   } while (0)
 
+// Pads too large for the in-kernel read-out (lanes of one environment over its taxels) are read on demand by tsim_readout; for those
+// the forward launch leaves the pose records of its final state (k_forward, end of the launch).  Not under stream capture: a graph
+// replay changes the state without the host seeing it, so a batch that was ever captured always recomputes the kinematics.
+enum { TS_POSE_EMIT_MIN_TAXELS = 4096 };
+static bool pose_emit(tsim_batch* b, hipStream_t st) {
+  pose_invalidate(b, st);
+  return !b->pose_off && b->nspt > 0 && b->poseR && b->ntax >= TS_POSE_EMIT_MIN_TAXELS;
+}
+
 template <class R>
 static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32_t* tac_slot, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
   FwdArgs<R> a;
@@ -1145,8 +1184,11 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
   a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm;
+  const bool emit = pose_emit(b, st);
+  if (emit) { a.poseR = (R*)b->poseR; a.poseD = b->poseD; a.nspt = b->nspt; }
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
+  b->pose_valid = emit ? 1 : 0;
   if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
   else if (b->B >= 256) {
     const int ns = TS_WAVE / launch_shape(b).lpe;
@@ -1288,6 +1330,7 @@ int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* st
   if (I[TSIM_IH_NI] != (int)b->I.size() || I[TSIM_IH_NF] != (int)b->F.size()) return fail("update_model: blob size changed");
   for (int i = 0; i < TSIM_IH_SIZE; ++i) if (I[i] != b->I[i]) return fail("update_model: topology changed");
   TS_DEVICE(b);
+  pose_invalidate(b, (hipStream_t)stream);
   b->I.assign(I, I + I[TSIM_IH_NI]); b->F.assign(F, F + I[TSIM_IH_NF]);
   if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; }     // per-environment tables refer to the old model
   return upload_model(b, (hipStream_t)stream);
@@ -1295,6 +1338,7 @@ int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* st
 
 int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream) {
   TS_DEVICE(b);
+  pose_invalidate(b, (hipStream_t)stream);
   if (!tables) { if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; } return 0; }
   size_t bytes = (size_t)b->B * b->nfrec * b->esz;
   if (!b->dFenv) HIPCHK(hipMalloc(&b->dFenv, bytes));
@@ -1313,6 +1357,7 @@ int tsim_reset(tsim_batch* b, const void* q0, const void* qd0, int backward_flag
   HIPCHK(hipGetLastError());
   if (zero_async(b->lamq, (size_t)2 * b->B * b->nr * b->esz, st) || zero_async(b->lamv, (size_t)2 * b->B * b->nr * b->esz, st)) return 1;
   b->t_cur = 0; b->record = backward_flag ? 1 : 0; b->order_valid = 0; b->has_prev = 0;
+  pose_invalidate(b, st);
   return 0;
 }
 
@@ -1321,6 +1366,7 @@ int tsim_reset_masked(tsim_batch* b, const void* q0, const void* qd0, const int3
   if (b->record) return fail("reset_masked: not while recording (the tape is shared by the batch): use reset");
   TS_DEVICE(b);
   hipStream_t st = (hipStream_t)stream;
+  pose_invalidate(b, st);
   int n = b->B * b->nr, blk = 256, grd = (n + blk - 1) / blk;
   size_t off = (size_t)b->t_cur * b->B * b->rec;
   // BDF2 models: the environment restarts with a constant-velocity history (q_-1 = q0 - h qd0, qd_-1 = qd0) [CHOICE]
@@ -1378,16 +1424,21 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
     slice = ((b->ntax + per_env - 1) / per_env + 255) / 256 * 256;
   }
   const dim3 tgrid(b->B, tac ? (b->ntax + slice - 1) / slice : 1);
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { b->pose_off = 1; b->pose_valid = 0; }
+  }
+  const bool fk = var_out || !tac || !b->pose_valid;      // the forward launch left the pose records of this state: k_taxels alone
   if (b->dtype == TSIM_F32) {
     ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, tac ? (float*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
-    hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
+    if (fk) hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
     if (tac) {
       TaxArgs<float> t{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, (const float*)b->poseR, b->poseD, b->nspt, (float*)tac_out, slice};
       hipLaunchKernelGGL(k_taxels<float>, tgrid, dim3(256), 0, st, t);
     }
   } else {
     ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, tac ? (double*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
-    hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
+    if (fk) hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
     if (tac) {
       TaxArgs<double> t{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, (const double*)b->poseR, b->poseD, b->nspt, (double*)tac_out, slice};
       hipLaunchKernelGGL(k_taxels<double>, tgrid, dim3(256), 0, st, t);
@@ -1478,6 +1529,7 @@ int tsim_cache_pop(tsim_batch* b, void* stream) {
   b->pool.push_back(b->tape);                 // stream order keeps earlier kernels on the old buffer safe: it is only
   b->tape = e.buf;                            // handed out again by a later save on the same stream
   b->t_cur = e.len; b->record = e.record; b->has_prev = 0; b->order_valid = 0;
+  pose_invalidate(b, (hipStream_t)stream);
   if (zero_async(b->lamq, (size_t)2 * b->B * b->nr * b->esz, (hipStream_t)stream) || zero_async(b->lamv, (size_t)2 * b->B * b->nr * b->esz, (hipStream_t)stream)) return 1;
   return 0;
 }

@@ -1,7 +1,7 @@
 # usage: tools/isa_stats.sh <lib.so> [kernel-mangled-substring]   — extract the gfx950 code object, print registers / spills and the
 # static instruction mix of one kernel (default: k_forward<float, 8, false, 16>)
 set -e
-SO=$(readlink -f $1); K=${2:-_Z9k_forwardIfLi8ELb0ELi16EEv7FwdArgsIT_E}
+SO=$(readlink -f $1); K=${2:-_Z9k_forwardIfLi8ELb0ELi16ELb0EEv7FwdArgsIT_E}
 W=$(mktemp -d); cd $W
 /opt/rocm/lib/llvm/bin/llvm-objdump --offloading $SO >/dev/null 2>&1 || true
 CO=$(ls $(dirname $SO)/$(basename $SO).0.hipv4-amdgcn* 2>/dev/null || ls *hipv4-amdgcn*)
