@@ -18,8 +18,10 @@ Prints ONE JSON line (rank 0).  Besides the contract's fields:
                 `valu`: what actually bounds the path (instruction issue of one wavefront per SIMD), from hardware counters
                 collected IN THIS RUN by short `rocprofv3 --pmc` passes of this same script (separate passes, counters only);
                 `traffic` = 2 * FETCH_SIZE + WRITE_SIZE of those passes (gfx950 correction of MI355X_MICROARCH.md §HBM)
-  closed_loop   BASELINE config 3 as cfg/gd_tactile.yaml runs it: policy between env-steps, BPTT, all-reduce, clip, Adam —
-                one HIP graph replay per episode (algorithms/batched_gd.GraphedRollout), timed here, not by a side script
+  closed_loop   BASELINE config 3 as cfg/gd_tactile.yaml runs it: policy between env-steps, BPTT, all-reduce, clip, Adam — the
+                policy evaluated inside the simulator's episode launches (envs/push_closed_loop.FusedPushEpisode), timed here, not by
+                a side script; closed_loop_per_step_graph: the same epoch as one launch per env-step replayed from one HIP graph
+                (algorithms/batched_gd.GraphedRollout: any torch policy)
   readout_hbm   the one HBM-relevant kernel of this path: 200 x 200-taxel read-out of RollingBall, GB/s
   cpu_baseline  the fp64 CPU oracle (this build's restatement, NOT DiffRedMax), built -O3 -march=native on this host,
                 one instance per usable core
@@ -498,14 +500,14 @@ def main():
                 if "f64" in res and "value" in res["f64"]:
                     res["f64_value"] = res["f64"]["value"]
             if args.workload == "push" and not args.no_closed_loop and not forward_only:
-                try:
-                    res["closed_loop"] = closed_loop_leg(model, B, T, tdt, dev)
+                try:                            # the path examples/train_tactile_push_gd_batched.py runs by default
+                    res["closed_loop"] = closed_loop_fused_leg(model, B, T, tdt, dev)
                 except Exception as e:      # the headline must not die with an optional leg
                     res["closed_loop"] = {"error": repr(e)}
                 try:
-                    res["closed_loop_fused"] = closed_loop_fused_leg(model, B, T, tdt, dev)
+                    res["closed_loop_per_step_graph"] = closed_loop_leg(model, B, T, tdt, dev)
                 except Exception as e:
-                    res["closed_loop_fused"] = {"error": repr(e)}
+                    res["closed_loop_per_step_graph"] = {"error": repr(e)}
                 progress("closed loop done")
             try:
                 res["readout_hbm"] = readout_leg(tdt, dev)

@@ -419,6 +419,17 @@ template <class C> __device__ __forceinline__ const int* ts_motor_rec(const C& c
 // primitive) record, number of records), then per record 2 ints (primitive type, contact pair)
 __device__ __forceinline__ const int* ts_tax_table(const int* S) { return S + S[TS_SCHED_TAXTAB]; }
 
+// A wavefront is about to read global memory it (or a wavefront of its CU) stored to earlier in the launch: wait until the stores
+// have reached L2 (s_waitcnt vmcnt(0): one CU, one XCD, one L2), then drop the vector L1's lines (buffer_inv sc1) — the L1 keeps a
+// line it fetched before the store.  __threadfence() does that too, but releases at device scope first: `buffer_wbl2 sc1`, a write-back
+// of the XCD's L2 for the benefit of the other XCDs, which nobody here needs (1.5 % of the closed-loop epoch;
+// profiles/r03_closed_loop_policy.md).
+__device__ __forceinline__ void ts_own_stores_visible() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
 template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, bool stage_cpt, const R* Fenv = nullptr) {

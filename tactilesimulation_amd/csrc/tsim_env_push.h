@@ -141,6 +141,7 @@ static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, i
   if (!b || !pol) return fail(std::string(who) + ": null batch / policy");
   if (b->nr != 7 || b->nu != 6 || 3 * b->ntax != PP_NTAC || b->nvar != 2 || b->has_exp) return fail(std::string(who) + ": not the TactilePush model (ndof_r 7, ndof_u 6, 130 taxels, 2 end-effector points)");
   if (num_frames <= 0 || num_steps <= 0) return fail(std::string(who) + ": num_frames and num_steps must be positive");
+  if (TS_PAIR_GROUP * ((int)PP_SIZE + b->nr * (int)PT_SIZE) < 64 * (int)PP_OCH + 2 * (int)PP_HID) return fail(std::string(who) + ": the pair-staging records are too small for the policy scratch");
   if (!pol->W1T || !pol->b1 || !pol->W2T || !pol->b2 || !pol->W3 || !pol->b3) return fail(std::string(who) + ": policy weights missing");
   if (b->dFenv) return fail(std::string(who) + ": per-environment tables are not supported in the closed-loop launch");
   return 0;

@@ -156,16 +156,25 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   TS_SYNC();
   // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
   // environment of the batch between env-steps: Newton stragglers average out over the episode.
+#ifdef TS_PP_TIME      // A/B builds only: share of the launch spent in the policy call, left in gnorm (tools/closed_loop_breakdown.py)
+  long long pp_cycles_ = 0; const long long pp_t0_ = clock64();
+#endif
   for (int f = 0; f < a.nframes; ++f) {
   {
     R uv = R(0);
     if (POLICY) {
       // closed loop: the action comes from the policy, evaluated by this slot on the observation the previous frame left
       // (tsim_policy_push.h).  The tactile frame was written by this slot: make the stores visible to its own loads first.
-      __threadfence();
+      ts_own_stores_visible();
       const R* tprev = f == 0 ? a.pol.tac0 + (size_t)env * PP_NTAC : a.tac_out + ((size_t)(f - 1) * a.B + env) * PP_NTAC;
+#ifdef TS_PP_TIME
+      const long long tp0_ = clock64();
+#endif
       push_policy_forward<LPE>(c, lane, valid, a.pol, (size_t)f * a.B + env, env, tprev);
       TS_SYNC();
+#ifdef TS_PP_TIME
+      pp_cycles_ += clock64() - tp0_;
+#endif
       if (lane < nu) uv = c.u[lane];
     } else
     if (lane < nu) { uv = a.u[((size_t)f * a.B + env) * nu + lane]; c.u[lane] = uv; }
@@ -316,6 +325,9 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
     if (a.evals && lane == 0) a.evals[env] = evals;
     if (a.gnorm && lane == 0) a.gnorm[env] = (float)gmax;
+#ifdef TS_PP_TIME
+    if (a.gnorm && lane == 0) a.gnorm[env] = (float)((double)pp_cycles_ / (double)(clock64() - pp_t0_));
+#endif
   }
 }
 
@@ -922,7 +934,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
         const int fr0 = j / a.seed_stride;
         pol_dq = push_policy_backward<LPE>(c, lane, valid, a.pol, (size_t)fr0 * a.B + env, env, du_frame, (double)c.q0[0]);
         pol_have = true;
-        __threadfence();                                   // dobs_tac is read back by this slot as the previous frame's tactile seed
+        ts_own_stores_visible();                           // dobs_tac is read back by this slot as the previous frame's tactile seed
       }
       du_frame = R(0);
     }

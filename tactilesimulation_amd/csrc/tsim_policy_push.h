@@ -7,10 +7,13 @@
 // environment run in ITS slot of the wavefront between two frames of k_forward, and their reverse between two frames of k_backward:
 // the closed loop becomes one launch per episode each way, and an environment never waits for another wavefront.
 //
-// Lanes of a slot = hidden units (64 / LPE per lane); inputs are broadcast (the observation row straight from HBM / L2 — the tactile
-// frame was written by this very slot a moment ago — the hidden vectors through the slot's idle pair-staging scratch in LDS); weights
-// stream from L2 in the layouts that make a slot's read contiguous:  W1T [393][64], W2T [64][64], W3 [3][64] forward;
-// W1p [64][W1S >= 393, padded to a multiple of 4], W2 [64][64] backward.  The per-layer (input, output-gradient) pairs go to HBM; the weight
+// The dense layers run WAVE-wide: lane j of the wavefront = output unit j, for all the wavefront's environments at once.  A weight row
+// is one coalesced 256-byte load per wavefront (one dword per lane), the inputs of the 1 / 2 / 4 environments are LDS broadcasts from the
+// slots' idle tangent / pair-staging records, and a lane accumulates one output per environment.  What a lone wavefront pays for here is
+// L2 latency — (rows / loads in flight) round trips — so the rows go 32 - 40 at a time, which a one-register row allows (the first version
+// gave every slot its own 16-byte weight loads: 4 registers per row, 8 rows in flight, the same row fetched once per slot: 70 us per
+// env-step forward, a fifth of the episode; profiles/r03_closed_loop_policy.md).  Layouts: W1T [393][64], W2T [64][64], W3 [3][64]
+// forward; W1p [64][W1S >= 393, padded to a multiple of 4], W2 [64][64] backward.  The per-layer (input, output-gradient) pairs go to HBM; the weight
 // gradients are batched GEMMs over the whole episode afterwards (as in algorithms/batched_gd.py).
 #pragma once
 #include "tsim_device.h"
@@ -41,13 +44,49 @@ template <int OPL, class R> __device__ __forceinline__ void pp_ld(const R* p, R*
   for (int o = 0; o < OPL; ++o) out[o] = p[o];
 }
 
+
+enum { PP_OBS_PAD = 400, PP_ROWS1 = 40, PP_ROWS2 = 32, PP_JB = 8, PP_OCH = (PP_OBS + 63) / 64 };
+// LDS scratch of the policy, per slot: the pair-staging records PP + PT (4 x 36 + 4 nd x 18 = 648 reals on the TactilePush model), idle
+// between two frames and rewritten whole by every staging: xs = the first 448 reals, hs = the next 128.  (NOT the link tangent records:
+// their entries for directions that do not move a link are zero from the start of the launch and never rewritten.)  x0 / h0 = slot 0's
+// copy, slots are `stride` reals apart.
+template <int LPE, class R> struct PPScr { R* xs; R* hs; R* xs0; R* hs0; int stride; };
+template <int LPE, class R> __device__ __forceinline__ PPScr<LPE, R> pp_scr(const Ctx<R>& c) {
+  PPScr<LPE, R> S;
+  S.stride = ts_lds_env_reals(c.nl, c.nr, c.nu, (int)sizeof(R));
+  const int slot = (int)threadIdx.x / LPE;
+  S.xs = c.PP; S.hs = c.PP + 64 * PP_OCH; S.xs0 = S.xs - slot * S.stride; S.hs0 = S.hs - slot * S.stride;
+  return S;
+}
+// acc[s] += sum_{i < nrows} W[min(i, wrows - 1)][j] * x_s[i]   (j = lane of the wavefront; x_s = x0 + s * stride in LDS; nrows a multiple
+// of ROWS — rows past wrows meet zero inputs)
+template <int NS, int ROWS, class R>
+__device__ __forceinline__ void pp_dense64(const R* W, int nrows, int wrows, const R* x0, int stride, R (&acc)[NS]) {
+  const R* Wj = W + threadIdx.x;
+#ifdef TS_PP_SKIP_DENSE      // A/B builds only: what the weight streams cost (results are wrong)
+  nrows = 0;
+#endif
+  for (int i0 = 0; i0 < nrows; i0 += ROWS) {
+    R wb[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wb[r] = Wj[(size_t)min(i0 + r, wrows - 1) * PP_HID];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] += wb[r] * x0[s * stride + i0 + r];
+  }
+}
+
 // Observation -> action for the environment of this slot.  tac_prev: the tactile frame the observation is built from (global; written by
 // this slot, hence the fence + bypassing loads).  q (double, the state before the frame) gives the goal in the gripper frame.
 // Writes c.u (the 6 actuator inputs of the frame) and the forward records.
 template <int LPE, class R>
 __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, bool valid, const PushPolicy<R>& P, size_t rec /* f * B + env */, int env, const R* tac_prev) {
   constexpr int OPL = PP_HID / LPE;                    // hidden units per lane
-  R* scr = c.PT;                                       // >= 128 reals of idle pair-staging scratch per slot
+#ifdef TS_PP_SKIP_ALL        // A/B builds only: what the whole policy call costs (results are wrong)
+  if (lane < 6) c.u[lane] = (lane >= 3 && lane < 5) ? P.dist[rec * 2 + (lane - 3)] : R(0);
+  return;
+#endif
   // goal pose in the gripper frame: rotation by -yaw, then the gripper's position is subtracted (tactile_push_env.py:84-92)
   R gl[3];
   {
@@ -56,40 +95,47 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
     const double gx = g[0], gy = g[1];
     gl[0] = (R)(cs * gx + sn * gy - c.q0D[1]); gl[1] = (R)(-sn * gx + cs * gy - c.q0D[2]); gl[2] = (R)((double)g[2] - c.q0D[0]);
   }
-  R acc[OPL], w[OPL];
-  pp_ld<OPL>(P.b1 + OPL * lane, acc);
+  constexpr int NS = TS_WAVE / LPE;
+  const PPScr<LPE, R> S = pp_scr<LPE>(c);
+  // the observation of this slot into LDS: goal (3), the tactile frame (390; every lane fetches its share in one batch of loads), zeros
+  {
+    constexpr int NX = (PP_OBS_PAD - 3 + LPE - 1) / LPE;
+    R xv[NX];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    pp_ld<OPL>(P.W1T + (size_t)i * PP_HID + OPL * lane, w);
+    for (int m = 0; m < NX; ++m) { const int i = lane + LPE * m; xv[m] = i < PP_NTAC ? __builtin_nontemporal_load(tac_prev + i) : R(0); }
+    if (lane < 3) S.xs[lane] = lane == 0 ? gl[0] : (lane == 1 ? gl[1] : gl[2]);
 #pragma unroll
-    for (int o = 0; o < OPL; ++o) acc[o] += w[o] * gl[i];
+    for (int m = 0; m < NX; ++m) { const int i = lane + LPE * m; if (3 + i < PP_OBS_PAD) S.xs[3 + i] = xv[m]; }
   }
-#pragma unroll 8
-  for (int i = 0; i < PP_NTAC; ++i) {
-    const R x = __builtin_nontemporal_load(tac_prev + i);          // slot-uniform address: one transaction per slot
-    pp_ld<OPL>(P.W1T + (size_t)(3 + i) * PP_HID + OPL * lane, w);
+  TS_SYNC();
+  R acc[NS], w[OPL];
+  {
+    const R bj = P.b1[threadIdx.x];
 #pragma unroll
-    for (int o = 0; o < OPL; ++o) acc[o] += w[o] * x;
+    for (int s_ = 0; s_ < NS; ++s_) acc[s_] = bj;
   }
+  pp_dense64<NS, PP_ROWS1>(P.W1T, PP_OBS_PAD, PP_OBS, S.xs0, S.stride, acc);
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + threadIdx.x] = pp_elu(acc[s_]);
+  TS_SYNC();
   R h1[OPL];
-#pragma unroll
-  for (int o = 0; o < OPL; ++o) { h1[o] = pp_elu(acc[o]); scr[OPL * lane + o] = h1[o]; }
+  pp_ld<OPL>(S.hs + OPL * lane, h1);
   if (valid) {
 #pragma unroll
     for (int o = 0; o < OPL; ++o) P.h1_out[rec * PP_HID + OPL * lane + o] = h1[o];
   }
-  TS_SYNC();
-  pp_ld<OPL>(P.b2 + OPL * lane, acc);
-#pragma unroll 8
-  for (int i = 0; i < PP_HID; ++i) {
-    const R x = scr[i];
-    pp_ld<OPL>(P.W2T + (size_t)i * PP_HID + OPL * lane, w);
+  {
+    const R bj = P.b2[threadIdx.x];
 #pragma unroll
-    for (int o = 0; o < OPL; ++o) acc[o] += w[o] * x;
+    for (int s_ = 0; s_ < NS; ++s_) acc[s_] = bj;
   }
-  R h2[OPL];
+  pp_dense64<NS, PP_ROWS2>(P.W2T, PP_HID, PP_HID, S.hs0, S.stride, acc);
+  TS_SYNC();
 #pragma unroll
-  for (int o = 0; o < OPL; ++o) h2[o] = pp_elu(acc[o]);
+  for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + PP_HID + threadIdx.x] = pp_elu(acc[s_]);
+  TS_SYNC();
+  R h2[OPL];
+  pp_ld<OPL>(S.hs + PP_HID + OPL * lane, h2);
   if (valid) {
 #pragma unroll
     for (int o = 0; o < OPL; ++o) P.h2_out[rec * PP_HID + OPL * lane + o] = h2[o];
@@ -123,7 +169,8 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
 template <int LPE, class R>
 __device__ __forceinline__ R push_policy_backward(const Ctx<R>& c, int lane, bool valid, const PushPolicy<R>& P, size_t rec, int env, R da, double yaw) {
   constexpr int OPL = PP_HID / LPE;
-  R* scr = c.PT;
+  constexpr int NS = TS_WAVE / LPE;
+  const PPScr<LPE, R> S = pp_scr<LPE>(c);
   R g3[3];
 #pragma unroll
   for (int a_ = 0; a_ < 3; ++a_) {
@@ -142,64 +189,69 @@ __device__ __forceinline__ R push_policy_backward(const Ctx<R>& c, int lane, boo
     for (int o = 0; o < OPL; ++o) g2[o] += w[o] * g3[a_];
   }
 #pragma unroll
-  for (int o = 0; o < OPL; ++o) { g2[o] *= pp_elu_grad_from_output(h[o]); scr[OPL * lane + o] = g2[o]; }
+  for (int o = 0; o < OPL; ++o) { g2[o] *= pp_elu_grad_from_output(h[o]); S.hs[OPL * lane + o] = g2[o]; }
   if (valid) {
 #pragma unroll
     for (int o = 0; o < OPL; ++o) P.g2_out[rec * PP_HID + OPL * lane + o] = g2[o];
   }
   TS_SYNC();
   R g1[OPL];
+  {                                                    // dh1_s[o] = sum_j W2[j][o] g2_s[j], wave-wide (o = lane of the wavefront)
+    R a2[NS];
 #pragma unroll
-  for (int o = 0; o < OPL; ++o) g1[o] = R(0);
-#pragma unroll 8
-  for (int j = 0; j < PP_HID; ++j) {                   // dh1[o] = sum_j W2[j][o] g2[j]
-    const R x = scr[j];
-    pp_ld<OPL>(P.W2 + (size_t)j * PP_HID + OPL * lane, w);
+    for (int s_ = 0; s_ < NS; ++s_) a2[s_] = R(0);
+    pp_dense64<NS, PP_ROWS2>(P.W2, PP_HID, PP_HID, S.hs0, S.stride, a2);
+    TS_SYNC();
 #pragma unroll
-    for (int o = 0; o < OPL; ++o) g1[o] += w[o] * x;
+    for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + PP_HID + threadIdx.x] = a2[s_];
+    TS_SYNC();
+    pp_ld<OPL>(S.hs + PP_HID + OPL * lane, g1);
   }
   pp_ld<OPL>(P.h1_out + rec * PP_HID + OPL * lane, h);
   TS_SYNC();
 #pragma unroll
-  for (int o = 0; o < OPL; ++o) { g1[o] *= pp_elu_grad_from_output(h[o]); scr[PP_HID + OPL * lane + o] = g1[o]; }
+  for (int o = 0; o < OPL; ++o) { g1[o] *= pp_elu_grad_from_output(h[o]); S.hs[PP_HID + OPL * lane + o] = g1[o]; }
   if (valid) {
 #pragma unroll
     for (int o = 0; o < OPL; ++o) P.g1_out[rec * PP_HID + OPL * lane + o] = g1[o];
   }
   TS_SYNC();
-  // d obs[i] = sum_j W1[j][i] g1[j]: a lane owns the 4-element chunks i = 4 (lane + LPE m) .. + 3
-  constexpr int NCH = (PP_OBS + 4 * LPE - 1) / (4 * LPE);
-  R dob[NCH][4];
+  // d obs_s[i] = sum_j W1[j][i] g1_s[j], wave-wide: lane l of the wavefront owns i = l + 64 m
+  {
+    R dob[PP_OCH][NS];
 #pragma unroll
-  for (int m = 0; m < NCH; ++m)
+    for (int m = 0; m < PP_OCH; ++m)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dob[m][e] = R(0);
-#pragma unroll 2
-  for (int j = 0; j < PP_HID; ++j) {
-    const R x = scr[PP_HID + j];
+      for (int s_ = 0; s_ < NS; ++s_) dob[m][s_] = R(0);
+    const R* g0 = S.hs0 + PP_HID;
+    for (int j0 = 0; j0 < PP_HID; j0 += PP_JB) {
+      R wb[PP_JB][PP_OCH];
 #pragma unroll
-    for (int m = 0; m < NCH; ++m) {
-      const int i0 = 4 * (lane + LPE * m);
-      if (i0 < P.w1s) {
-        const R* wp = P.W1p + (size_t)j * P.w1s + i0;
+      for (int r = 0; r < PP_JB; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dob[m][e] += wp[e] * x;
-      }
+        for (int m = 0; m < PP_OCH; ++m) wb[r][m] = P.W1p[(size_t)(j0 + r) * P.w1s + min((int)threadIdx.x + 64 * m, P.w1s - 1)];
+#pragma unroll
+      for (int r = 0; r < PP_JB; ++r)
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+          const R x = g0[s_ * S.stride + j0 + r];
+#pragma unroll
+          for (int m = 0; m < PP_OCH; ++m) dob[m][s_] += wb[r][m] * x;
+        }
     }
+    TS_SYNC();
+#pragma unroll
+    for (int m = 0; m < PP_OCH; ++m)
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) S.xs0[s_ * S.stride + (int)threadIdx.x + 64 * m] = dob[m][s_];
+    TS_SYNC();
   }
+  // tactile part -> the seed of the previous frame's tactile read-out (consecutive lanes, consecutive addresses); goal part -> q[0..2]
+  if (valid) {
+    for (int i = lane; i < PP_NTAC; i += LPE) P.dobs_tac[rec * PP_NTAC + i] = S.xs[3 + i];
+  }
+  const R d0 = S.xs[0], d1 = S.xs[1], d2 = S.xs[2];
   TS_SYNC();
-  // tactile part -> the seed of the previous frame's tactile read-out; goal part -> q[0..2] of the state before the frame
-#pragma unroll
-  for (int m = 0; m < NCH; ++m) {
-    const int i0 = 4 * (lane + LPE * m);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = i0 + e;
-      if (valid && i >= 3 && i < PP_OBS) P.dobs_tac[rec * PP_NTAC + (i - 3)] = dob[m][e];
-    }
-  }
-  // lane 0 holds d obs[0..2] in its first chunk
-  const R d0 = seg_bcast<LPE>(dob[0][0], 0), d1 = seg_bcast<LPE>(dob[0][1], 0), d2 = seg_bcast<LPE>(dob[0][2], 0);
   double sn, cs; t_sincos_d(yaw, sn, cs);
   const R* g = P.goal + (size_t)env * 3;
   const double gx = g[0], gy = g[1];
