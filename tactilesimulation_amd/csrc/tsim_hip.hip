@@ -394,7 +394,10 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
   }
 }
 
-template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int fstride; const R* poseR; const double* poseD; int nspt; R* tac_out; int slice; };
+template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int fstride; const R* poseR; const double* poseD; int nspt; R* tac_out; int slice;
+  // model constants the host knows (header entries and the offset of the staging table): as kernel arguments they cost the prologue no
+  // dependent global loads (header -> table offset -> table -> record was four L2 round trips per block, ~2 us of a 28 us kernel)
+  int ntax, nsensor, foff_sensor, foff_pair, foff_taxel, tt_off; };
 
 // Per-block staging of everything k_taxels needs that does not depend on the taxel: the block works on ONE environment, so the sensor
 // ranges, the primitive of every (sensor, primitive) record with its shape, the sensors' penalty parameters and the pose records are
@@ -412,14 +415,14 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
   const int env = blockIdx.x;
   const int* I = a.I;
   const R* F = a.Fenv ? a.Fenv + (size_t)env * a.fstride : a.F;        // this environment's float records (domain randomisation)
-  const int ntax = I[TSIM_IH_NTAXEL], nsensor = I[TSIM_IH_NSENSOR];
+  const int ntax = a.ntax, nsensor = a.nsensor;
   __shared__ int sEnd[TX_MAXS], sKb[TX_MAXS], sNsp[TX_MAXS], sPrim[TX_MAXK];
   __shared__ R sSf[TX_MAXS * TSIM_SF_SIZE], sShape[TX_MAXK * 4], sP[TX_MAXK * TP_R_SIZE];
   __shared__ double sD[TX_MAXK * TP_D_SIZE];
   __shared__ __attribute__((aligned(16))) R sC[TX_MAXK * 4];          // per record: the primitive's centre in the sensor-link frame, (bounding radius + margin)^2
   {
-    const int* TT = ts_tax_table(I + I[TSIM_IH_NI]);
-    const int foff_sensor = I[TSIM_IH_FOFF_SENSOR], foff_pair = I[TSIM_IH_FOFF_PAIR];
+    const int* TT = I + a.tt_off;
+    const int foff_sensor = a.foff_sensor, foff_pair = a.foff_pair;
     for (int i = threadIdx.x; i < nsensor; i += 256) { sEnd[i] = TT[3 * i]; sKb[i] = TT[3 * i + 1]; sNsp[i] = TT[3 * i + 2]; }
     for (int i = threadIdx.x; i < a.nspt; i += 256) sPrim[i] = TT[3 * nsensor + 2 * i];
     for (int i = threadIdx.x; i < a.nspt * 4; i += 256) sShape[i] = F[foff_pair + TT[3 * nsensor + 2 * (i >> 2) + 1] * TSIM_PF_SIZE + TSIM_PF_SHAPE + (i & 3)];
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
     }
     __syncthreads();
   }
-  const R* tax = a.F + I[TSIM_IH_FOFF_TAXEL];                          // SoA planes: position (3), axis0, axis1, normal (9); shared
+  const R* tax = a.F + a.foff_taxel;                          // SoA planes: position (3), axis0, axis1, normal (9); shared
   R* out = a.tac_out + (size_t)env * 3 * ntax;
   const int te = min(ntax, ((int)blockIdx.y + 1) * a.slice);
   // One taxel: its three outputs go out as ONE 12-byte (fp64: 24-byte) store per lane — consecutive lanes, consecutive addresses: a
@@ -494,7 +497,10 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
     // Without the list a wavefront runs the ~1000-instruction law whenever ONE of its 64 taxels is near the primitive — 15 % of the
     // wavefronts of the RollingBall pad for 5 % of its taxels, and that was the kernel's time (12.4 M vector instructions for
     // 10.2 M taxels; profiles/r03_readout_ab.md).  A taxel's result does not depend on the lane that computes it: same bits as before.
-    enum { CH = 4 };
+#ifndef TS_TAX_CH
+#define TS_TAX_CH 8
+#endif
+    enum { CH = TS_TAX_CH };
     __shared__ int sList[256 * CH];
     __shared__ int sCount;
     const V3<R> cA = ldv(sC);
@@ -987,6 +993,7 @@ struct tsim_batch {
   int n_simd;                    // SIMDs of the device (CUs x 4)
   int pose_valid = 0;            // the pose records are those of the current state (left by the last forward launch)
   int pose_off = 0;              // a launch of this batch was captured in a HIP graph: replays change the state behind the host's back, no reuse
+  int tt_off = 0;                // offset of the taxel staging table in the device int blob (I[NI] + S[TS_SCHED_TAXTAB])
   int tax_slots = 0;             // blocks of k_taxels the device holds at once (occupancy x CUs), queried on first use
   size_t esz;
   std::vector<CacheEntry> cache;   // saved tapes, newest last
@@ -1071,6 +1078,7 @@ static int upload_model(tsim_batch* b, hipStream_t st) {
   {
     std::vector<int32_t> S = build_sched(b->I);              // appended to the device copy at I[TSIM_IH_NI]
     if ((int)S.size() != b->nsched) return fail("sweep schedule size changed");
+    b->tt_off = b->I[TSIM_IH_NI] + S[TS_SCHED_TAXTAB];
     HIPCHK(hipMemcpyAsync(b->dI + b->I.size(), S.data(), S.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -1254,7 +1262,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->t_cur = 0; b->record = 0; b->has_exp = n_exp > 0;
   b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT];
   b->lpe_forced = 0;
-  b->nsched = (int)build_sched(b->I).size();
+  { const std::vector<int32_t> S_ = build_sched(b->I); b->nsched = (int)S_.size(); b->tt_off = b->I[TSIM_IH_NI] + S_[TS_SCHED_TAXTAB]; }
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
   b->cross_kinks = dtype == TSIM_F32 ? 1 : 0;
   {
@@ -1445,14 +1453,16 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
     ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, tac ? (float*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
     if (fk) hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
     if (tac) {
-      TaxArgs<float> t{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, (const float*)b->poseR, b->poseD, b->nspt, (float*)tac_out, slice};
+      TaxArgs<float> t{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, (const float*)b->poseR, b->poseD, b->nspt, (float*)tac_out, slice,
+                       b->ntax, b->I[TSIM_IH_NSENSOR], b->I[TSIM_IH_FOFF_SENSOR], b->I[TSIM_IH_FOFF_PAIR], b->I[TSIM_IH_FOFF_TAXEL], b->tt_off};
       hipLaunchKernelGGL(k_taxels<float>, tgrid, dim3(256), 0, st, t);
     }
   } else {
     ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, tac ? (double*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
     if (fk) hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
     if (tac) {
-      TaxArgs<double> t{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, (const double*)b->poseR, b->poseD, b->nspt, (double*)tac_out, slice};
+      TaxArgs<double> t{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, (const double*)b->poseR, b->poseD, b->nspt, (double*)tac_out, slice,
+                        b->ntax, b->I[TSIM_IH_NSENSOR], b->I[TSIM_IH_FOFF_SENSOR], b->I[TSIM_IH_FOFF_PAIR], b->I[TSIM_IH_FOFF_TAXEL], b->tt_off};
       hipLaunchKernelGGL(k_taxels<double>, tgrid, dim3(256), 0, st, t);
     }
   }
