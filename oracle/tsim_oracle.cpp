@@ -487,7 +487,6 @@ static void eval_g_c(const Model& m, const double* q1, const StepCoef& c, const 
 // which: 0 = d/dq1, 1 = d/dq0, 2 = d/dqd0, 3 = d/du, 4 = d/dq_1, 5 = d/dqd_1 (BDF2 history) — q1 held fixed for 1, 2, 4, 5 ;  J[row*ncol+col]
 static void eval_g_jac_c(const Model& m, const double* q1, const StepCoef& c, const double* u, int which, double* g, double* J) {
   int nr = m.nr, ncol = which == 3 ? m.nu : nr;
-  double h = m.h;
   for (int c0 = 0; c0 < ncol; c0 += NDMAX) {
     int nd = std::min(NDMAX, ncol - c0);
     g_nd = nd;
@@ -570,7 +569,7 @@ static int substep_literal(Sim& S, const double* u, const StepCoef& c, double* q
 // one implicit sub-step (BDF1, or BDF2 once a previous state exists); returns Newton iterations used, negative if not converged
 static int substep(Sim& S, const double* u) {
   const Model& m = S.m; int nr = m.nr; double h = m.h;
-  double q0[MAXR], qd0[MAXR], q1[MAXR], g[MAXR], H[MAXR * MAXR], dq[MAXR], qn[MAXR], gn[MAXR];
+  double q0[MAXR] = {0}, qd0[MAXR] = {0}, q1[MAXR], g[MAXR], H[MAXR * MAXR], dq[MAXR], qn[MAXR], gn[MAXR];
   for (int k = 0; k < nr; ++k) { q0[k] = S.q[k]; qd0[k] = S.qd[k]; }
   const bool bdf2 = m.integrator == 2 && S.has_prev;
   StepCoef c; make_coef(m, q0, qd0, bdf2 ? S.qm1.data() : nullptr, bdf2 ? S.qdm1.data() : nullptr, c);
