@@ -42,6 +42,30 @@ def test_plain_formulas_match_the_reference_env():
     assert np.abs(terms.sum(1) - G["reward"]).max() < 1e-10 * np.abs(G["reward"]).max()
 
 
+def test_observation_types_match_the_reference_env():
+    """tactile_push_env.py:72-131 builds four observations from the same state; the batched env derives "no_tactile", "privilege" and
+    "tactile_map" from the "tactile_flatten" one and q (envs/tactile_push.shape_observation) — checked here against what the reference's
+    own class returned for each type on the same scripted episode."""
+    import torch
+    from tactilesimulation_amd.envs.tactile_push import shape_observation
+    obs = torch.tensor(np.concatenate([G["obs0"][None], G["obs"]]))
+    q = torch.tensor(np.concatenate([G["q0"][None], G["q"]]))
+    nt = shape_observation("no_tactile", obs, q).numpy()
+    assert np.array_equal(nt[0], G["obs0_no_tactile"]) and np.array_equal(nt[1:], G["obs_no_tactile"])
+    pv = shape_observation("privilege", obs, q).numpy()
+    assert pv.shape == (41, 6) and np.abs(pv[0] - G["obs0_privilege"]).max() < 1e-15 and np.abs(pv[1:] - G["obs_privilege"]).max() < 1e-15
+    tm, st = shape_observation("tactile_map", obs, q)
+    assert np.array_equal(tm.numpy()[0], G["obs0_tactile_map"]) and np.array_equal(tm.numpy()[1:], G["obs_tactile_map"])
+    assert np.array_equal(st.numpy()[1:], G["obs_tactile_map_state"])
+    assert shape_observation("tactile_flatten", obs, q) is obs
+    with pytest.raises(ValueError):
+        shape_observation("depth", obs, q)
+    # differentiable: the privileged observation carries the box pose's gradient
+    qg = q.clone().requires_grad_(True)
+    shape_observation("privilege", obs, qg)[:, 0:3].sum().backward()
+    assert float(qg.grad[:, 3:5].abs().min()) > 0.0 and float(qg.grad[:, 6].abs().min()) == 1.0
+
+
 @pytest.mark.gpu
 def test_fused_kernels_match_the_reference_env():
     import torch

@@ -81,6 +81,53 @@ def test_policy_gradient_matches_finite_differences(pusher_model):
     assert np.isfinite(l0) and np.isfinite(l1)
 
 
+@pytest.mark.parametrize("observation_type,obs_dim", [("privilege", 6), ("no_tactile", 3)])
+def test_policy_gradient_with_the_other_observation_types(pusher_model, observation_type, obs_dim):
+    """cfg/gd_privilege.yaml / gd_no_tactile.yaml: the same GD loop on the 6- / 3-value observations of tactile_push_env.py:104-131.
+    dLoss/dtheta of the closed loop (policy -> env-step -> ... -> BPTT; the privileged observation adds a path from the box pose to the
+    policy) against central differences, and one graphed training epoch."""
+    import copy
+    import tactilesimulation_amd.model.blob as Bl
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.algorithms.batched_gd import Actor, GraphedRollout, rollout_loss, train_epoch_graphed
+    m = copy.copy(pusher_model); m.F = pusher_model.F.copy(); m.F[Bl.TSIM_FH_TOL] = 1e-13
+    B, T = 4, 8
+    env = BatchedTactilePushEnv(m, B, dtype=torch.float64, gradient=True, seed=5, tape_steps=T, observation_type=observation_type)
+    assert env.obs_dim == obs_dim
+    torch.manual_seed(0)
+    actor = Actor(obs_dim=obs_dim, dtype=torch.float64).cuda()
+    with torch.no_grad():
+        for p in actor.parameters():
+            p.mul_(3.0)                                                   # a policy that acts
+    obs = env.reset()
+    assert tuple(obs.shape) == (B, obs_dim)
+    q0, goal = env.q0.cpu().numpy(), env.goal.cpu().numpy()
+    D = torch.tensor(np.random.default_rng(1).uniform(-1, 1, size=(T, B, 2)))
+    kw = dict(q0=q0, goal=goal, disturbances=D)
+    rollout_loss(env, actor, T, **kw).backward()
+    w, b = actor.mu_net[0].weight, actor.mu_net[2].bias
+    checks = [(w, (5, 0), w.grad[5, 0].item()), (w, (17, obs_dim - 1), w.grad[17, obs_dim - 1].item()), (b, (9,), b.grad[9].item())]
+    eps = 1e-6
+    with torch.no_grad():
+        for t, ix, ga in checks:
+            t[ix] += eps; lp = rollout_loss(env, actor, T, **kw).item()
+            t[ix] -= 2 * eps; lm = rollout_loss(env, actor, T, **kw).item()
+            t[ix] += eps
+            fd = (lp - lm) / (2 * eps)
+            assert abs(fd - ga) < 2e-5 * max(abs(fd), 1e-2), (ix, fd, ga)
+    assert abs(w.grad[5, 0].item()) > 0.0
+    # the graphed epoch on the same environment class (fp32)
+    env32 = BatchedTactilePushEnv(pusher_model, 64, dtype=torch.float32, gradient=True, seed=5, tape_steps=T, observation_type=observation_type)
+    a32 = Actor(obs_dim=obs_dim, dtype=torch.float32).cuda()
+    env32.reset()
+    q0s, goals = env32.q0.clone(), env32.goal.clone()
+    Ds = torch.tensor(np.random.default_rng(2).uniform(-1, 1, size=(T, 64, 2)), device="cuda", dtype=torch.float32)
+    gr = GraphedRollout(env32, a32, T, q0s, goals, Ds, warmup=1)
+    opt = torch.optim.Adam(a32.parameters(), lr=1e-3)
+    l0 = float(train_epoch_graphed(gr, opt, 64).detach()); l1 = float(train_epoch_graphed(gr, opt, 64).detach())
+    assert np.isfinite(l0) and np.isfinite(l1)
+
+
 def test_graphed_rollout_matches_eager(pusher_model):
     """algorithms/batched_gd.GraphedRollout: the episode + its backward replayed from one HIP graph give the loss and the
     policy gradient of the eager loop, also after new episode data has been written into the static inputs."""

@@ -82,6 +82,22 @@ if __name__ == "__main__":
         assert not done
     out.update({"obs": np.array(obs), "reward": np.array(rew), "external_force": np.array(ext), "reward_terms": np.array(terms),
                 "robot_action": np.array(LOG["set_u"]), "frame_skip": np.array(sorted(set(LOG["forward"])))})
+    # the other observation types of :72-131 on the same script (same seed: same goal, same disturbances)
+    for ot in ("no_tactile", "privilege", "tactile_map"):
+        LOG["set_u"].clear(); LOG["forward"].clear()
+        e2 = TactilePushEnv(use_torch=True, gradient=False, observation_type=ot, seed=3)
+        o0 = e2.reset()
+        assert np.array_equal(e2.goal.numpy(), out["goal"])
+        rec = []
+        for t in range(T):
+            o, r, done, info = e2.step(torch.tensor(out["u"][t], dtype=torch.float64))
+            rec.append(o)
+            assert abs(float(r) - out["reward"][t]) < 1e-12 * abs(out["reward"][t])
+        if ot == "tactile_map":
+            out["obs0_tactile_map"], out["obs0_tactile_map_state"] = o0[0].numpy().copy(), o0[1].numpy().copy()
+            out["obs_tactile_map"] = np.array([o[0].numpy() for o in rec]); out["obs_tactile_map_state"] = np.array([o[1].numpy() for o in rec])
+        else:
+            out["obs0_" + ot] = o0.numpy().copy(); out["obs_" + ot] = np.array([o.numpy() for o in rec])
     path = os.path.join(ROOT, "tests", "golden", "tactile_push_env.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; obs", out["obs"].shape, "frame_skip", out["frame_skip"], "reward[0:3]", out["reward"][:3])
