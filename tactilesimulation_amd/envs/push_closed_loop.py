@@ -50,13 +50,20 @@ class FusedPushEpisode:
         self._pol.w1_stride = 396
         return C.byref(self._pol)
 
-    def rollout(self, q0, goal, disturbances):
+    def evaluate(self, q0, goal, disturbances):
+        """The episode without a tape (algorithms/gd.py:265-290 evaluates the deterministic policy this way between epochs): per-environment
+        return [B] (sum of rewards).  backward() is not available afterwards."""
+        self.rollout(q0, goal, disturbances, record=False)
+        return self.returns
+
+    def rollout(self, q0, goal, disturbances, record=True):
         """One episode forward.  q0 [B, 7], goal [B, 3], disturbances [T, B, 2].  Returns -sum of rewards (a 0-d tensor; its
         partials w.r.t. the frames' outputs are kept for backward())."""
         env, sim = self.env, self.sim
         self.goal = goal.to(self.dev, self.dt).contiguous()
         dist = disturbances.to(self.dev, self.dt).contiguous()
-        sim.reset(q0.to(self.dev, self.dt), None, backward_flag=True)
+        sim.reset(q0.to(self.dev, self.dt), None, backward_flag=bool(record))
+        self._recorded = bool(record)
         _, tac0 = sim.readout(want_var=False)
         self.tac0 = tac0
         pol = self._weights()
@@ -76,6 +83,7 @@ class FusedPushEpisode:
         self.df_dq[:, :, 6] = (0.2 * k) * dr
         self.df_dvar = torch.cat([5000.0 * dt_, -5000.0 * dt_], dim=2)
         self.du_direct = 0.2 * self.u
+        self.returns = rew.sum(0)                                   # per environment
         self.loss = -rew.sum()
         return self.loss
 
@@ -83,6 +91,8 @@ class FusedPushEpisode:
         """Adjoint launch of the episode rollout() ran, then the weight gradients: sets .grad of the actor's weights and biases
         (assigned, not accumulated; un-normalised, as rollout_loss(...).backward() would)."""
         sim = self.sim
+        if not getattr(self, "_recorded", False):
+            raise RuntimeError("FusedPushEpisode.backward: the last roll-out was not recorded (evaluate())")
         st = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
         capi.check(capi.lib().tsim_push_closed_backward(sim._h, C.byref(self._pol), _p(self.goal), self.T, self.env.frame_skip,
                                                         _p(self.df_dq), _p(self.df_dvar), _p(self.du_direct), _p(self.u), _p(self.h1), _p(self.h2),

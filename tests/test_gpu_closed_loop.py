@@ -88,6 +88,29 @@ def test_fused_epoch_b4096_trains_and_matches_the_graphed_loop(pusher_model):
     assert losses[-1] < losses[0], losses
 
 
+def test_evaluate_is_the_unrecorded_rollout(pusher_model):
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode
+    from tactilesimulation_amd.algorithms.batched_gd import Actor
+    B, T = 37, 10
+    q0, goal, dist = (torch.tensor(a, device="cuda", dtype=torch.float32) for a in _episode(B, T, 5))
+    torch.manual_seed(2)
+    actor = Actor(dtype=torch.float32).cuda()
+    with torch.no_grad():
+        for p in actor.parameters():
+            p.mul_(3.0)
+    env = BatchedTactilePushEnv(pusher_model, B, dtype=torch.float32, gradient=True, seed=0, tape_steps=T)
+    ep = FusedPushEpisode(env, actor, T)
+    loss = float(ep.rollout(q0, goal, dist))
+    q_rec = ep.q.clone()
+    ret = ep.evaluate(q0, goal, dist)
+    assert env.sim.tape_len() == 0
+    assert torch.equal(ep.q, q_rec)                                  # the same launch, no tape
+    assert abs(float(-ret.sum()) - loss) <= 1e-6 * abs(loss) and tuple(ret.shape) == (B,)
+    with pytest.raises(RuntimeError):
+        ep.backward()
+
+
 def test_simulator_gradients_in_the_regime_a_trained_policy_reaches():
     """The bench workload and the parity tests drive the environments with random open-loop actions.  Here: 40 epochs of the fused GD
     loop at B = 4096, then the 6 actuator inputs per env-step the trained policy produced in one more episode are replayed OPEN LOOP
