@@ -78,7 +78,11 @@ int tsim_step(tsim_batch* b, const void* u, int num_steps, void* q_out, void* qd
               void* tac_out, int32_t* status, void* stream);
 
 /* sim.get_q() / get_qdot() / get_variables() / get_tactile_force_vector() at the current state, e.g.
- * right after reset (envs/tactile_push_env.py:157). */
+ * right after reset (envs/tactile_push_env.py:157) or after forward() where the pad is too large to be read out inside the step
+ * (examples/RollingBallExp/test_sim_speed.py:77-80: 40 000 taxels).  tsim_readout is two launches — kinematics of the current state,
+ * then one kernel whose lanes are taxels — or, for pads of >= 4096 taxels right after a forward launch, the second one alone: that
+ * launch leaves the pose records of the state it ends in.  Same results either way; any other change of state (reset, masked reset,
+ * new model tables, cache pop) and any HIP-graph capture of this batch's launches switch back to two. */
 int tsim_get_state(tsim_batch* b, void* q_out, void* qd_out, void* stream);
 int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream);
 
