@@ -63,8 +63,7 @@ def main():
     ap.add_argument("--graphed", action="store_true", help="one launch per env-step, the episode replayed from one HIP graph (algorithms/batched_gd.GraphedRollout)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--observation-type", default="tactile_flatten", choices=["tactile_flatten", "no_tactile", "privilege"],
-                    help="cfg/gd_tactile.yaml / gd_no_tactile.yaml / gd_privilege.yaml (tactile_push_env.py:72-131); the policy inside the episode "
-                         "launches is the tactile_flatten one, the other two run as one HIP graph per episode")
+                    help="cfg/gd_tactile.yaml / gd_no_tactile.yaml / gd_privilege.yaml (tactile_push_env.py:72-131)")
     ap.add_argument("--disturbance-period", type=int, default=1, help="env-steps between new random forces on the box (the reference: 1, see draw_episode)")
     ap.add_argument("--save-best", default=None, help="torch.save the best policy (lowest loss, as algorithms/gd.py:187-189 keeps it) here")
     args = ap.parse_args()
@@ -77,8 +76,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev, dtype = "cuda:%d" % local, (torch.float32 if args.dtype == "f32" else torch.float64)
     B, T = args.batch, args.horizon
-    if args.observation_type != "tactile_flatten" and not args.eager:
-        args.graphed = True
     env = BatchedTactilePushEnv(args.model, B, device=dev, dtype=dtype, gradient=True, seed=args.seed + rank, tape_steps=T, observation_type=args.observation_type)
     torch.manual_seed(args.seed)                                   # identical initial policy on every rank
     actor = Actor(obs_dim=env.obs_dim, dtype=dtype).to(dev)

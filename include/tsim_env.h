@@ -47,12 +47,15 @@ int tsim_push_observe_backward(int B, int ntac, int dtype, const void* q, const 
 typedef struct tsim_push_policy {
   const void *W1T, *b1, *W2T, *b2, *W3, *b3, *W1p, *W2;
   int w1_stride;
+  int obs_mode;      /* observation_type of envs/tactile_push_env.py:72-131: 0 tactile_flatten (393 inputs: goal in the gripper frame, tactile frame;
+                        cfg/gd_tactile.yaml), 1 no_tactile (3: the goal; gd_no_tactile.yaml), 2 privilege (6: box pose in the gripper frame, goal;
+                        gd_privilege.yaml).  W1T is [inputs][64], W1p [64][w1_stride >= inputs]. */
 } tsim_push_policy;
 
 /* Forward: num_frames env-steps of num_steps sub-steps from the batch's current state; frame f acts with
  *   action_f = [tanh(policy(obs_f)), dist[f][env][0:2], 0],  obs_f = [goal in the gripper frame of the state before the frame, tactile frame before it]
- * (tac0 [B][390]: the tactile frame at the current state, tsim_readout).  Outputs per frame [T][B][.]: q, qd (may be NULL), var, tac (required:
- * it feeds the next observation), and the policy's records u (3, pre-tanh), gl (3, goal part of the observation), h1, h2 (64, ELU outputs). */
+ * (tac0 [B][390]: the tactile frame at the current state, tsim_readout).  Outputs per frame [T][B][.]: q, qd (may be NULL), var, tac (required with
+ * the tactile observation, which it feeds; may be NULL otherwise, and the launch then skips the read-out), and the policy's records u (3, pre-tanh), gl (3, goal part of the observation), h1, h2 (64, ELU outputs). */
 int tsim_push_closed_rollout(tsim_batch* b, const tsim_push_policy* pol, const void* goal, const void* dist, const void* tac0,
                              int num_frames, int num_steps, void* q_out, void* qd_out, void* var_out, void* tac_out,
                              void* u_out, void* gl_out, void* h1_out, void* h2_out, int32_t* status, void* stream);

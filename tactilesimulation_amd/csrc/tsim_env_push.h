@@ -129,12 +129,14 @@ extern "C" int tsim_push_observe_backward(int B, int ntac, int dtype, const void
 
 // ================================================================================================ closed loop in one launch each way
 // (tsim_policy_push.h: the policy between the frames of k_forward / k_backward)
+static int push_obs_len(int mode) { return mode == TSIM_PUSH_OBS_TACTILE ? (int)PP_OBS : (mode == TSIM_PUSH_OBS_NO_TACTILE ? 3 : (mode == TSIM_PUSH_OBS_PRIVILEGE ? 6 : -1)); }
 template <class R>
 static PushPolicy<R> make_push_policy(const tsim_push_policy* p) {
   PushPolicy<R> P;
   memset(&P, 0, sizeof(P));
   P.W1T = (const R*)p->W1T; P.b1 = (const R*)p->b1; P.W2T = (const R*)p->W2T; P.b2 = (const R*)p->b2; P.W3 = (const R*)p->W3; P.b3 = (const R*)p->b3;
   P.W1p = (const R*)p->W1p; P.W2 = (const R*)p->W2; P.w1s = p->w1_stride;
+  P.mode = p->obs_mode; P.nin = push_obs_len(p->obs_mode); P.nin_pad = (P.nin + PP_ROWS1 - 1) / PP_ROWS1 * PP_ROWS1;
   return P;
 }
 static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, int num_frames, int num_steps, const char* who) {
@@ -143,6 +145,7 @@ static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, i
   if (num_frames <= 0 || num_steps <= 0) return fail(std::string(who) + ": num_frames and num_steps must be positive");
   if (TS_PAIR_GROUP * ((int)PP_SIZE + b->nr * (int)PT_SIZE) < 64 * (int)PP_OCH + 2 * (int)PP_HID) return fail(std::string(who) + ": the pair-staging records are too small for the policy scratch");
   if (!pol->W1T || !pol->b1 || !pol->W2T || !pol->b2 || !pol->W3 || !pol->b3) return fail(std::string(who) + ": policy weights missing");
+  if (push_obs_len(pol->obs_mode) < 0) return fail(std::string(who) + ": obs_mode must be 0 (tactile_flatten), 1 (no_tactile) or 2 (privilege)");
   if (b->dFenv) return fail(std::string(who) + ": per-environment tables are not supported in the closed-loop launch");
   return 0;
 }
@@ -176,7 +179,8 @@ extern "C" int tsim_push_closed_rollout(tsim_batch* b, const tsim_push_policy* p
                                         int num_frames, int num_steps, void* q_out, void* qd_out, void* var_out, void* tac_out,
                                         void* u_out, void* gl_out, void* h1_out, void* h2_out, int32_t* status, void* stream) {
   if (int rc = push_closed_check(b, pol, num_frames, num_steps, "push_closed_rollout")) return rc;
-  if (!goal || !dist || !tac0 || !tac_out || !u_out || !gl_out || !h1_out || !h2_out) return fail("push_closed_rollout: null pointer (goal, dist, tac0, tac_out and the policy records are required)");
+  if (!goal || !dist || !u_out || !gl_out || !h1_out || !h2_out) return fail("push_closed_rollout: null pointer (goal, dist and the policy records are required)");
+  if (pol->obs_mode == TSIM_PUSH_OBS_TACTILE && (!tac0 || !tac_out)) return fail("push_closed_rollout: tac0 and tac_out are required with the tactile observation (they feed it)");
   if (b->record && b->t_cur + (long long)num_frames * num_steps > b->cap) return fail("push_closed_rollout: tape capacity exceeded (" + std::to_string(b->cap) + " sub-steps)");
   TS_DEVICE(b);
   int rc = b->dtype == TSIM_F32 ? push_closed_rollout_t<float>(b, pol, goal, dist, tac0, num_frames, num_steps, q_out, qd_out, var_out, tac_out, u_out, gl_out, h1_out, h2_out, status, (hipStream_t)stream)
@@ -209,11 +213,12 @@ extern "C" int tsim_push_closed_backward(tsim_batch* b, const tsim_push_policy* 
                                          const void* df_dq, const void* df_dvar, const void* du_direct, const void* u_out, const void* h1_out, const void* h2_out,
                                          void* g1_out, void* g2_out, void* g3_out, void* dobs_tac, void* df_du, void* stream) {
   if (int rc = push_closed_check(b, pol, num_frames, num_steps, "push_closed_backward")) return rc;
-  if (!pol->W1p || !pol->W2 || pol->w1_stride < PP_OBS || pol->w1_stride % 4) return fail("push_closed_backward: W1p [64][w1_stride >= 393, multiple of 4] and W2 are required");
+  if (!pol->W1p || !pol->W2 || pol->w1_stride < push_obs_len(pol->obs_mode) || pol->w1_stride % 4 || pol->w1_stride > 64 * (int)PP_OCH) return fail("push_closed_backward: W1p [64][w1_stride >= observation length, multiple of 4] and W2 are required");
   if (!b->record) return fail("push_closed_backward: reset(backward_flag=True) was not called");
   const long long n = (long long)num_frames * num_steps;
   if (n > b->t_cur) return fail("push_closed_backward: only " + std::to_string(b->t_cur) + " sub-steps on the tape");
-  if (!goal || !du_direct || !u_out || !h1_out || !h2_out || !g1_out || !g2_out || !g3_out || !dobs_tac) return fail("push_closed_backward: null pointer");
+  if (!goal || !du_direct || !u_out || !h1_out || !h2_out || !g1_out || !g2_out || !g3_out) return fail("push_closed_backward: null pointer");
+  if (pol->obs_mode == TSIM_PUSH_OBS_TACTILE && !dobs_tac) return fail("push_closed_backward: dobs_tac is required with the tactile observation");
   TS_DEVICE(b);
   int rc = b->dtype == TSIM_F32 ? push_closed_backward_t<float>(b, pol, goal, num_frames, num_steps, df_dq, df_dvar, du_direct, u_out, h1_out, h2_out, g1_out, g2_out, g3_out, dobs_tac, df_du, (hipStream_t)stream)
                                 : push_closed_backward_t<double>(b, pol, goal, num_frames, num_steps, df_dq, df_dvar, du_direct, u_out, h1_out, h2_out, g1_out, g2_out, g3_out, dobs_tac, df_du, (hipStream_t)stream);

@@ -166,7 +166,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       // closed loop: the action comes from the policy, evaluated by this slot on the observation the previous frame left
       // (tsim_policy_push.h).  The tactile frame was written by this slot: make the stores visible to its own loads first.
       ts_own_stores_visible();
-      const R* tprev = f == 0 ? a.pol.tac0 + (size_t)env * PP_NTAC : a.tac_out + ((size_t)(f - 1) * a.B + env) * PP_NTAC;
+      const R* tprev = a.pol.mode != TSIM_PUSH_OBS_TACTILE ? nullptr : (f == 0 ? a.pol.tac0 + (size_t)env * PP_NTAC : a.tac_out + ((size_t)(f - 1) * a.B + env) * PP_NTAC);
 #ifdef TS_PP_TIME
       const long long tp0_ = clock64();
 #endif
@@ -885,10 +885,10 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
       const int tslot = (a.frames && a.tac_slot) ? a.tac_slot[fr] : 0;
       const size_t sot = (a.frames && a.tac_slot) ? (size_t)max(tslot, 0) * a.B + env : so;
       if (a.df_dq && lane < nr) c.lamq[lane] += a.df_dq[so * nr + lane];
-      if (POLICY && pol_have && lane < 3) c.lamq[lane] += pol_dq;        // goal part of the next frame's observation
+      if (POLICY && pol_have && lane < nr) c.lamq[lane] += pol_dq;       // state part of the next frame's observation (goal; privilege: box pose)
       TS_SYNC();
       const R* wtac_ = (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr;
-      if (POLICY) wtac_ = pol_have ? a.pol.dobs_tac + ((size_t)(fr + 1) * a.B + env) * PP_NTAC : nullptr;   // tactile part (frame fr + 1's observation)
+      if (POLICY) wtac_ = (pol_have && a.pol.mode == TSIM_PUSH_OBS_TACTILE) ? a.pol.dobs_tac + ((size_t)(fr + 1) * a.B + env) * PP_NTAC : nullptr;   // tactile part (frame fr + 1's observation)
       output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, wtac_);
     }
     TS_STAMP(c);
@@ -938,7 +938,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
         // ... and so is the policy call in front of it: dL/d(action) -> MLP -> observation -> the state / tactile frame before it
         TS_SYNC();
         const int fr0 = j / a.seed_stride;
-        pol_dq = push_policy_backward<LPE>(c, lane, valid, a.pol, (size_t)fr0 * a.B + env, env, du_frame, (double)c.q0[0]);
+        pol_dq = push_policy_backward<LPE>(c, lane, valid, a.pol, (size_t)fr0 * a.B + env, env, du_frame, c.q0);
         pol_have = true;
         ts_own_stores_visible();                           // dobs_tac is read back by this slot as the previous frame's tactile seed
       }

@@ -19,10 +19,12 @@
 #include "tsim_device.h"
 
 enum { PP_OBS = 393, PP_HID = 64, PP_ACT = 3, PP_GOAL = 3, PP_NTAC = 390 };
+enum { TSIM_PUSH_OBS_TACTILE = 0, TSIM_PUSH_OBS_NO_TACTILE = 1, TSIM_PUSH_OBS_PRIVILEGE = 2 };      // include/tsim_env.h tsim_push_policy.obs_mode
 
 template <class R> struct PushPolicy {
   const R *W1T, *b1, *W2T, *b2, *W3, *b3;      // forward layouts
   const R *W1p, *W2; int w1s;                  // backward layouts (row stride of W1p)
+  int mode, nin, nin_pad;                      // observation type (TSIM_PUSH_OBS_*), its length (393 / 3 / 6), padded to a multiple of PP_ROWS1
   const R* goal;                               // [B][3] goal pose (x, y, yaw)
   const R* dist;                               // [T][B][2] external force on the box per env-step
   const R* tac0;                               // [B][390] tactile at the initial state (tsim_readout after the reset)
@@ -97,8 +99,9 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
   }
   constexpr int NS = TS_WAVE / LPE;
   const PPScr<LPE, R> S = pp_scr<LPE>(c);
-  // the observation of this slot into LDS: goal (3), the tactile frame (390; every lane fetches its share in one batch of loads), zeros
-  {
+  const int mode = ts_u(P.mode);
+  if (mode == TSIM_PUSH_OBS_TACTILE) {
+    // the observation of this slot into LDS: goal (3), the tactile frame (390; every lane fetches its share in one batch of loads), zeros
     constexpr int NX = (PP_OBS_PAD - 3 + LPE - 1) / LPE;
     R xv[NX];
 #pragma unroll
@@ -106,6 +109,16 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
     if (lane < 3) S.xs[lane] = lane == 0 ? gl[0] : (lane == 1 ? gl[1] : gl[2]);
 #pragma unroll
     for (int m = 0; m < NX; ++m) { const int i = lane + LPE * m; if (3 + i < PP_OBS_PAD) S.xs[3 + i] = xv[m]; }
+  } else {
+    // no_tactile: the goal (3); privilege: the box pose in the gripper frame (3), then the goal (tactile_push_env.py:104-131)
+    for (int i = lane; i < P.nin_pad; i += LPE) S.xs[i] = R(0);
+    const int go = mode == TSIM_PUSH_OBS_PRIVILEGE ? 3 : 0;
+    if (lane < 3) S.xs[go + lane] = lane == 0 ? gl[0] : (lane == 1 ? gl[1] : gl[2]);
+    if (mode == TSIM_PUSH_OBS_PRIVILEGE && lane < 3) {
+      double sn, cs; t_sincos_d(c.q0D[0], sn, cs);
+      const double ox = c.q0D[3], oy = c.q0D[4];
+      S.xs[lane] = lane == 0 ? (R)(cs * ox + sn * oy - c.q0D[1]) : (lane == 1 ? (R)(-sn * ox + cs * oy - c.q0D[2]) : (R)(c.q0D[6] - c.q0D[0]));
+    }
   }
   TS_SYNC();
   R acc[NS], w[OPL];
@@ -114,7 +127,7 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) acc[s_] = bj;
   }
-  pp_dense64<NS, PP_ROWS1>(P.W1T, PP_OBS_PAD, PP_OBS, S.xs0, S.stride, acc);
+  pp_dense64<NS, PP_ROWS1>(P.W1T, ts_u(P.nin_pad), ts_u(P.nin), S.xs0, S.stride, acc);
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + threadIdx.x] = pp_elu(acc[s_]);
   TS_SYNC();
@@ -165,9 +178,10 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
 
 // Reverse of the above for frame f: da = dL/d(action) of the frame (lane m < 6 holds entry m).  Writes the pre-activation gradients
 // (g1, g2, g3), the gradient w.r.t. the tactile part of the observation into P.dobs_tac (the seed of the previous frame's tactile
-// read-out) and returns, in lanes 0..2, what the goal part of the observation puts on q[0..2] of the state before the frame.
+// read-out) and returns, in lanes 0..6, what the state part of the observation (goal; privilege: box pose) puts on q of the state before the frame.
 template <int LPE, class R>
-__device__ __forceinline__ R push_policy_backward(const Ctx<R>& c, int lane, bool valid, const PushPolicy<R>& P, size_t rec, int env, R da, double yaw) {
+__device__ __forceinline__ R push_policy_backward(const Ctx<R>& c, int lane, bool valid, const PushPolicy<R>& P, size_t rec, int env, R da, const R* qb /* state before the frame */) {
+  const double yaw = (double)qb[0];
   constexpr int OPL = PP_HID / LPE;
   constexpr int NS = TS_WAVE / LPE;
   const PPScr<LPE, R> S = pp_scr<LPE>(c);
@@ -224,33 +238,37 @@ __device__ __forceinline__ R push_policy_backward(const Ctx<R>& c, int lane, boo
 #pragma unroll
       for (int s_ = 0; s_ < NS; ++s_) dob[m][s_] = R(0);
     const R* g0 = S.hs0 + PP_HID;
+    const int w1s = ts_u(P.w1s), och = (w1s + 63) / 64;          // 64-wide chunks of the observation (7 with the tactile frame, 1 without)
     for (int j0 = 0; j0 < PP_HID; j0 += PP_JB) {
       R wb[PP_JB][PP_OCH];
 #pragma unroll
       for (int r = 0; r < PP_JB; ++r)
 #pragma unroll
-        for (int m = 0; m < PP_OCH; ++m) wb[r][m] = P.W1p[(size_t)(j0 + r) * P.w1s + min((int)threadIdx.x + 64 * m, P.w1s - 1)];
+        for (int m = 0; m < PP_OCH; ++m) if (m < och) wb[r][m] = P.W1p[(size_t)(j0 + r) * w1s + min((int)threadIdx.x + 64 * m, w1s - 1)];
 #pragma unroll
       for (int r = 0; r < PP_JB; ++r)
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
           const R x = g0[s_ * S.stride + j0 + r];
 #pragma unroll
-          for (int m = 0; m < PP_OCH; ++m) dob[m][s_] += wb[r][m] * x;
+          for (int m = 0; m < PP_OCH; ++m) if (m < och) dob[m][s_] += wb[r][m] * x;
         }
     }
     TS_SYNC();
 #pragma unroll
     for (int m = 0; m < PP_OCH; ++m)
 #pragma unroll
-      for (int s_ = 0; s_ < NS; ++s_) S.xs0[s_ * S.stride + (int)threadIdx.x + 64 * m] = dob[m][s_];
+      for (int s_ = 0; s_ < NS; ++s_) if (m < och) S.xs0[s_ * S.stride + (int)threadIdx.x + 64 * m] = dob[m][s_];
     TS_SYNC();
   }
+  const int mode = ts_u(P.mode);
   // tactile part -> the seed of the previous frame's tactile read-out (consecutive lanes, consecutive addresses); goal part -> q[0..2]
-  if (valid) {
+  if (valid && mode == TSIM_PUSH_OBS_TACTILE) {
     for (int i = lane; i < PP_NTAC; i += LPE) P.dobs_tac[rec * PP_NTAC + i] = S.xs[3 + i];
   }
-  const R d0 = S.xs[0], d1 = S.xs[1], d2 = S.xs[2];
+  const int go = mode == TSIM_PUSH_OBS_PRIVILEGE ? 3 : 0;
+  const R d0 = S.xs[go], d1 = S.xs[go + 1], d2 = S.xs[go + 2];
+  const R e0 = S.xs[0], e1 = S.xs[1], e2 = S.xs[2];              // privilege: gradient w.r.t. the box pose in the gripper frame
   TS_SYNC();
   double sn, cs; t_sincos_d(yaw, sn, cs);
   const R* g = P.goal + (size_t)env * 3;
@@ -259,5 +277,14 @@ __device__ __forceinline__ R push_policy_backward(const Ctx<R>& c, int lane, boo
   if (lane == 0) out = (R)((double)d0 * (-sn * gx + cs * gy) + (double)d1 * (-cs * gx - sn * gy) - (double)d2);
   else if (lane == 1) out = -d0;
   else if (lane == 2) out = -d1;
+  if (mode == TSIM_PUSH_OBS_PRIVILEGE) {             // obj = (cs ox + sn oy - q1, -sn ox + cs oy - q2, q6 - q0)
+    const double ox = (double)qb[3], oy = (double)qb[4];
+    if (lane == 0) out += (R)((double)e0 * (-sn * ox + cs * oy) + (double)e1 * (-cs * ox - sn * oy) - (double)e2);
+    else if (lane == 1) out -= e0;
+    else if (lane == 2) out -= e1;
+    else if (lane == 3) out = (R)((double)e0 * cs - (double)e1 * sn);
+    else if (lane == 4) out = (R)((double)e0 * sn + (double)e1 * cs);
+    else if (lane == 6) out = e2;
+  }
   return out;
 }

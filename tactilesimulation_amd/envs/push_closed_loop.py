@@ -19,22 +19,33 @@ from ..host import capi
 _p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+OBS_MODES = {"tactile_flatten": (0, 393), "no_tactile": (1, 3), "privilege": (2, 6)}      # include/tsim_env.h tsim_push_policy.obs_mode
+
+
 class FusedPushEpisode:
     def __init__(self, env, actor, horizon):
-        """env: BatchedTactilePushEnv (its BatchSim, dtype, device); actor: algorithms.batched_gd.Actor (393 -> 64 -> 64 -> 3)."""
+        """env: BatchedTactilePushEnv (its BatchSim, dtype, device, observation_type: tactile_flatten / no_tactile / privilege — the
+        three GD configurations of examples/TactilePushExp/cfg); actor: algorithms.batched_gd.Actor (obs -> 64 -> 64 -> 3)."""
         self.env, self.actor, self.T = env, actor, int(horizon)
         self.sim, self.B, self.dt, self.dev = env.sim, env.B, env.dtype, env.device
+        self.obs_type = getattr(env, "observation_type", "tactile_flatten")
+        if self.obs_type not in OBS_MODES:
+            raise ValueError("the policy inside the episode launches takes the observation types %s (not %r)" % (tuple(OBS_MODES), self.obs_type))
+        self.mode, self.nin = OBS_MODES[self.obs_type]
         lin = [m for m in actor.mu_net if isinstance(m, torch.nn.Linear)]
-        assert [tuple(m.weight.shape) for m in lin] == [(64, 393), (64, 64), (3, 64)], "the fused policy is the gd_tactile actor (393-64-64-3)"
+        assert [tuple(m.weight.shape) for m in lin] == [(64, self.nin), (64, 64), (3, 64)], "the fused policy is the GD actor (obs-64-64-3)"
         self.lin = lin
         T, B = self.T, self.B
         new = lambda *d: torch.empty(d, device=self.dev, dtype=self.dt)
-        self.q, self.var, self.tac = new(T, B, 7), new(T, B, 6), new(T, B, 390)
+        tactile = self.mode == 0
+        self.q, self.var = new(T, B, 7), new(T, B, 6)
+        self.tac = new(T, B, 390) if tactile else None              # without the tactile observation the launch skips the read-out
         self.u, self.gl, self.h1, self.h2 = new(T, B, 3), new(T, B, 3), new(T, B, 64), new(T, B, 64)
         self.g1, self.g2, self.g3 = new(T, B, 64), new(T, B, 64), new(T, B, 3)
-        self.dobs_tac = new(T, B, 390)
+        self.dobs_tac = new(T, B, 390) if tactile else None
         self.status = torch.empty(B, device=self.dev, dtype=torch.int32)
-        self.W1p = torch.zeros(64, 396, device=self.dev, dtype=self.dt)
+        self.w1s = (self.nin + 3) // 4 * 4
+        self.W1p = torch.zeros(64, self.w1s, device=self.dev, dtype=self.dt)
         self._pol = capi.PushPolicyStruct()
 
     def _weights(self):
@@ -43,11 +54,12 @@ class FusedPushEpisode:
         with torch.no_grad():
             self._w = [l1.weight.t().contiguous(), l1.bias.contiguous(), l2.weight.t().contiguous(), l2.bias.contiguous(),
                        l3.weight.contiguous(), l3.bias.contiguous(), self.W1p, l2.weight.contiguous()]
-            self.W1p[:, :393].copy_(l1.weight)
+            self.W1p[:, :self.nin].copy_(l1.weight)
         for n, t in zip(("W1T", "b1", "W2T", "b2", "W3", "b3", "W1p", "W2"), self._w):
             assert t.dtype == self.dt and t.device == self.dev
             setattr(self._pol, n, t.data_ptr())
-        self._pol.w1_stride = 396
+        self._pol.w1_stride = self.w1s
+        self._pol.obs_mode = self.mode
         return C.byref(self._pol)
 
     def evaluate(self, q0, goal, disturbances):
@@ -62,9 +74,10 @@ class FusedPushEpisode:
         env, sim = self.env, self.sim
         self.goal = goal.to(self.dev, self.dt).contiguous()
         dist = disturbances.to(self.dev, self.dt).contiguous()
-        sim.reset(q0.to(self.dev, self.dt), None, backward_flag=bool(record))
+        self.q0 = q0.to(self.dev, self.dt).contiguous()
+        sim.reset(self.q0, None, backward_flag=bool(record))
         self._recorded = bool(record)
-        _, tac0 = sim.readout(want_var=False)
+        tac0 = sim.readout(want_var=False)[1] if self.mode == 0 else None
         self.tac0 = tac0
         pol = self._weights()
         st = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -100,12 +113,21 @@ class FusedPushEpisode:
         l1, l2, l3 = self.lin
         g1, g2, g3 = self.g1, self.g2, self.g3
         T = self.T
-        # layer 1: x = [gl, tactile frame before the env-step]: tac0 for frame 0, the previous frame's read-out otherwise (no concatenated copy)
         w1 = torch.empty_like(l1.weight)
-        w1[:, 0:3] = torch.bmm(g1.transpose(1, 2), self.gl).sum(0)
-        w1[:, 3:] = g1[0].t() @ self.tac0
-        if T > 1:
-            w1[:, 3:] += torch.bmm(g1[1:].transpose(1, 2), self.tac[:-1]).sum(0)
+        go = 3 if self.mode == 2 else 0
+        w1[:, go:go + 3] = torch.bmm(g1.transpose(1, 2), self.gl).sum(0)
+        if self.mode == 0:
+            # x = [gl, tactile frame before the env-step]: tac0 for frame 0, the previous frame's read-out otherwise (no concatenated copy)
+            w1[:, 3:] = g1[0].t() @ self.tac0
+            if T > 1:
+                w1[:, 3:] += torch.bmm(g1[1:].transpose(1, 2), self.tac[:-1]).sum(0)
+        elif self.mode == 2:
+            # x = [box pose in the gripper frame of the state before the env-step, gl] (tactile_push_env.py:96-106)
+            qb = torch.cat([self.q0.unsqueeze(0), self.q[:-1]], dim=0)
+            th = qb[:, :, 0]
+            c, s_ = torch.cos(th), torch.sin(th)
+            obj = torch.stack([c * qb[:, :, 3] + s_ * qb[:, :, 4] - qb[:, :, 1], -s_ * qb[:, :, 3] + c * qb[:, :, 4] - qb[:, :, 2], qb[:, :, 6] - th], dim=2)
+            w1[:, 0:3] = torch.bmm(g1.transpose(1, 2), obj).sum(0)
         l1.weight.grad, l1.bias.grad = w1, g1.sum((0, 1))
         l2.weight.grad, l2.bias.grad = torch.bmm(g2.transpose(1, 2), self.h1).sum(0), g2.sum((0, 1))
         l3.weight.grad, l3.bias.grad = torch.bmm(g3.transpose(1, 2), self.h2).sum(0), g3.sum((0, 1))

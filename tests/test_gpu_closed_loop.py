@@ -19,21 +19,31 @@ def _episode(B, T, seed):
     return q0, goal, dist
 
 
+@pytest.mark.parametrize("observation_type", ["no_tactile", "privilege"])
+@pytest.mark.parametrize("lanes", [16, 64])
+@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-3)])
+def test_fused_episode_with_the_other_observation_types(pusher_model, dtype, tol_q, tol_g, lanes, observation_type):
+    """cfg/gd_no_tactile.yaml / gd_privilege.yaml on the fused path: 3 / 6 policy inputs; the privileged observation adds a path from
+    the box pose of the state before a frame to the policy, which the adjoint launch returns to that state's adjoint."""
+    test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes, observation_type)
+
+
 @pytest.mark.parametrize("lanes", [16, 32, 64])
 @pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-3)])
-def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes):
+def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes, observation_type="tactile_flatten"):
     from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
     from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode
     from tactilesimulation_amd.algorithms.batched_gd import Actor, rollout_loss
     B, T = 10, 12                                                    # a batch that is no multiple of the slots per wavefront
     q0, goal, dist = (torch.tensor(a, device="cuda", dtype=dtype) for a in _episode(B, T, 3))
     torch.manual_seed(1)
-    actor = Actor(dtype=dtype).cuda()
+    nin = {"tactile_flatten": 393, "no_tactile": 3, "privilege": 6}[observation_type]
+    actor = Actor(obs_dim=nin, dtype=dtype).cuda()
     with torch.no_grad():                                            # a policy that acts (the initial one outputs ~0)
         for p in actor.parameters():
             p.mul_(3.0)
     # ---- the per-step loop with autograd
-    env = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T)
+    env = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T, observation_type=observation_type)
     env.sim.set_lanes_per_env(lanes)
     obs = env.reset(q0, goal)
     qs, us, total = [], [], obs.new_zeros(())
@@ -45,7 +55,7 @@ def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_
     named = [(n, p) for n, p in actor.named_parameters() if n != "logstd"]
     ref = torch.autograd.grad(total, [p for _, p in named])
     # ---- the fused episode
-    env2 = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T)
+    env2 = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T, observation_type=observation_type)
     env2.sim.set_lanes_per_env(lanes)
     ep = FusedPushEpisode(env2, actor, T)
     loss = ep.rollout(q0, goal, dist)
