@@ -50,6 +50,12 @@ typedef struct tsim_push_policy {
   int obs_mode;      /* observation_type of envs/tactile_push_env.py:72-131: 0 tactile_flatten (393 inputs: goal in the gripper frame, tactile frame;
                         cfg/gd_tactile.yaml), 1 no_tactile (3: the goal; gd_no_tactile.yaml), 2 privilege (6: box pose in the gripper frame, goal;
                         gd_privilege.yaml).  W1T is [inputs][64], W1p [64][w1_stride >= inputs]. */
+  /* Roll-out collection (cfg/ppo_tactile.yaml: the same actor, stochastic, on normalised observations).  All may be NULL. */
+  const void* eps;      /* [T][B][3] standard-normal draws: u = mean + exp(logstd) * eps (the u record holds the sampled action) */
+  const void* logstd;   /* [3] (utils/model.py:123-151 DiagGaussianActor.logstd) */
+  const void *obs_mean, *obs_istd;  /* [inputs] each: observation -> clamp((x - obs_mean) * obs_istd, +-obs_clip) before the first layer (VecNormalize
+                                       with the statistics frozen for the launch); forward-only launches (reset with backward_flag = 0) */
+  double obs_clip;
 } tsim_push_policy;
 
 /* Forward: num_frames env-steps of num_steps sub-steps from the batch's current state; frame f acts with

@@ -60,6 +60,8 @@ __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double t_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float t_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double t_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float t_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double t_min(double a, double b) { return fmin(a, b); }
 
 // ------------------------------------------------------------------------------------------------ 3-vectors / 3x3
 template <class T> struct V3 { T x, y, z; };

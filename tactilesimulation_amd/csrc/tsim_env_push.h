@@ -136,6 +136,7 @@ static PushPolicy<R> make_push_policy(const tsim_push_policy* p) {
   memset(&P, 0, sizeof(P));
   P.W1T = (const R*)p->W1T; P.b1 = (const R*)p->b1; P.W2T = (const R*)p->W2T; P.b2 = (const R*)p->b2; P.W3 = (const R*)p->W3; P.b3 = (const R*)p->b3;
   P.W1p = (const R*)p->W1p; P.W2 = (const R*)p->W2; P.w1s = p->w1_stride;
+  P.eps = (const R*)p->eps; P.logstd = (const R*)p->logstd; P.obs_mean = (const R*)p->obs_mean; P.obs_istd = (const R*)p->obs_istd; P.obs_clip = (R)p->obs_clip;
   P.mode = p->obs_mode; P.nin = push_obs_len(p->obs_mode); P.nin_pad = (P.nin + PP_ROWS1 - 1) / PP_ROWS1 * PP_ROWS1;
   return P;
 }
@@ -146,6 +147,9 @@ static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, i
   if (TS_PAIR_GROUP * ((int)PP_SIZE + b->nr * (int)PT_SIZE) < 64 * (int)PP_OCH + 2 * (int)PP_HID) return fail(std::string(who) + ": the pair-staging records are too small for the policy scratch");
   if (!pol->W1T || !pol->b1 || !pol->W2T || !pol->b2 || !pol->W3 || !pol->b3) return fail(std::string(who) + ": policy weights missing");
   if (push_obs_len(pol->obs_mode) < 0) return fail(std::string(who) + ": obs_mode must be 0 (tactile_flatten), 1 (no_tactile) or 2 (privilege)");
+  if (pol->eps && !pol->logstd) return fail(std::string(who) + ": eps without logstd");
+  if ((pol->obs_mean != nullptr) != (pol->obs_istd != nullptr)) return fail(std::string(who) + ": obs_mean and obs_istd come together");
+  if (pol->obs_mean && b->record) return fail(std::string(who) + ": observation normalisation is for roll-out collection (reset with backward_flag = False); the adjoint launch does not undo it");
   if (b->dFenv) return fail(std::string(who) + ": per-environment tables are not supported in the closed-loop launch");
   return 0;
 }

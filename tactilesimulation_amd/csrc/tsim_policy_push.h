@@ -25,6 +25,10 @@ template <class R> struct PushPolicy {
   const R *W1T, *b1, *W2T, *b2, *W3, *b3;      // forward layouts
   const R *W1p, *W2; int w1s;                  // backward layouts (row stride of W1p)
   int mode, nin, nin_pad;                      // observation type (TSIM_PUSH_OBS_*), its length (393 / 3 / 6), padded to a multiple of PP_ROWS1
+  // roll-out collection (PPO): the stochastic policy u = mean + exp(logstd) eps, observations normalised with FIXED statistics
+  const R* eps;                                // [T][B][3] standard-normal draws, or null (deterministic: gd.py)
+  const R* logstd;                             // [3]
+  const R *obs_mean, *obs_istd; R obs_clip;    // [nin] each: x -> clamp((x - mean) * istd, +-clip), or null (forward-only launches)
   const R* goal;                               // [B][3] goal pose (x, y, yaw)
   const R* dist;                               // [T][B][2] external force on the box per env-step
   const R* tac0;                               // [B][390] tactile at the initial state (tsim_readout after the reset)
@@ -120,6 +124,11 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
       S.xs[lane] = lane == 0 ? (R)(cs * ox + sn * oy - c.q0D[1]) : (lane == 1 ? (R)(-sn * ox + cs * oy - c.q0D[2]) : (R)(c.q0D[6] - c.q0D[0]));
     }
   }
+  if (P.obs_mean) {                                    // VecNormalize with frozen statistics (a2c_ppo_acktr envs.py: norm_obs, clip_obs)
+    TS_SYNC();
+    const int nin = ts_u(P.nin);
+    for (int i = lane; i < nin; i += LPE) S.xs[i] = t_min(t_max((S.xs[i] - P.obs_mean[i]) * P.obs_istd[i], -P.obs_clip), P.obs_clip);
+  }
   TS_SYNC();
   R acc[NS], w[OPL];
   {
@@ -161,6 +170,7 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
 #pragma unroll
     for (int o = 0; o < OPL; ++o) s += w[o] * h2[o];
     up[a_] = seg_sum<LPE>(s) + P.b3[a_];
+    if (P.eps) up[a_] += (R)exp((double)P.logstd[a_]) * P.eps[rec * 3 + a_];       // the sampled action; u_out records it
   }
   TS_SYNC();                                           // scr is the pair staging of the next evaluation
   // action mapping (tactile_push_env.py:175-193): [tanh(u), force on the box, 0]

@@ -60,7 +60,46 @@ class FusedPushEpisode:
             setattr(self._pol, n, t.data_ptr())
         self._pol.w1_stride = self.w1s
         self._pol.obs_mode = self.mode
+        sample, norm = getattr(self, "_sample", None), getattr(self, "_norm", None)
+        self._pol.eps, self._pol.logstd = (sample[0].data_ptr(), sample[1].data_ptr()) if sample else (None, None)
+        self._pol.obs_mean, self._pol.obs_istd, self._pol.obs_clip = (norm[0].data_ptr(), norm[1].data_ptr(), norm[2]) if norm else (None, None, 0.0)
         return C.byref(self._pol)
+
+    def collect(self, q0, goal, disturbances, eps=None, obs_mean=None, obs_var=None, obs_clip=10.0, var_eps=1e-8):
+        """One episode of roll-out collection as cfg/ppo_tactile.yaml runs it (the same actor, stochastic, on normalised observations),
+        without a tape: u = mean + exp(logstd) eps with eps [T, B, 3] standard-normal draws (None: the deterministic mean), the
+        observation normalised as VecNormalize does — clamp((obs - mean) / sqrt(var + 1e-8), +-clip) — with the statistics frozen for
+        the episode (None: raw observations).  Returns dict(obs [T, B, nin] raw observations the policy saw before each env-step,
+        action [T, B, 3] (pre-tanh, as the env takes it), reward [T, B], q, var)."""
+        self._sample = None
+        if eps is not None:
+            eps = eps.to(self.dev, self.dt).contiguous()
+            assert tuple(eps.shape) == (self.T, self.B, 3)
+            self._sample = (eps, self.actor.logstd.detach().to(self.dev, self.dt).contiguous())
+        self._norm = None
+        if obs_mean is not None:
+            m = obs_mean.to(self.dev, self.dt).reshape(-1).contiguous()
+            istd = (1.0 / torch.sqrt(obs_var.to(self.dev, torch.float64).reshape(-1) + var_eps)).to(self.dt).contiguous()
+            assert m.numel() == self.nin and istd.numel() == self.nin
+            self._norm = (m, istd, float(obs_clip))
+        try:
+            self.rollout(q0, goal, disturbances, record=False)
+        finally:
+            self._sample = self._norm = None
+        return {"obs": self.observations(), "action": self.u, "reward": self.rewards, "q": self.q, "var": self.var}
+
+    def observations(self):
+        """[T, B, nin]: the (raw) observation in front of every env-step of the last roll-out, assembled from its records."""
+        if self.mode == 0:
+            tprev = torch.cat([self.tac0.unsqueeze(0), self.tac[:-1]], dim=0)
+            return torch.cat([self.gl, tprev], dim=2)
+        if self.mode == 1:
+            return self.gl
+        qb = torch.cat([self.q0.unsqueeze(0), self.q[:-1]], dim=0)
+        th = qb[:, :, 0]
+        c, s_ = torch.cos(th), torch.sin(th)
+        obj = torch.stack([c * qb[:, :, 3] + s_ * qb[:, :, 4] - qb[:, :, 1], -s_ * qb[:, :, 3] + c * qb[:, :, 4] - qb[:, :, 2], qb[:, :, 6] - th], dim=2)
+        return torch.cat([obj, self.gl], dim=2)
 
     def evaluate(self, q0, goal, disturbances):
         """The episode without a tape (algorithms/gd.py:265-290 evaluates the deterministic policy this way between epochs): per-environment
@@ -96,6 +135,7 @@ class FusedPushEpisode:
         self.df_dq[:, :, 6] = (0.2 * k) * dr
         self.df_dvar = torch.cat([5000.0 * dt_, -5000.0 * dt_], dim=2)
         self.du_direct = 0.2 * self.u
+        self.rewards = rew                                          # [T, B]
         self.returns = rew.sum(0)                                   # per environment
         self.loss = -rew.sum()
         return self.loss

@@ -53,7 +53,8 @@ EXPORTS = sorted(_SIGS)
 
 class PushPolicyStruct(C.Structure):
     """include/tsim_env.h tsim_push_policy"""
-    _fields_ = [(n, C.c_void_p) for n in ("W1T", "b1", "W2T", "b2", "W3", "b3", "W1p", "W2")] + [("w1_stride", C.c_int), ("obs_mode", C.c_int)]
+    _fields_ = [(n, C.c_void_p) for n in ("W1T", "b1", "W2T", "b2", "W3", "b3", "W1p", "W2")] + [("w1_stride", C.c_int), ("obs_mode", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("eps", "logstd", "obs_mean", "obs_istd")] + [("obs_clip", C.c_double)]
 
 
 def lib():

@@ -136,3 +136,54 @@ def test_simulator_gradients_in_the_regime_a_trained_policy_reaches():
     assert f32["q_err_max"] < 5e-6 and f64["q_err_max"] < 1e-10, (f32, f64)
     assert f32["branch_agree"] >= out["subset"] - 2 and f64["branch_agree"] == out["subset"], (f32, f64)
     assert f32["grad_err_max_agreeing"] < 1e-4 and f64["grad_err_max_agreeing"] < 1e-8, (f32, f64)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 3e-5)])
+def test_collection_with_the_stochastic_policy_on_normalised_observations(pusher_model, dtype, tol):
+    """cfg/ppo_tactile.yaml: the same 393-64-64-3 actor, sampled (u = mean + exp(logstd) eps), on observations normalised and clipped
+    with frozen statistics — inside the forward launch (FusedPushEpisode.collect), against the per-step loop in torch."""
+    from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
+    from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode
+    from tactilesimulation_amd.algorithms.batched_gd import Actor
+    B, T = 21, 12
+    q0, goal, dist = (torch.tensor(a, device="cuda", dtype=dtype) for a in _episode(B, T, 7))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    eps = torch.randn(T, B, 3, generator=g, dtype=torch.float64).to("cuda", dtype)
+    mean = (torch.randn(393, generator=g, dtype=torch.float64) * 0.05).to("cuda", dtype)
+    var = (torch.rand(393, generator=g, dtype=torch.float64) * 0.01 + 1e-6).to("cuda", dtype)      # small: the clip at 3 does act
+    torch.manual_seed(4)
+    actor = Actor(dtype=dtype).cuda()
+    with torch.no_grad():
+        for p in actor.parameters():
+            p.mul_(2.0)
+        actor.logstd.fill_(-0.7)
+    norm = lambda o: torch.clamp((o - mean) / torch.sqrt(var.double() + 1e-8).to(dtype), -3.0, 3.0)
+    env = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=False, seed=0, tape_steps=T)
+    obs = env.reset(q0, goal)
+    O, U, R, Q = [], [], [], []
+    with torch.no_grad():
+        for t in range(T):
+            O.append(obs.clone())
+            u = actor(norm(obs)) + torch.exp(actor.logstd) * eps[t]
+            obs, rew, info = env.step(u, dist[t])
+            U.append(u.clone()); R.append(rew.clone()); Q.append(info["q"].clone())
+    clipped = float((norm(torch.stack(O)).abs() == 3.0).double().mean())
+    assert 0.0 < clipped < 0.9, clipped
+    env2 = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=False, seed=0, tape_steps=T)
+    ep = FusedPushEpisode(env2, actor, T)
+    out = ep.collect(q0, goal, dist, eps=eps, obs_mean=mean, obs_var=var, obs_clip=3.0)
+    assert int((ep.status != 0).sum()) == 0 and env2.sim.tape_len() == 0
+    sc = lambda a: max(1.0, float(a.abs().max()))
+    assert float((out["q"] - torch.stack(Q)).abs().max()) < tol
+    assert float((out["action"] - torch.stack(U)).abs().max()) < 50 * tol * sc(torch.stack(U))
+    assert float((out["obs"] - torch.stack(O)).abs().max()) < 50 * tol * sc(torch.stack(O))
+    assert float((out["reward"] - torch.stack(R)).abs().max()) < 200 * tol * sc(torch.stack(R))
+    # the deterministic, un-normalised collection is evaluate()
+    out2 = ep.collect(q0, goal, dist)
+    ret = ep.evaluate(q0, goal, dist)
+    assert torch.equal(out2["reward"].sum(0), ret)
+    # statistics are for collection only: a recorded roll-out refuses them
+    ep._norm = (mean.contiguous(), mean.contiguous(), 3.0)
+    with pytest.raises(RuntimeError):
+        ep.rollout(q0, goal, dist, record=True)
+    ep._norm = None
