@@ -26,6 +26,9 @@ CASES = {
     # name: (q0, u sampler, T, S)
     "point_fall": (np.zeros(3), lambda r: r.uniform(-1, 1, 3), 6, 3),
     "box_rest": (np.zeros(3), lambda r: np.zeros(0), 6, 5),
+    # both regimes of the tangential penalty law (creep below the Coulomb limit, sliding above) and lift-off, with closed forms in
+    # tests/test_oracle_physics.py::test_friction_creep_and_sliding_closed_forms
+    "box_slide": (np.array([0.0, 0.0, -6e-4]), lambda r: np.array([r.uniform(-0.1, 0.9), r.uniform(-0.5, 0.5), r.uniform(-0.3, 0.55)]), 16, 4),
     "pendulum": (np.array([0.7, -0.4]), lambda r: r.uniform(-1, 1, 2), 8, 4),
     "slider_push": (np.zeros(4), lambda r: np.array([r.uniform(0.2, 1.0)]), 16, 4),
     "dclaw_position_control": (None, None, 10, 5),

@@ -283,3 +283,35 @@ def test_bdf2_adjoint_matches_finite_differences(name, nsub0, T):
     assert np.abs(Gfd).max() > 1e-3
     assert np.abs(G - Gfd).max() < 1e-6 * np.abs(Gfd).max(), np.abs(G - Gfd).max() / np.abs(Gfd).max()
     assert np.abs(lv - lvf).max() < 1e-6 * np.abs(lvf).max(), np.abs(lv - lvf).max() / np.abs(lvf).max()
+
+
+def test_friction_creep_and_sliding_closed_forms():
+    """The tangential penalty law ft = -min(kt |vt|, mu |fn|) vt/|vt| on a cube pushed along the ground (4 corner points, N = m g):
+    below the Coulomb limit the box creeps at the velocity where 4 kt v balances the push, above it the discrete (BDF1) velocity grows by
+    h (F - mu m g) / m per sub-step — exactly, the force being constant — and the vertical equilibrium m g = 4 kn d is not disturbed."""
+    m = _model("box_slide")
+    o = OracleSim(m)
+    o.reset(np.zeros(3))
+    mass, g, kn, kt, mu, h = 0.5, 9.8, 2e3, 5.0, 0.8, m.h
+    assert o.forward(np.zeros(3), 4000) == 0                       # settle
+    force = lambda F: np.array([F / 10.0, 0.0, 0.0])               # ctrl_range [-10, 10] N
+    assert o.forward(force(1.0), 4000) == 0                        # 1 N < mu m g = 3.92 N
+    q, qd = o.state()
+    assert abs(qd[0] - 1.0 / (4 * kt)) < 1e-8 and abs(qd[1]) < 1e-14 and abs(qd[2]) < 1e-12
+    assert abs(q[2] + mass * g / (4 * kn)) < 1e-9
+    assert o.forward(force(6.0), 40) == 0                          # 6 N: through the creep regime into sliding (v > mu N / (4 kt) = 0.196)
+    _, v0 = o.state()
+    assert v0[0] > mu * mass * g / (4 * kt)
+    n = 40
+    assert o.forward(force(6.0), n) == 0
+    q, v1 = o.state()
+    assert abs((v1[0] - v0[0]) - n * h * (6.0 - mu * mass * g) / mass) < 1e-10
+    assert abs(q[2] + mass * g / (4 * kn)) < 1e-9 and abs(v1[2]) < 1e-12
+    # pushed along the diagonal the friction force opposes the velocity direction: the same growth of |v|
+    o.reset(np.zeros(3)); assert o.forward(np.zeros(3), 4000) == 0
+    d = np.array([0.6, 0.6, 0.0]) / np.sqrt(2.0)
+    assert o.forward(d, 80) == 0
+    _, va = o.state()
+    assert o.forward(d, n) == 0
+    _, vb = o.state()
+    assert abs(va[0] - va[1]) < 1e-12 and abs((np.hypot(vb[0], vb[1]) - np.hypot(va[0], va[1])) - n * h * (6.0 - mu * mass * g) / mass) < 1e-10
