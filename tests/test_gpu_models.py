@@ -29,6 +29,8 @@ CASES = {
     # both regimes of the tangential penalty law (creep below the Coulomb limit, sliding above) and lift-off, with closed forms in
     # tests/test_oracle_physics.py::test_friction_creep_and_sliding_closed_forms
     "box_slide": (np.array([0.0, 0.0, -6e-4]), lambda r: np.array([r.uniform(-0.1, 0.9), r.uniform(-0.5, 0.5), r.uniform(-0.3, 0.55)]), 16, 4),
+    # 3 x 3 taxels pressed flat onto a block, no gravity: the tactile law's closed forms are in tests/test_oracle_physics.py
+    "pad_press": (np.array([0.0, 0.0, -1e-3, 0.0, 0.0, 0.0]), lambda r: np.zeros(0), 8, 4),
     "pendulum": (np.array([0.7, -0.4]), lambda r: r.uniform(-1, 1, 2), 8, 4),
     "slider_push": (np.zeros(4), lambda r: np.array([r.uniform(0.2, 1.0)]), 16, 4),
     "dclaw_position_control": (None, None, 10, 5),
@@ -180,3 +182,22 @@ def test_per_environment_tables_domain_randomisation(pusher_model):
     sim.set_env_tables(None)        # back to the shared model
     sim.reset(torch.tensor(q0), None, False)
     sim.step(torch.tensor(u[:, 0]), 5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-14), (torch.float32, 2e-7)])
+def test_tactile_read_out_closed_forms_on_the_kernels(dtype, tol):
+    """The tactile law's closed forms (tests/test_oracle_physics.py::test_tactile_law_closed_forms) asserted on the HIP read-out itself,
+    without the oracle in between: five environments = the five (velocity) cases, plus one lifted off."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    m = _load("pad_press")
+    kn, kt, mu, kd, d = 1e2, 8.0, 1.0, 1e1, 1e-3
+    q = np.zeros((6, 6)); q[:, 2] = -d; q[5, 2] = 1e-4
+    qd = np.zeros((6, 6))
+    qd[1, 0] = 0.002; qd[2, 3] = 0.002; qd[3, 0] = 0.5; qd[4, 1], qd[4, 2] = 0.3, -0.01
+    fn4 = (kn + kd * 0.01) * d
+    want = np.array([[0, 0, -kn * d], [kt * 0.002, 0, -kn * d], [-kt * 0.002, 0, -kn * d], [mu * kn * d, 0, -kn * d], [0, mu * fn4, -fn4], [0, 0, 0]])
+    sim = BatchSim(m, 6, dtype=dtype, tape_capacity=0)
+    sim.reset(torch.tensor(q, device="cuda", dtype=dtype), torch.tensor(qd, device="cuda", dtype=dtype), backward_flag=False)
+    _, tac = sim.readout(want_var=False)
+    tac = tac.double().cpu().numpy().reshape(6, 9, 3)
+    assert np.abs(tac - want[:, None, :]).max() <= tol, np.abs(tac - want[:, None, :]).max()

@@ -315,3 +315,32 @@ def test_friction_creep_and_sliding_closed_forms():
     assert o.forward(d, n) == 0
     _, vb = o.state()
     assert abs(va[0] - va[1]) < 1e-12 and abs((np.hypot(vb[0], vb[1]) - np.hypot(va[0], va[1])) - n * h * (6.0 - mu * mass * g) / mass) < 1e-10
+
+
+def test_tactile_law_closed_forms():
+    """A 3 x 3-taxel pad pressed flat onto a block by d = 1 mm, no gravity (tests/models/pad_press.xml; tactile kn 1e2, kt 8, mu 1,
+    damping 1e1 as in pusher.xml:11): every taxel reads, in its own frame (axis0, axis1, normal),
+      normal  -(kn - kd ddot) d          negative under compression (utils/tactile_utils.py:18,28),
+      shear   min(kt |vt|, mu fn)        against the taxel's motion relative to the block."""
+    m = _model("pad_press")
+    assert (m.ndof_r, m.ndof_tactile) == (6, 27)
+    o = OracleSim(m)
+    kn, kt, mu, kd, d = 1e2, 8.0, 1.0, 1e1, 1e-3
+    q = np.zeros(6); q[2] = -d                                     # the taxel plane is the block's top face at q = 0
+
+    def read(qd):
+        o.reset(q, np.asarray(qd, dtype=float))
+        return o.outputs()[1].reshape(9, 3)
+    t = read(np.zeros(6))
+    assert np.allclose(t, np.tile([0.0, 0.0, -kn * d], (9, 1)), rtol=0, atol=1e-15)
+    t = read([0.002, 0, 0, 0, 0, 0])                               # creeping along +x: axis0 = -x, the force opposes the motion
+    assert np.allclose(t, np.tile([kt * 0.002, 0.0, -kn * d], (9, 1)), rtol=0, atol=1e-15)
+    t = read([0, 0, 0, 0.002, 0, 0])                               # the block moves instead: the opposite shear
+    assert np.allclose(t, np.tile([-kt * 0.002, 0.0, -kn * d], (9, 1)), rtol=0, atol=1e-15)
+    t = read([0.5, 0, 0, 0, 0, 0])                                 # sliding: the Coulomb limit
+    assert np.allclose(t, np.tile([mu * kn * d, 0.0, -kn * d], (9, 1)), rtol=0, atol=1e-15)
+    t = read([0, 0.3, -0.01, 0, 0, 0])                             # pressing in at 1 cm/s while sliding along +y (axis1 = -y)
+    fn = (kn + kd * 0.01) * d
+    assert np.allclose(t, np.tile([0.0, mu * fn, -fn], (9, 1)), rtol=0, atol=1e-15)
+    q[2] = 1e-4                                                    # lifted off: nothing
+    assert not read(np.zeros(6)).any()
