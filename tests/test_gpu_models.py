@@ -201,3 +201,41 @@ def test_tactile_read_out_closed_forms_on_the_kernels(dtype, tol):
     _, tac = sim.readout(want_var=False)
     tac = tac.double().cpu().numpy().reshape(6, 9, 3)
     assert np.abs(tac - want[:, None, :]).max() <= tol, np.abs(tac - want[:, None, :]).max()
+
+
+def test_dynamics_closed_forms_on_the_kernels():
+    """Closed-form mechanics asserted on the HIP path itself (fp64 kernels), not through the oracle: discrete free fall under a force
+    motor (tests/test_oracle_physics.py::test_discrete_free_fall_and_force_motor), the rest penetration m g / (4 kn) of a cube on its
+    corners, and the two regimes of the friction law (creep at F / (4 kt), sliding with h (F - mu m g) / m per sub-step)."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    dt = torch.float64
+    t = lambda a: torch.tensor(np.asarray(a, dtype=float), device="cuda", dtype=dt)
+    # free fall: v_n = a h n, z_n = a h^2 n (n + 1) / 2
+    m = _load("point_fall", tol=1e-12)
+    sim = BatchSim(m, 2, dtype=dt, tape_capacity=0)
+    sim.reset(t(np.zeros((2, 3))), None, backward_flag=False)
+    n, h = 50, m.h
+    out = sim.step(t([[0.5, -1.0, 0.0], [0.0, 0.0, 1.0]]), n, want_qd=True, want_var=False, want_tactile=False)
+    acc = np.array([[1.0, -2.0, -9.8], [0.0, 0.0, -9.8 + 2.0]])
+    assert np.abs(out["qd"].cpu().numpy() - acc * n * h).max() < 1e-10
+    assert np.abs(out["q"].cpu().numpy() - acc * h * h * n * (n + 1) / 2).max() < 1e-10
+    # friction: environment 0 creeps under 1 N, environment 1 slides under 6 N, environment 2 is pushed along the diagonal
+    m = _load("box_slide", tol=1e-12)
+    mass, g, kn, kt, mu, h = 0.5, 9.8, 2e3, 5.0, 0.8, m.h
+    sim = BatchSim(m, 3, dtype=dt, tape_capacity=0)
+    sim.reset(t(np.zeros((3, 3))), None, backward_flag=False)
+    out = sim.step(t(np.zeros((3, 3))), 4000, want_qd=True, want_var=False, want_tactile=False)
+    assert int(out["status"].sum()) == 0
+    assert np.abs(out["q"].cpu().numpy()[:, 2] + mass * g / (4 * kn)).max() < 1e-9               # rest penetration
+    d = 0.6 / np.sqrt(2.0)
+    u = t([[0.1, 0, 0], [0.6, 0, 0], [d, d, 0]])
+    o1 = sim.step(u, 4000, want_qd=True, want_var=False, want_tactile=False)
+    v1 = o1["qd"].cpu().numpy()
+    assert abs(v1[0, 0] - 1.0 / (4 * kt)) < 1e-8                                                   # creep
+    nn = 40
+    o2 = sim.step(u, nn, want_qd=True, want_var=False, want_tactile=False)
+    v2 = o2["qd"].cpu().numpy()
+    growth = nn * h * (6.0 - mu * mass * g) / mass
+    assert abs((v2[1, 0] - v1[1, 0]) - growth) < 1e-9                                              # sliding
+    assert abs((np.hypot(*v2[2, :2]) - np.hypot(*v1[2, :2])) - growth) < 1e-9 and abs(v2[2, 0] - v2[2, 1]) < 1e-12
+    assert np.abs(o2["q"].cpu().numpy()[:, 2] + mass * g / (4 * kn)).max() < 1e-9
