@@ -31,6 +31,8 @@ CASES = {
     "box_slide": (np.array([0.0, 0.0, -6e-4]), lambda r: np.array([r.uniform(-0.1, 0.9), r.uniform(-0.5, 0.5), r.uniform(-0.3, 0.55)]), 16, 4),
     # 3 x 3 taxels pressed flat onto a block, no gravity: the tactile law's closed forms are in tests/test_oracle_physics.py
     "pad_press": (np.array([0.0, 0.0, -1e-3, 0.0, 0.0, 0.0]), lambda r: np.zeros(0), 8, 4),
+    # limit spring, joint damping, PD position motor — closed forms in tests/test_oracle_physics.py::test_joint_space_laws_closed_forms
+    "joint_laws": (np.array([0.02, 0.0, 0.3]), lambda r: np.array([r.uniform(-1, 1), r.uniform(-1, 1), r.uniform(-1.5, 1.5)]), 10, 4),
     "pendulum": (np.array([0.7, -0.4]), lambda r: r.uniform(-1, 1, 2), 8, 4),
     "slider_push": (np.zeros(4), lambda r: np.array([r.uniform(0.2, 1.0)]), 16, 4),
     "dclaw_position_control": (None, None, 10, 5),
@@ -239,3 +241,12 @@ def test_dynamics_closed_forms_on_the_kernels():
     assert abs((v2[1, 0] - v1[1, 0]) - growth) < 1e-9                                              # sliding
     assert abs((np.hypot(*v2[2, :2]) - np.hypot(*v1[2, :2])) - growth) < 1e-9 and abs(v2[2, 0] - v2[2, 1]) < 1e-12
     assert np.abs(o2["q"].cpu().numpy()[:, 2] + mass * g / (4 * kn)).max() < 1e-9
+    # joint-space laws: limit spring (q = hi + F / k, lo - F / k), terminal velocity F / d, PD servo on its target
+    m = _load("joint_laws", tol=1e-12)
+    sim = BatchSim(m, 2, dtype=dt, tape_capacity=0)
+    sim.reset(t(np.zeros((2, 3))), None, backward_flag=False)
+    o3 = sim.step(t([[0.5, 0.5, 0.7], [-0.25, 0.5, -0.4]]), 6000, want_qd=True, want_var=False, want_tactile=False)
+    q3, v3 = o3["q"].cpu().numpy(), o3["qd"].cpu().numpy()
+    assert int(o3["status"].sum()) == 0
+    assert abs(q3[0, 0] - (0.03 + 1.0 / 50.0)) < 1e-9 and abs(q3[1, 0] - (-0.02 - 0.5 / 50.0)) < 1e-9
+    assert np.abs(v3[:, 1] - 0.5).max() < 1e-10 and abs(q3[0, 2] - 0.7) < 1e-10 and abs(q3[1, 2] + 0.4) < 1e-10

@@ -344,3 +344,20 @@ def test_tactile_law_closed_forms():
     assert np.allclose(t, np.tile([0.0, mu * fn, -fn], (9, 1)), rtol=0, atol=1e-15)
     q[2] = 1e-4                                                    # lifted off: nothing
     assert not read(np.zeros(6)).any()
+
+
+def test_joint_space_laws_closed_forms():
+    """tests/models/joint_laws.xml, no gravity, no contact: a prismatic joint pushed past its limits rests where the limit spring
+    balances the push (q = hi + F / k, lo - F / k: `lim`, `lim_stiffness`), a damped joint reaches the terminal velocity F / d, a PD
+    position motor (ctrl="position": P (u - q) - D qd, tactile_insertion.xml:91-92) settles on its target."""
+    m = _model("joint_laws")
+    o = OracleSim(m)
+    o.reset(np.zeros(3))
+    assert o.forward(np.array([0.5, 0.5, 0.7]), 6000) == 0           # force motors: ctrl_range [-2, 2] N -> +1 N, +1 N; servo target 0.7 rad
+    q, qd = o.state()
+    assert abs(q[0] - (0.03 + 1.0 / 50.0)) < 1e-9 and abs(qd[0]) < 1e-8
+    assert abs(qd[1] - 1.0 / 2.0) < 1e-10
+    assert abs(q[2] - 0.7) < 1e-10 and abs(qd[2]) < 1e-10
+    assert o.forward(np.array([-0.25, 0.5, -0.4]), 6000) == 0         # -0.5 N: the lower limit
+    q, qd = o.state()
+    assert abs(q[0] - (-0.02 - 0.5 / 50.0)) < 1e-9 and abs(q[2] + 0.4) < 1e-10 and abs(qd[1] - 0.5) < 1e-10
