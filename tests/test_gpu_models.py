@@ -33,6 +33,8 @@ CASES = {
     "pad_press": (np.array([0.0, 0.0, -1e-3, 0.0, 0.0, 0.0]), lambda r: np.zeros(0), 8, 4),
     # limit spring, joint damping, PD position motor — closed forms in tests/test_oracle_physics.py::test_joint_space_laws_closed_forms
     "joint_laws": (np.array([0.02, 0.0, 0.3]), lambda r: np.array([r.uniform(-1, 1), r.uniform(-1, 1), r.uniform(-1.5, 1.5)]), 10, 4),
+    # sphere primitive on the ground: one moving contact point (closed forms in tests/test_oracle_physics.py)
+    "sphere_rest": (np.array([0.0, 0.0, -1.3e-4]), lambda r: np.array([r.uniform(-0.2, 0.9), r.uniform(-0.4, 0.4), r.uniform(-0.3, 0.5)]), 12, 4),
     "pendulum": (np.array([0.7, -0.4]), lambda r: r.uniform(-1, 1, 2), 8, 4),
     "slider_push": (np.zeros(4), lambda r: np.array([r.uniform(0.2, 1.0)]), 16, 4),
     "dclaw_position_control": (None, None, 10, 5),

@@ -361,3 +361,21 @@ def test_joint_space_laws_closed_forms():
     assert o.forward(np.array([-0.25, 0.5, -0.4]), 6000) == 0         # -0.5 N: the lower limit
     q, qd = o.state()
     assert abs(q[0] - (-0.02 - 0.5 / 50.0)) < 1e-9 and abs(q[2] + 0.4) < 1e-10 and abs(qd[1] - 0.5) < 1e-10
+
+
+def test_sphere_on_ground_closed_forms():
+    """A sphere's ground contact is ONE moving point, the lowest point of the sphere (tactile_pad.xml's ball): rest penetration m g / kn,
+    creep at F / kt, sliding with h (F - mu m g) / m per sub-step (tests/models/sphere_rest.xml, translational joint: no rolling)."""
+    m = _model("sphere_rest")
+    o = OracleSim(m)
+    o.reset(np.zeros(3))
+    mass, g, kn, kt, mu, h = 2000.0 * 4.0 / 3.0 * np.pi * 0.02 ** 3, 9.8, 5e3, 2.0, 0.8, m.h
+    assert o.forward(np.zeros(3), 4000) == 0
+    q, qd = o.state()
+    assert abs(q[2] + mass * g / kn) < 1e-9
+    assert o.forward(np.array([0.1, 0, 0]), 4000) == 0                # 0.1 N < mu m g = 0.525 N
+    assert abs(o.state()[1][0] - 0.1 / kt) < 1e-7
+    assert o.forward(np.array([0.9, 0, 0]), 400) == 0
+    va = o.state()[1][0]
+    assert o.forward(np.array([0.9, 0, 0]), 40) == 0
+    assert abs((o.state()[1][0] - va) - 40 * h * (0.9 - mu * mass * g) / mass) < 1e-9
