@@ -379,3 +379,26 @@ def test_sphere_on_ground_closed_forms():
     va = o.state()[1][0]
     assert o.forward(np.array([0.9, 0, 0]), 40) == 0
     assert abs((o.state()[1][0] - va) - 40 * h * (0.9 - mu * mass * g) / mass) < 1e-9
+
+
+def _cyl_cases():
+    kn, kt, mu, kd, d = 1e2, 8.0, 1.0, 1e1, 1e-3
+    q = np.zeros((6, 6)); q[:, 0] = -d; q[5, 2] = 0.035             # case 5: the pad slid up the post, its top taxel beyond the cap's edge
+    qd = np.zeros((6, 6)); qd[1, 2] = 0.002; qd[2, 1] = 0.002; qd[3, 2] = 0.9; qd[4, 0] = -0.01
+    fn4 = (kn + kd * 0.01) * d
+    row = lambda a, b, c: np.tile([a, b, c], (3, 1))
+    want = np.stack([row(0, 0, -kn * d), row(kt * 0.002, 0, -kn * d), row(0, -kt * 0.002, -kn * d), row(mu * kn * d, 0, -kn * d), row(0, 0, -fn4),
+                     np.array([[0, 0, 0], [0, 0, -kn * d], [0, 0, -kn * d]])])
+    return q, qd, want
+
+
+def test_cylinder_primitive_tactile_closed_forms():
+    """tests/models/cyl_press.xml: a 3-taxel strip pressed radially onto the curved side of a cylinder primitive (the D'Claw cap's type,
+    dclaw_position_control.xml:114): radial depth d -> normal -kn d, shear kt v along the axis / around it against the motion, the Coulomb
+    limit, the damping term, and no force on a taxel past the end cap."""
+    m = _model("cyl_press")
+    o = OracleSim(m)
+    q, qd, want = _cyl_cases()
+    for k in range(len(q)):
+        o.reset(q[k], qd[k])
+        assert np.allclose(o.outputs()[1].reshape(3, 3), want[k], rtol=0, atol=1e-14), k
