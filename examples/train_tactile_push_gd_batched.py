@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="plain python loop, one launch per env-step")
     ap.add_argument("--graphed", action="store_true", help="one launch per env-step, the episode replayed from one HIP graph (algorithms/batched_gd.GraphedRollout)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + TSIM_SHARE_GPU=1: several ranks on one GPU (plumbing tests)")
     ap.add_argument("--observation-type", default="tactile_flatten", choices=["tactile_flatten", "no_tactile", "privilege"],
                     help="cfg/gd_tactile.yaml / gd_no_tactile.yaml / gd_privilege.yaml (tactile_push_env.py:72-131)")
     ap.add_argument("--disturbance-period", type=int, default=1, help="env-steps between new random forces on the box (the reference: 1, see draw_episode)")
@@ -69,11 +70,16 @@ def main():
     args = ap.parse_args()
 
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("TSIM_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     dev, dtype = "cuda:%d" % local, (torch.float32 if args.dtype == "f32" else torch.float64)
     B, T = args.batch, args.horizon
     env = BatchedTactilePushEnv(args.model, B, device=dev, dtype=dtype, gradient=True, seed=args.seed + rank, tape_steps=T, observation_type=args.observation_type)
@@ -116,6 +122,7 @@ def main():
     if rank == 0 and args.save_best and best[2] is not None:
         torch.save({"actor": best[2], "loss_per_episode": best[0], "epoch": best[1]}, args.save_best)
         print("best policy: epoch %d, loss/episode %.3f -> %s" % (best[1], best[0], args.save_best))
+    print("rank %d: parameter checksum %.10e" % (rank, float(sum(p.detach().double().abs().sum() for p in actor.parameters()))), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 

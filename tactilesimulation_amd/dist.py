@@ -22,7 +22,12 @@ def allreduce_policy_grad_(params, global_episodes, group=None):
         return None
     flat = torch.cat([g.reshape(-1) for g in grads])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":      # CPU plumbing runs (several ranks sharing one GPU): through the host
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat /= float(global_episodes)
     off = 0
     for g in grads:

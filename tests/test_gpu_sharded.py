@@ -126,3 +126,25 @@ def test_bench_gpus_2_self_launched_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["ranks"]["ranks_in_first_allreduce"] == 2 and j["ranks"]["shared_gpu"] is True
     assert j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["roofline"]["kernel_ms"]["k_forward"] > 0
+
+
+def test_two_ranks_train_the_fused_loop_to_identical_parameters(tmp_path):
+    """examples/train_tactile_push_gd_batched.py under torch.distributed.run with two ranks sharing this GPU (gloo): every rank rolls out
+    its own environments through the fused closed loop, the flat policy gradient is all-reduced once per epoch, and both ranks must end
+    on the same parameters — which differ from a single rank's (other environments entered the gradient)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, TSIM_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    ex = os.path.join(root, "examples", "train_tactile_push_gd_batched.py")
+    common = ["--batch", "256", "--epochs", "3", "--horizon", "20", "--backend", "gloo"]
+    out2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29531", ex] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    sums = dict((int(r), float(v)) for r, v in re.findall(r"rank (\d+): parameter checksum ([0-9.e+-]+)", out2.stdout))
+    assert set(sums) == {0, 1} and sums[0] == sums[1], sums
+    out1 = subprocess.run([sys.executable, ex] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert out1.returncode == 0, out1.stderr[-2000:]
+    one = float(re.findall(r"rank 0: parameter checksum ([0-9.e+-]+)", out1.stdout)[0])
+    assert one != sums[0]
