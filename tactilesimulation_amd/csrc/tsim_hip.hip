@@ -506,7 +506,11 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
     const V3<R> cA = ldv(sC);
     const R r2 = sC[3];
     const R* px = tax; const R* py = tax + ntax; const R* pz = tax + 2 * ntax;
-    for (int base = (int)blockIdx.y * a.slice; base < te; base += 256 * CH) {
+    // chunks are dealt to the environment's blocks round-robin, not as contiguous slices: the taxels near the primitive lie in a band of
+    // the pad (RollingBall: ~50 of 200 rows), and with contiguous slices two of an environment's eight blocks ran the law for all of them
+    // while the others stored zeros — the kernel lasted as long as those two
+    const int te = ntax;
+    for (int base = (int)blockIdx.y * 256 * CH; base < te; base += (int)gridDim.y * 256 * CH) {
       if (threadIdx.x == 0) sCount = 0;
       __syncthreads();
       V3<R> xa[CH];
