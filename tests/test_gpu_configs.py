@@ -344,3 +344,39 @@ def test_config3_reward_loss_gradient_as_survey_words_it(pusher_model):
           % (ok.sum(), len(idx), np.median(survey), survey.max(), np.median(rel)))
     assert ok.sum() >= len(idx) - 1, (np.sort(survey)[-6:], "environments off: %d" % (~ok).sum())     # the few that crossed a kink (§5)
     assert np.median(survey) < 2e-5 and np.median(rel) < 2e-5 and cos[ok].min() > 1.0 - 1e-8, (np.median(survey), np.median(rel), cos[ok].min())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float64, 1e-12)])
+def test_adjoint_properties_at_full_size(pusher_model, dtype, tol):
+    """Size-independent properties of the adjoint launch on the bench's own batch (B = 4096, 100 env-steps): it is LINEAR in the seeds,
+    CAUSAL (an action after the last seeded frame gets exactly zero), DETERMINISTIC (same tape, same seeds: same bits), and independent of
+    what else is in the batch (the first 1024 environments alone give the same rows)."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    B = 4096
+    q0, u, _ = push_workload(B, T, seed=0)
+    q0t = torch.tensor(q0, device=DEV, dtype=dtype)
+    ut = torch.tensor(u, device=DEV, dtype=dtype).transpose(0, 1).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).to(DEV, dtype)
+    s1 = (rnd(T, B, 7), rnd(T, B, 6), rnd(T, B, 390) * 10.0)
+    s2 = (rnd(T, B, 7), rnd(T, B, 6), rnd(T, B, 390) * 10.0)
+    K = 60                                                          # s2 seeds frames 0..K-1 only
+    for w in s2:
+        w[K:] = 0.0
+    a, b = 0.7, -1.3
+    sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+
+    def grad(seeds, sim_=sim, n=B):
+        sim_.reset(q0t[:n], None, backward_flag=True)
+        ro = sim_.rollout(ut[:, :n], S)
+        assert int((ro["status"] != 0).sum()) == 0
+        return sim_.backward_episode(T, S, *(w[:, :n].contiguous() for w in seeds))
+    d1, d2 = grad(s1), grad(s2)
+    d12 = grad(tuple(a * x + b * y for x, y in zip(s1, s2)))
+    scale = float((a * d1 + b * d2).abs().max())
+    assert float((d12 - (a * d1 + b * d2)).abs().max()) <= tol * scale                      # linear
+    assert float(d2[K:].abs().max()) == 0.0 and float(d2[:K].abs().max()) > 0.0             # causal
+    assert torch.equal(grad(s1), d1)                                                        # deterministic
+    small = BatchSim(pusher_model, 1024, dtype=dtype, tape_capacity=T * S)
+    small.set_lanes_per_env(sim.launch_info()["lanes_per_env"])                             # the same launch shape: the same summation orders
+    assert torch.equal(grad(s1, small, 1024), d1[:, :1024])                                 # batch-composition independent
