@@ -87,7 +87,7 @@ def test_config3_push_b4096_fwd_adjoint_fp32(pusher_model):
     dt = torch.float32
     sim = BatchSim(pusher_model, B, dtype=dt, tape_capacity=T * S)
     info = sim.launch_info()
-    assert info["lanes_per_env"] == 16 and info["blocks"] == 1024, info          # the instantiation bench.py times
+    assert os.environ.get("TSIM_LPE") or (info["lanes_per_env"] == 16 and info["blocks"] == 1024), info   # the instantiation bench.py times (TSIM_LPE: the whole suite under a forced shape)
     sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None, backward_flag=True)
     ud = torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous()
     ro = sim.rollout(ud, S, want_qd=True)

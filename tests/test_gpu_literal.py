@@ -87,7 +87,7 @@ def test_every_substep_lands_on_the_literal_solvers_root(name, B, T, n_sub, tol6
     dt = torch.float64 if dtype == "f64" else torch.float32
     q, qd, bad, info = _hip_substep_states(m, q0, u, dt, S=S)
     if name == "pusher" and dtype == "f32":
-        assert info["lanes_per_env"] == 16 and info["blocks"] == 1024, info          # the instantiation bench.py times
+        assert os.environ.get("TSIM_LPE") or (info["lanes_per_env"] == 16 and info["blocks"] == 1024), info   # the instantiation bench.py times (TSIM_LPE: the whole suite under a forced shape)
     flagged = np.nonzero(bad.any(axis=1))[0]
     # TactilePush and D'Claw converge everywhere.  The insertion inputs close a stiff position-controlled grasp on a randomly offset box:
     # a few environments of the 4096 flag a sub-step of the closing phase (status; test_gpu_configs.py bounds their number) — those
