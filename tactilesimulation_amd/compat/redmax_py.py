@@ -132,6 +132,9 @@ class Simulation:
         self._sim.reset(self._t(self._q_init, self.ndof_r, "q_init"), self._t(self._qdot_init, self.ndof_r, "qdot_init"),
                         backward_flag=self._backward_flag)
         self._dirty_outputs = True
+        # which taped sub-steps had their tactile frame read: the reference's EpisodicSimFunction.backward hands over the gradients of
+        # exactly those frames (envs/redmax_torch_functions.py:55-57,87: sum(mask) x ndof_tactile values, "TODO: change c++ for tactile masks")
+        self._nsub, self._tac_reads = 0, []
 
     def set_u(self, u):
         u = np.asarray(u, dtype=np.float64).reshape(-1)
@@ -140,9 +143,9 @@ class Simulation:
         self._u = u.copy()          # callers mutate their array afterwards (envs/tactile_insertion_env.py:160-163)
 
     def forward(self, num_steps, verbose=False, test_derivatives=False, save_last_frame_var_only=False):
-        if test_derivatives:
-            raise NotImplementedError("test_derivatives: use tests/test_gpu_parity.py (adjoint vs oracle / finite differences)")
         self._sync_model()
+        if test_derivatives:
+            self._check_derivatives(int(num_steps), verbose)
         # high-resolution sensors (RollingBall: 120 000 values) are read out on demand by the read-out kernels instead of after every
         # step (test_sim_speed.py:79 asks for them every 5th step only)
         lazy = self._lazy_tac
@@ -164,6 +167,49 @@ class Simulation:
         self._tac = None if lazy else (h[2 * nr + nv:] if self.ndof_tactile else np.zeros(0))
         self._dirty_outputs = False
         self.last_nonconverged_substeps = st
+        self._nsub = getattr(self, "_nsub", 0) + int(num_steps)
+
+    def _check_derivatives(self, num_steps, verbose):
+        """forward(..., test_derivatives=True) (envs/redmax_torch_functions.py:49,132 pass the flag through): DiffRedMax checks its analytic
+        derivatives against finite differences inside forward() and prints the errors.  Here: the adjoint of the `num_steps` sub-steps
+        about to be taken — dL/du, dL/dq0, dL/dqdot0 of a fixed random linear functional of the final q, variables and tactile frame —
+        against central differences of the same kernels, on scratch batches (the simulation's own state and tape are not touched).
+        The report is printed and kept in `last_derivative_check` (relative errors; a contact / friction kink inside the step shows as a
+        large one, as it does in the reference)."""
+        sim = self._sim
+        nr, nu, nv, nt = self.ndof_r, self.ndof_u, self.ndof_var, self.ndof_tactile
+        q, qd = sim.get_state()
+        u = torch.from_numpy(self._u.copy()).to(self._dev, self._dtype).reshape(1, nu)
+        g = torch.Generator().manual_seed(0)
+        w = lambda n: (torch.rand(1, n, generator=g, dtype=torch.float64) - 0.5).to(self._dev, self._dtype) if n else None
+        wq, wv, wt = w(nr), w(nv), w(nt)
+        a = BatchSim(self._model, 1, device=str(self._dev), dtype=self._dtype, tape_capacity=num_steps)
+        a.reset(q, qd, backward_flag=True)
+        a.step(u, num_steps)
+        du = a.backward_steps(num_steps, wq, wv, wt).double().sum(1)[0].cpu().numpy()
+        lq, lv = (x.double()[0].cpu().numpy() for x in a.get_adjoint())
+        n = nu + 2 * nr
+        eps = 1e-6 if self._dtype == torch.float64 else 1e-3
+        Q, QD, U = q.repeat(2 * n, 1), qd.repeat(2 * n, 1), u.repeat(2 * n, 1)
+        for k in range(n):
+            tgt, j = (U, k) if k < nu else ((Q, k - nu) if k < nu + nr else (QD, k - nu - nr))
+            tgt[2 * k, j] += eps; tgt[2 * k + 1, j] -= eps
+        f = BatchSim(self._model, 2 * n, device=str(self._dev), dtype=self._dtype, tape_capacity=0)
+        f.reset(Q, QD, backward_flag=False)
+        o = f.step(U, num_steps)
+        L = (o["q"].double() * wq.double()).sum(1)
+        if nv:
+            L = L + (o["var"].double() * wv.double()).sum(1)
+        if nt:
+            L = L + (o["tactile"].double() * wt.double()).sum(1)
+        fd = ((L[0::2] - L[1::2]) / (2 * eps)).cpu().numpy()
+        an = np.concatenate([du, lq, lv])
+        rel = lambda x, y: float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30))
+        rep = {"df_du": rel(an[:nu], fd[:nu]), "df_dq0": rel(an[nu:nu + nr], fd[nu:nu + nr]), "df_dqdot0": rel(an[nu + nr:], fd[nu + nr:]),
+               "eps": eps, "num_steps": num_steps}
+        self.last_derivative_check = rep
+        print("[redmax_py shim] test_derivatives over %d sub-step(s): relative error of the adjoint vs central differences: df_du %.3e, "
+              "df_dq0 %.3e, df_dqdot0 %.3e (eps %.0e)" % (num_steps, rep["df_du"], rep["df_dq0"], rep["df_dqdot0"], eps))
 
     def get_q(self):
         self._refresh()
@@ -179,6 +225,8 @@ class Simulation:
 
     def get_tactile_force_vector(self):
         self._refresh()
+        if self._backward_flag and getattr(self, "_nsub", 0) > 0 and (not self._tac_reads or self._tac_reads[-1] != self._nsub - 1):
+            self._tac_reads.append(self._nsub - 1)          # the frame of taped sub-step _nsub - 1 has been handed out
         if self._tac is None:
             _, tac = self._sim.readout(want_var=False)
             if getattr(self, "_host_tac", None) is None:
@@ -212,9 +260,19 @@ class Simulation:
             if a is None or dim == 0:
                 return None
             a = np.asarray(a, dtype=np.float64).reshape(-1)
+            if name == "df_dtactile" and a.size != n * dim:
+                # masked frames only (envs/redmax_torch_functions.py:85-90 with tactile_masks): one block per tactile frame that was READ
+                # among the newest n sub-steps, in the order they were read — scattered to their sub-steps here
+                first = self._nsub - n
+                reads = [t - first for t in self._tac_reads if t >= first]
+                if a.size != len(reads) * dim:
+                    raise RuntimeError("backward_info.df_dtactile has %d values: neither num_steps * %d = %d nor one block for each of the %d "
+                                       "tactile frames read in these sub-steps" % (a.size, dim, n * dim, len(reads)))
+                full = np.zeros((n, dim))
+                full[reads] = a.reshape(len(reads), dim)
+                a = full.reshape(-1)
             if a.size != n * dim:
-                raise RuntimeError("backward_info.%s has %d values, expected num_steps * %d = %d (a tactile gradient that "
-                                   "holds only masked frames must be scattered to all frames first)" % (name, a.size, dim, n * dim))
+                raise RuntimeError("backward_info.%s has %d values, expected num_steps * %d = %d" % (name, a.size, dim, n * dim))
             return self._t(a, n * dim, name)
         return seed(bi.df_dq, nr, "df_dq"), seed(bi.df_dvar, nv, "df_dvar"), seed(bi.df_dtactile, nt, "df_dtactile")
 
@@ -226,6 +284,8 @@ class Simulation:
         du = self._sim.backward_steps(n, a, b, c, all_steps=True)
         self.backward_results.df_du = self._np(du)
         self._dirty_outputs = True
+        self._nsub -= n
+        self._tac_reads = [t for t in self._tac_reads if t < self._nsub]
 
     def backward(self):
         """envs/redmax_torch_functions.py:92 — the whole tape."""
@@ -239,13 +299,18 @@ class Simulation:
 
     def saveBackwardCache(self):
         self._sim.cache_save()
+        # the simulation goes on from its current state on a spare tape, at the same sub-step index (tsim_cache_save)
+        self._cache = getattr(self, "_cache", []) + [(self._nsub, list(self._tac_reads), self._backward_flag)]
 
     def popBackwardCache(self):
         self._sim.cache_pop()
         self._dirty_outputs = True
+        if getattr(self, "_cache", None):
+            self._nsub, self._tac_reads, self._backward_flag = self._cache.pop()
 
     def clearBackwardCache(self):
         self._sim.cache_clear()
+        self._cache = []
 
     # ------------------------------------------------------------------ model edits (domain randomisation)
     def _edit(self, what, name, *args, **kw):

@@ -228,5 +228,6 @@ extern "C" int tsim_push_closed_backward(tsim_batch* b, const tsim_push_policy* 
                                 : push_closed_backward_t<double>(b, pol, goal, num_frames, num_steps, df_dq, df_dvar, du_direct, u_out, h1_out, h2_out, g1_out, g2_out, g3_out, dobs_tac, df_du, (hipStream_t)stream);
   if (rc) return rc;
   b->t_cur -= (int)n;
+  pose_invalidate(b, (hipStream_t)stream);
   return 0;
 }

@@ -338,18 +338,24 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
 // wavefront are sub-step-synchronous, so two expensive environments in one wavefront cost the sum of their per-sub-step
 // maxima (measured: a batch sorted by work runs 22 % slower than the unsorted one, profiles/r01_imbalance_exp.json).
 // Runs on the same stream right after k_forward.
-__global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* order, int B, int ns) {
+// Episode launches (nframes > 1) are ordered by the per-environment TOTALS of the previous episode launch of the same length — useful
+// when consecutive episodes resemble each other (the bench replays one table; a GD epoch with fixed start states and a slowly
+// changing policy), harmless when they do not (any order is a valid one).  bin = (evals - lo) * 64 / span maps the totals onto the
+// 64 bins (lo = 2 evaluations per sub-step, the minimum of a converging Newton loop; span = 2.5 per sub-step); per-step launches keep
+// bin = evals (lo 0, span 64).
+__global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* order, int B, int ns, int lo, int span) {
   __shared__ int hist[64], base[64];
   const int t = threadIdx.x;
   if (t < 64) hist[t] = 0;
   __syncthreads();
-  for (int e = t; e < B; e += 1024) atomicAdd(&hist[min(evals[e], 63)], 1);
+  auto bin = [lo, span](int ev) { return min(max((ev - lo) * 64 / span, 0), 63); };
+  for (int e = t; e < B; e += 1024) atomicAdd(&hist[bin(evals[e])], 1);
   __syncthreads();
   if (t == 0) { int acc = 0; for (int k = 63; k >= 0; --k) { base[k] = acc; acc += hist[k]; } }
   __syncthreads();
   const int nwaves = (B + ns - 1) / ns;
   for (int e = t; e < B; e += 1024) {
-    const int r = atomicAdd(&base[min(evals[e], 63)], 1);       // rank of environment e, 0 = most expensive
+    const int r = atomicAdd(&base[bin(evals[e])], 1);           // rank of environment e, 0 = most expensive
     order[(r % nwaves) * ns + r / nwaves] = e;                  // slot r / nwaves of wavefront r % nwaves (B % ns == 0)
   }
 }
@@ -987,6 +993,7 @@ struct tsim_batch {
   float* gnorm = nullptr;        // largest ||g|| a sub-step of the last forward launch ended with, per env
   int cross_kinks = 0, eval_budget = 0;     // tsim_set_solver_options
   int* order; int order_valid;   // block -> env map for the next forward launch (LPT scheduling)
+  int* order_ep = nullptr; int order_ep_n = 0;   // ... for the next EPISODE launch of order_ep_n sub-steps (from the previous one's totals; survives reset)
   void* prev; int has_prev;      // BDF2: state before the previous sub-step [B][2 nr]
   void* poseR; double* poseD; int nspt;   // tsim_readout: pose records [B][nspt] of the (sensor, primitive) combinations (k_readout -> k_taxels)
   int has_exp;                   // model contains a rotation-vector joint
@@ -1205,7 +1212,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   FwdArgs<R> a;
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = tac_slot;
   a.tape = (R*)b->tape; a.u = (const R*)u;
-  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->order_valid && b->B >= 256 && nframes == 1) ? b->order : nullptr;
+  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->B >= 256 && nframes == 1 && b->order_valid) ? b->order : (b->B >= 256 && nframes > 1 && b->order_ep_n == nframes * nsub && !getenv("TSIM_NO_EPISODE_LPT")) ? b->order_ep : nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
   a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm;
   const bool emit = pose_emit(b, st);
@@ -1213,13 +1220,18 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
   b->pose_valid = emit ? 1 : 0;
-  if (nframes > 1) b->order_valid = 0;     // the per-env counts are episode totals: no use for the next launch's order
-  else if (b->B >= 256) {
-    const int ns = TS_WAVE / launch_shape(b).lpe;
-    hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B, (b->B % ns == 0) ? ns : 1);
+  if (b->B >= 256) {
+    const int ns = TS_WAVE / launch_shape(b).lpe, nsv = (b->B % ns == 0) ? ns : 1;
+    if (nframes > 1) {          // episode totals: the order of the next episode launch of this length (kept across resets)
+      const int n = nframes * nsub;
+      hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order_ep, b->B, nsv, 2 * n, std::max(1, 5 * n / 2));
+      b->order_ep_n = n; b->order_valid = 0;
+    } else {
+      hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B, nsv, 0, 64);
+      b->order_valid = 1;
+    }
     HIPCHK(hipGetLastError());
-    b->order_valid = 1;
-  }
+  } else if (nframes > 1) b->order_valid = 0;
   return 0;
 }
 
@@ -1284,7 +1296,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)2 * B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)2 * B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->gnorm, (size_t)B * sizeof(float)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
+      hipMalloc(&b->lamv, (size_t)2 * B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->gnorm, (size_t)B * sizeof(float)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->order_ep, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
       (b->nspt > 0 && (hipMalloc(&b->poseR, (size_t)B * b->nspt * TP_R_SIZE * b->esz) != hipSuccess || hipMalloc((void**)&b->poseD, (size_t)B * b->nspt * TP_D_SIZE * sizeof(double)) != hipSuccess))) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
@@ -1301,7 +1313,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   DeviceGuard guard_(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
   for (void* p : b->pool) (void)hipFree(p);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD);
   delete b;
 }
 
@@ -1321,7 +1333,7 @@ int tsim_launch_info(const tsim_batch* b, int32_t* out) {
 int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
   if (lanes != 0 && lanes != 16 && lanes != 32 && lanes != 64) return fail("set_lanes_per_env: 0 (automatic), 16, 32 or 64");
   b->lpe_forced = lanes;
-  b->order_valid = 0;
+  b->order_valid = 0; b->order_ep_n = 0;
   // the contact-point staging decision depends on the shape: redo it, the flag lives in the device copy of the schedule
   const int old = b->stage_cpt;
   b->stage_cpt = 0;
@@ -1485,6 +1497,7 @@ int tsim_backward_steps(tsim_batch* b, int n, int seed_mode, const void* df_dq, 
                                 : launch_backward<double>(b, n, stride, 0, nullptr, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
   if (rc) return rc;
   b->t_cur -= n;
+  pose_invalidate(b, (hipStream_t)stream);      // the pose records a forward launch left are those of the state before the roll-back
   return 0;
 }
 
@@ -1512,6 +1525,7 @@ int tsim_backward_episode(tsim_batch* b, int num_frames, int num_steps, const in
                                 : launch_backward<double>(b, (int)n, num_steps, 1, tactile_slot, df_dq, df_dvar, df_dtac, df_du, (hipStream_t)stream);
   if (rc) return rc;
   b->t_cur -= (int)n;
+  pose_invalidate(b, (hipStream_t)stream);
   return 0;
 }
 
@@ -1543,6 +1557,10 @@ int tsim_cache_save(tsim_batch* b, void* stream) {
   // the simulation goes on from its current state: carry the newest record (q, qd of all environments) over
   const size_t rec_bytes = (size_t)b->B * b->rec * b->esz, off = (size_t)b->t_cur * rec_bytes;
   HIPCHK(hipMemcpyAsync((char*)spare + off, (char*)b->tape + off, rec_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  // ... and, for BDF2 models, the record before it: while recording, k_forward takes the state before the previous sub-step from tape
+  // record t0 - 1, so a forward launch that continues on the spare buffer must find it there
+  if (b->I[TSIM_IH_INTEGRATOR] == 2 && b->t_cur >= 1)
+    HIPCHK(hipMemcpyAsync((char*)spare + off - rec_bytes, (char*)b->tape + off - rec_bytes, rec_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   CacheEntry e; e.buf = b->tape; e.len = b->t_cur; e.record = b->record;
   b->cache.push_back(e);
   b->tape = spare;

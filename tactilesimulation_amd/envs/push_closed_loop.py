@@ -52,8 +52,10 @@ class FusedPushEpisode:
         """The layouts the kernels read (tiny copies; the parameters themselves stay torch's)."""
         l1, l2, l3 = self.lin
         with torch.no_grad():
-            self._w = [l1.weight.t().contiguous(), l1.bias.contiguous(), l2.weight.t().contiguous(), l2.bias.contiguous(),
-                       l3.weight.contiguous(), l3.bias.contiguous(), self.W1p, l2.weight.contiguous()]
+            # snapshots, all eight: .contiguous() on an already-contiguous parameter returns the parameter itself, and an optimizer step
+            # between rollout() and backward() would then pair new W2 / W3 / biases with the old transposes and the old forward records
+            self._w = [l1.weight.t().contiguous(), l1.bias.clone(), l2.weight.t().contiguous(), l2.bias.clone(),
+                       l3.weight.clone(), l3.bias.clone(), self.W1p, l2.weight.clone()]
             self.W1p[:, :self.nin].copy_(l1.weight)
         for n, t in zip(("W1T", "b1", "W2T", "b2", "W3", "b3", "W1p", "W2"), self._w):
             assert t.dtype == self.dt and t.device == self.dev

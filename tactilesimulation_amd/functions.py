@@ -90,15 +90,10 @@ class EpisodicSimFunction(autograd.Function):
         sim.backward_info.set_flags(flag_q0=ctx.need_q0, flag_qdot0=ctx.need_qdot0, flag_p=False, flag_u=ctx.need_du)
         sim.backward_info.df_dq = df_dq.reshape(-1).detach().cpu().numpy()
         sim.backward_info.df_dvar = df_dvar.reshape(-1).detach().cpu().numpy()
-        # Deviation from the reference (its TODO at envs/redmax_torch_functions.py:69): the reference hands the
-        # simulator only the masked tactile frames; here they are scattered to all T frames so that each gradient row
-        # lands on the sub-step it belongs to.
-        nt = sim.ndof_tactile
-        full = np.zeros((T, nt))
-        mask = np.asarray([bool(m) for m in ctx.tactile_masks])
-        if nt and mask.any():
-            full[mask] = df_dtactile.reshape(-1, nt).detach().cpu().numpy()
-        sim.backward_info.df_dtactile = full.reshape(-1)
+        # As the reference does (envs/redmax_torch_functions.py:87): only the frames the mask selected, sum(mask) x ndof_tactile values.
+        # The simulator knows which sub-steps had their tactile frame read (compat/redmax_py.py records every get_tactile_force_vector()
+        # after a forward) and puts each block on its sub-step.
+        sim.backward_info.df_dtactile = df_dtactile.reshape(-1).detach().cpu().numpy()
         sim.backward_info.df_dq0 = np.zeros(sim.ndof_r)
         sim.backward_info.df_dqdot0 = np.zeros(sim.ndof_r)
         sim.backward_info.df_du = np.zeros(sim.ndof_u * T)

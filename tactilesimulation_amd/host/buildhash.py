@@ -32,3 +32,30 @@ def read(lib):
 def write(lib, value):
     with open(sidecar(lib), "w") as fh:
         fh.write(value + "\n")
+
+
+# ---------------------------------------------------------------------------------------------------- the HIP library's recipe
+# One description of what libtsim_hip.so is built from, resolved from THIS file's location: __graft_entry__.build() compiles with it and
+# host/capi.py checks the sidecar against it without importing anything from the repository root (an import that fails silently would
+# skip the check — exactly the stale-library situation the sidecar exists to catch).
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(_PKG, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
+HIP_SO = os.path.join(CSRC, "libtsim_hip.so")
+# -amdgpu-function-calls=false: every device function is inlined into its kernel (LDS pointers stay LDS pointers; out-of-line calls
+#   would pass them as flat pointers, which is slower and trips a backend assertion here)
+# -Os, not -O3: the simulation kernels are one 8 - 9 k-instruction body per wavefront, four wavefronts of a CU at four places of it;
+#   13 % fewer static instructions measured 1 - 2 % faster on every bench leg (profiles/r03_pmc_wait_decomposition.md)
+# -fno-slp-vectorize: packing scalar fp32 math into v_pk_* pairs costs more v_mov than it saves FMAs here and pushes the kernels over
+#   256 registers (measured: +9 %, profiles/r01_launch_shape_ab.txt)
+HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-function-calls=false"]
+
+
+def hip_sources():
+    """Every source next to the library (a new header cannot be forgotten) + the three public headers."""
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    return [os.path.join(CSRC, f) for f in srcs] + [os.path.join(INCLUDE, f) for f in ("tsim.h", "tsim_blob.h", "tsim_env.h")]
+
+
+def hip_digest():
+    return digest(hip_sources(), HIP_FLAGS)

@@ -72,3 +72,25 @@ def test_state_changes_outside_forward_launches_recompute(dtype):
     _, t2 = sim.readout(want_var=False)
     t2 = t2.reshape(sim.B, -1)
     assert not (t2[::2] != 0).any() and (t2[1::2] != 0).any()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_a_backward_launch_invalidates_the_pose_records(dtype):
+    """After a recorded forward launch and a backward launch the live state is the rolled-back one (tape record t_cur): the tactile read-out
+    must describe THAT state, with or without the variables (the pose records of the pre-backward state were reused)."""
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.host.batch import BatchSim
+    m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "tactile_pad.npz"))
+    B, n = 3, 60
+    sim = BatchSim(m, B, dtype=dtype, tape_capacity=n)
+    sim.reset(torch.zeros(B, sim.ndof_r, device=sim.device, dtype=dtype), None, backward_flag=True)
+    u = torch.zeros(n, B, sim.ndof_u, device=sim.device, dtype=dtype); u[:, :, 2] = 0.2
+    u[:, :, 0] = torch.linspace(-0.05, 0.05, B, device=sim.device, dtype=dtype)
+    sim.rollout(u, 1, want_tactile=False, want_var=False)
+    _, t_end = sim.readout(want_var=False)
+    assert (t_end != 0).any()
+    sim.backward_steps(n - 5, torch.zeros(B, sim.ndof_r, device=sim.device, dtype=dtype))       # back to sub-step 5: the pad is still in the air
+    _, t_fast = sim.readout(want_var=False)
+    _, t_full = sim.readout(want_var=True)
+    assert torch.equal(t_fast, t_full)
+    assert not (t_fast != 0).any()

@@ -258,3 +258,92 @@ def test_reference_env_call_protocols_replay_on_the_shim(which, asset_name, size
             "insertion": {"update_contact_parameters", "update_tactile_parameters", "clearBackwardCache", "set_state_init", "get_tactile_force_vector"}}[which]
     assert need <= set(seen)
     assert np.all(np.isfinite(sim.get_q())) and np.abs(sim.get_q()).max() < 5.0
+
+
+def test_reference_episodic_protocol_c2_forward_and_backward_with_partial_masks():
+    """SURVEY.md App. C.2 on the real simulator: EpisodicSimFunction on the TactileInsertion model (ndof_r 12, ndof_u 6, ndof_var 0,
+    ndof_tactile 780), T = 4, tactile_masks [F, T, F, T], grad_mode True.  The backward hands the shim sum(mask) x 780 = 1560 tactile
+    gradients, as the reference's function does (envs/redmax_torch_functions.py:85-90; tests/test_protocol.py pins that call for call); the
+    shim puts each block on the sub-step whose frame was read.  Values and all three gradients against the fp64 oracle, which is given
+    the gradient already scattered."""
+    import redmax_py as redmax
+    from tactilesimulation_amd.functions import EpisodicSimFunction
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd import workloads as W
+    from oracle.oracle import OracleSim
+    m = _tight(load_model(W.asset("tactile_insertion")))
+    sim = redmax.Simulation(m)
+    assert (sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile) == (12, 6, 0, 780)
+    q0s, u = W.insertion_attempt_workload(1, seed=3)
+    T = 4
+    acts = torch.tensor(u[0, :T], dtype=torch.float64, requires_grad=True)
+    q0 = torch.tensor(q0s[0], dtype=torch.float64, requires_grad=True)
+    qd0 = torch.zeros(12, dtype=torch.float64, requires_grad=True)
+    mask = torch.tensor([False, True, False, True])
+    qs, vs, ts = EpisodicSimFunction.apply(q0, qd0, acts, mask, sim, True)
+    assert qs.shape == (T, 12) and vs.shape == (T, 0) and ts.shape == (2, 780)
+    wt = torch.tensor(np.random.default_rng(5).normal(size=(2, 780)))
+    (qs[:, 6:9].sum() + 40.0 * (ts * wt).sum()).backward()
+    o = OracleSim(m); o.reset(q0s[0], np.zeros(12), record=True)
+    for t in range(T):
+        assert o.forward(u[0, t], 1) == 0
+        assert np.abs(qs[t].detach().numpy() - o.state()[0]).max() < 1e-10
+    dq = np.zeros((T, 12)); dq[:, 6:9] = 1
+    dt = np.zeros((T, 780)); dt[1] = 40 * wt[0].numpy(); dt[3] = 40 * wt[1].numpy()
+    du = o.backward_steps(T, dq, None, dt)
+    lq, lv = o.adjoint()
+    assert np.abs(acts.grad.numpy() - du).max() < 1e-7 * np.abs(du).max()
+    assert np.abs(q0.grad.numpy() - lq).max() < 1e-7 * np.abs(lq).max()
+    assert np.abs(qd0.grad.numpy() - lv).max() < 1e-7 * np.abs(lv).max()
+    # a gradient that fits neither all frames nor the frames that were read is refused
+    qs, vs, ts = EpisodicSimFunction.apply(q0, qd0, acts, mask, sim, True)
+    sim.popBackwardCache()
+    sim.backward_info.set_flags(False, False, False, True)
+    sim.backward_info.df_dq = np.zeros(T * 12); sim.backward_info.df_dvar = np.zeros(0)
+    sim.backward_info.df_dtactile = np.zeros(3 * 780)
+    with pytest.raises(RuntimeError):
+        sim.backward()
+
+
+def test_forward_with_test_derivatives_runs_the_finite_difference_check(pusher_model, capsys):
+    """forward(num_steps, test_derivatives=True) (envs/redmax_torch_functions.py:49,132 pass the flag through): the shim checks the adjoint of
+    those sub-steps against central differences of the kernels, prints the report, and then steps as usual (same state as without)."""
+    import redmax_py as redmax
+    m = _tight(pusher_model)
+    q0, u, _ = push_workload(1, 3, seed=31)
+    a, b = redmax.Simulation(m), redmax.Simulation(m)
+    for s in (a, b):
+        s.set_q_init(q0[0]); s.reset(True)
+    for t in range(3):
+        a.set_u(u[0, t]); a.forward(5, verbose=False, test_derivatives=True)
+        b.set_u(u[0, t]); b.forward(5)
+        rep = a.last_derivative_check
+        assert rep["num_steps"] == 5 and max(rep["df_du"], rep["df_dq0"], rep["df_dqdot0"]) < 1e-5, rep
+        assert np.array_equal(a.get_q(), b.get_q()) and np.array_equal(a.get_tactile_force_vector(), b.get_tactile_force_vector())
+    assert "test_derivatives over 5 sub-step(s)" in capsys.readouterr().out
+    assert a._sim.tape_len() == b._sim.tape_len() == 15
+
+
+def test_bdf2_backward_cache_save_and_continue():
+    """saveBackwardCache in the middle of a recorded BDF2 roll-out, then stepping on: the spare tape must carry the state before
+    the previous sub-step too — k_forward takes the BDF2 history from tape record t0 - 1 while recording."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.workloads import asset
+    from oracle.oracle import OracleSim
+    m = load_model(asset("tactile_pad"))                     # the reference's BDF2 model (assets/tactile_pad/tactile_pad.xml:2)
+    B, n1, n2 = 2, 30, 20
+    u = np.zeros((B, n1 + n2, 3)); u[:, :, 2] = 0.2; u[:, 20:, 0] = 0.1; u[1, 20:, 1] = -0.05
+    sim = BatchSim(m, B, dtype=torch.float64, tape_capacity=n1 + n2)
+    sim.reset(torch.zeros(B, 9, dtype=torch.float64, device="cuda"), None, backward_flag=True)
+    U = torch.tensor(u, device="cuda").transpose(0, 1).contiguous()
+    sim.rollout(U[:n1], 1, want_tactile=False)
+    sim.cache_save()                                         # tape swapped for a spare one; the simulation goes on
+    ro = sim.rollout(U[n1:], 1, want_tactile=False)
+    assert int(ro["status"].abs().max()) == 0
+    for e in range(B):
+        o = OracleSim(m); o.reset(np.zeros(9))
+        for t in range(n1 + n2):
+            o.forward(u[e, t], 1)
+            if t >= n1:
+                assert np.abs(ro["q"][t - n1, e].cpu().numpy() - o.state()[0]).max() < 1e-9, (e, t)
