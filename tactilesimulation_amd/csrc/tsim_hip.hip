@@ -413,6 +413,15 @@ template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int
 // number of records; per record: primitive type, contact pair) is a MODEL constant: the host builds it once (build_sched, ts_tax_table)
 // so that the prologue is one cooperative copy instead of a serial walk of dependent global loads by thread 0.
 enum { TX_MAXS = 16, TX_MAXK = 64 };
+// the three outputs of a taxel.  -DTS_TAX_NT (A/B): as non-temporal stores — the read-out is a pure write stream (1.97 GB at 4096 environments,
+// 7 x the Infinity Cache) that nothing on the device reads back
+template <class R> __device__ __forceinline__ void ts_store3(R* o, R a, R b, R c) {
+#ifdef TS_TAX_NT
+  __builtin_nontemporal_store(a, o); __builtin_nontemporal_store(b, o + 1); __builtin_nontemporal_store(c, o + 2);
+#else
+  o[0] = a; o[1] = b; o[2] = c;
+#endif
+}
 #ifndef TS_TAX_UNROLL
 #define TS_TAX_UNROLL 2      // taxels per thread and loop iteration: their loads are in flight together (A/B: profiles/r03_readout_ab.md)
 #endif
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
 #ifdef TS_TAX_ZEROS        // A/B only: the store pattern alone (no taxel arithmetic) — the ceiling of this write stream
     o0 = o1 = o2 = R(0);
 #endif
-    out[3 * t] = o0; out[3 * t + 1] = o1; out[3 * t + 2] = o2;
+    ts_store3(out + 3 * t, o0, o1, o2);
   };
   if (nsensor == 1 && a.nspt == 1 && sC[3] >= R(0)) {
     // One sensor against one bounded primitive (RollingBall's pad and ball, TactilePush's pad and box), in two passes per 1024 taxels:
@@ -530,7 +539,7 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
         const int tr = base + (int)threadIdx.x + 256 * r;
         if (tr < te) {
           const V3<R> dc = xa[r] - cA;
-          if (dot3(dc, dc) > r2) { out[3 * tr] = R(0); out[3 * tr + 1] = R(0); out[3 * tr + 2] = R(0); }
+          if (dot3(dc, dc) > r2) ts_store3(out + 3 * tr, R(0), R(0), R(0));
           else sList[atomicAdd(&sCount, 1)] = tr;
         }
       }

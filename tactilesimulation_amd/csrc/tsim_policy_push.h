@@ -83,6 +83,37 @@ __device__ __forceinline__ void pp_dense64(const R* W, int nrows, int wrows, con
   }
 }
 
+// MFMA A/B (-DTS_PP_MFMA; fp32, four environments per wavefront only).  The dense layers are the one contraction-shaped piece of this
+// path with a non-trivial K: out[unit j][env s] = sum_k W[k][j] x_s[k], i.e. per wavefront a (64 x K) (K x 4) product, K = 393 / 64.
+// v_mfma_f32_4x4x1_16b_f32 does one k of it per instruction: 16 blocks of (4 x 1)(1 x 4); block b takes A from lanes 4b .. 4b+3 (lane l: W[k][l],
+// exactly what the coalesced row load leaves in the lanes) and B from the same lanes (lane l: x_{l % 4}[k], one LDS read with a per-lane
+// address), and lane 4b + s accumulates D_b[0..3][s] = units 4b .. 4b+3 of environment s in four registers.  Per weight row: 1 global load,
+// 1 LDS read, 1 MFMA (8 cycles) against 1 load, 4 broadcast reads and 4 FMAs (16 cycles) on the vector ALU.  Full fp32 FMAs, another
+// summation order.  Result layout differs from pp_dense64 (lane = unit): lane 4b + s holds ITS environment's units 4b + i.
+// Measured: profiles/r04_mfma_ab.md.
+#ifdef TS_PP_MFMA
+typedef float pp_v4f __attribute__((ext_vector_type(4)));
+template <int ROWS>
+__device__ __forceinline__ pp_v4f pp_dense64_mfma(const float* W, int nrows, int wrows, const float* x0, int stride) {
+  const float* Wj = W + threadIdx.x;
+  const float* xl = x0 + ((int)threadIdx.x & 3) * stride;
+  pp_v4f d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;      // four independent accumulation chains: no MFMA waits for the one before it
+  for (int i0 = 0; i0 < nrows; i0 += ROWS) {
+    float wb[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wb[r] = Wj[(size_t)min(i0 + r, wrows - 1) * PP_HID];
+#pragma unroll
+    for (int r = 0; r < ROWS; r += 4) {
+      d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[r], xl[i0 + r], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[r + 1], xl[i0 + r + 1], d1, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[r + 2], xl[i0 + r + 2], d2, 0, 0, 0);
+      d3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb[r + 3], xl[i0 + r + 3], d3, 0, 0, 0);
+    }
+  }
+  return (d0 + d1) + (d2 + d3);
+}
+#endif
+
 // Observation -> action for the environment of this slot.  tac_prev: the tactile frame the observation is built from (global; written by
 // this slot, hence the fence + bypassing loads).  q (double, the state before the frame) gives the goal in the gripper frame.
 // Writes c.u (the 6 actuator inputs of the frame) and the forward records.
@@ -131,14 +162,28 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
   }
   TS_SYNC();
   R acc[NS], w[OPL];
-  {
-    const R bj = P.b1[threadIdx.x];
+#ifdef TS_PP_MFMA
+  constexpr bool kMfma = sizeof(R) == 4 && NS == 4;
+#else
+  constexpr bool kMfma = false;
+#endif
+  if constexpr (kMfma) {
+#ifdef TS_PP_MFMA
+    const pp_v4f d = pp_dense64_mfma<PP_ROWS1>((const float*)P.W1T, ts_u(P.nin_pad), ts_u(P.nin), (const float*)S.xs0, S.stride);
+    const int u0 = (int)threadIdx.x & ~3, es = (int)threadIdx.x & 3;          // this lane: units u0 .. u0 + 3 of environment es
 #pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) acc[s_] = bj;
+    for (int i = 0; i < 4; ++i) S.hs0[es * S.stride + u0 + i] = pp_elu((R)d[i] + P.b1[u0 + i]);
+#endif
+  } else {
+    {
+      const R bj = P.b1[threadIdx.x];
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) acc[s_] = bj;
+    }
+    pp_dense64<NS, PP_ROWS1>(P.W1T, ts_u(P.nin_pad), ts_u(P.nin), S.xs0, S.stride, acc);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + threadIdx.x] = pp_elu(acc[s_]);
   }
-  pp_dense64<NS, PP_ROWS1>(P.W1T, ts_u(P.nin_pad), ts_u(P.nin), S.xs0, S.stride, acc);
-#pragma unroll
-  for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + threadIdx.x] = pp_elu(acc[s_]);
   TS_SYNC();
   R h1[OPL];
   pp_ld<OPL>(S.hs + OPL * lane, h1);
@@ -146,15 +191,25 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
 #pragma unroll
     for (int o = 0; o < OPL; ++o) P.h1_out[rec * PP_HID + OPL * lane + o] = h1[o];
   }
-  {
-    const R bj = P.b2[threadIdx.x];
+  if constexpr (kMfma) {
+#ifdef TS_PP_MFMA
+    const pp_v4f d = pp_dense64_mfma<PP_ROWS2>((const float*)P.W2T, PP_HID, PP_HID, (const float*)S.hs0, S.stride);
+    const int u0 = (int)threadIdx.x & ~3, es = (int)threadIdx.x & 3;
+    TS_SYNC();
 #pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) acc[s_] = bj;
+    for (int i = 0; i < 4; ++i) S.hs0[es * S.stride + PP_HID + u0 + i] = pp_elu((R)d[i] + P.b2[u0 + i]);
+#endif
+  } else {
+    {
+      const R bj = P.b2[threadIdx.x];
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) acc[s_] = bj;
+    }
+    pp_dense64<NS, PP_ROWS2>(P.W2T, PP_HID, PP_HID, S.hs0, S.stride, acc);
+    TS_SYNC();
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + PP_HID + threadIdx.x] = pp_elu(acc[s_]);
   }
-  pp_dense64<NS, PP_ROWS2>(P.W2T, PP_HID, PP_HID, S.hs0, S.stride, acc);
-  TS_SYNC();
-#pragma unroll
-  for (int s_ = 0; s_ < NS; ++s_) S.hs0[s_ * S.stride + PP_HID + threadIdx.x] = pp_elu(acc[s_]);
   TS_SYNC();
   R h2[OPL];
   pp_ld<OPL>(S.hs + PP_HID + OPL * lane, h2);

@@ -8,6 +8,9 @@ that exercise the rotation-vector joint.  The oracle differentiates the step equ
 reset: BDF1 start-up, the rest BDF2 — both kinds are in every case below."""
 import os
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _report import rep as _rep
 import numpy as np
 import pytest
 import torch
@@ -88,5 +91,6 @@ def test_bdf2_adjoint_matches_the_oracle(name, dtype, tol_q, tol_g, episode):
         assert rel(G[:, e], Go) < tol_g, (name, e, rel(G[:, e], Go))
         # dL/dq0, dL/dqd0 over 120 sub-steps of the rolling ball in fp32: the rotation-vector exponential is evaluated in fp32 and the
         # ball's contact is stiff — 5.5e-3 / 5.5e-4 measured (fp64: 1e-9); everything else holds the gradient tolerance
+        _rep("site2_bdf2", name=name, dtype=str(dtype), episode=int(episode), env=e, g=rel(G[:, e], Go), lq=rel(lq[e], alq), lv=rel(lv[e], alv))
         tol_l = 2e-2 if (name == "tactile_pad" and dtype == torch.float32) else tol_g
         assert rel(lq[e], alq) < tol_l and rel(lv[e], alv) < tol_l, (name, e, rel(lq[e], alq), rel(lv[e], alv))

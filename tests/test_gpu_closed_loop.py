@@ -3,6 +3,9 @@ against the loop it replaces: algorithms/batched_gd.rollout_loss on BatchedTacti
 env-step as separate launches per env-step with torch autograd in between (itself pinned to the reference's TactilePushEnv and GD class on
 golden vectors: tests/test_env_golden.py, tests/test_gd_loop_golden.py).  Same episode, same policy: the loss, every frame's state and
 policy output, and the gradient of every policy parameter must agree."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _report import rep as _rep
 import numpy as np
 import pytest
 import torch
@@ -68,6 +71,7 @@ def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_
     assert abs(float(loss) - float(total)) < 100 * tol_q * abs(float(total))
     for (n, p), r in zip(named, ref):
         err = float((p.grad - r).norm()) / max(float(r.norm()), 1e-30)
+        _rep("site5_closed_loop", dtype=str(dtype), lanes=lanes, obs=observation_type, param=n, rel=err)
         assert err < tol_g, (n, err)
     assert float(torch.stack([r.norm() for r in ref]).min()) > 0.0   # every parameter does get a gradient
 
@@ -92,6 +96,7 @@ def test_fused_epoch_b4096_trains_and_matches_the_graphed_loop(pusher_model):
     ep.backward()
     assert abs(float(loss) - float(total)) < 1e-4 * abs(float(total))
     for (n, p), r in zip(named, ref):
+        _rep("site5_closed_loop_b4096", param=n, rel=float((p.grad - r).norm()) / float(r.norm()))
         assert float((p.grad - r).norm()) <= 2e-3 * float(r.norm()), (n, float((p.grad - r).norm()) / float(r.norm()))
     opt = torch.optim.Adam(actor.parameters(), lr=5e-3, betas=(0.7, 0.95))
     losses = [float(train_epoch_fused(ep, opt, q0, goal, dist, B)) / B for _ in range(4)]

@@ -6,6 +6,9 @@ import copy
 import os
 import sys
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _report import rep as _rep
 import numpy as np
 import pytest
 import torch
@@ -163,6 +166,7 @@ def test_baseline_worded_sizes_run_and_match_the_oracle(name, B_, T, S, dtype, t
         n = T * S
         st = np.zeros((n, m.ndof_tactile)); st[S - 1::S] = wt
         g = o.backward_steps(n, None, None, st).reshape(T, S, m.ndof_u).sum(1)
+        _rep("site1_layout_grad", name=name, dtype=str(dtype), env=e, rel=np.abs(du[:, e] - g).max() / max(np.abs(g).max(), 1e-12))
         assert np.abs(du[:, e] - g).max() < (1e-6 if dtype == torch.float64 else 2e-2) * max(np.abs(g).max(), 1e-12), (name, e)
     assert tmax > 1e-4, "no taxel touched anything in %s" % name
 

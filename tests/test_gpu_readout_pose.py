@@ -81,7 +81,7 @@ def test_a_backward_launch_invalidates_the_pose_records(dtype):
     from tactilesimulation_amd.model.compiler import load_model
     from tactilesimulation_amd.host.batch import BatchSim
     m = load_model(os.path.join(ROOT, "tactilesimulation_amd", "assets", "tactile_pad.npz"))
-    B, n = 3, 60
+    B, n = 3, 130                                          # the pad reaches the ball after ~100 sub-steps (test_sim_speed.py:43)
     sim = BatchSim(m, B, dtype=dtype, tape_capacity=n)
     sim.reset(torch.zeros(B, sim.ndof_r, device=sim.device, dtype=dtype), None, backward_flag=True)
     u = torch.zeros(n, B, sim.ndof_u, device=sim.device, dtype=dtype); u[:, :, 2] = 0.2

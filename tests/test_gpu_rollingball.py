@@ -4,6 +4,9 @@ redmax_py shim exactly like the reference script drives its simulator."""
 import os
 import sys
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _report import rep as _rep
 import numpy as np
 import pytest
 import torch
@@ -70,5 +73,7 @@ def test_sim_speed_script_sequence(dtype, newton_tol, tq, tt):
             assert tac.shape[0] // 3 == 200 * 200
             _, to = o.outputs()
             q, _ = o.state()
+            _rep("site3_rollingball", dtype=str(dtype), step=i, q=np.abs(sim.get_q() - q).max() / max(1.0, np.abs(q).max()), tac=np.abs(tac - to).max() / max(np.abs(to).max(), 1e-4),
+                 tac_scale=np.abs(to).max(), n_contact_oracle=int((to.reshape(-1, 3)[:, 2] != 0).sum()), n_contact_hip=int((tac.reshape(-1, 3)[:, 2] != 0).sum()))
             assert np.abs(sim.get_q() - q).max() <= tq * max(1.0, np.abs(q).max()), i
             assert np.abs(tac - to).max() <= tt * max(np.abs(to).max(), 1e-4), i

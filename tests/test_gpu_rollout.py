@@ -2,6 +2,9 @@
 46-57, 77-92, as one launch each): bit-identical to the per-step entry points, and checked against the oracle."""
 import os
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+from _report import rep as _rep
 import numpy as np
 import pytest
 import torch
@@ -165,6 +168,8 @@ def test_stable_grasp_episode_matches_oracle(dtype, tq, tt):
             if mask[t]:
                 _, tac = o.outputs()
                 assert np.abs(tac).max() > 1e-3                                       # the pads do press on the object
+                _rep("site4_stable_grasp", dtype=str(dtype), env=e, t=t, tac=np.abs(tacs[k, e] - tac).max() / np.abs(tac).max(), q=np.abs(qs[t, e] - q).max(),
+                     n_contact_oracle=int((tac.reshape(-1, 3)[:, 2] != 0).sum()), n_contact_hip=int((tacs[k, e].reshape(-1, 3)[:, 2] != 0).sum()))
                 assert np.abs(tacs[k, e] - tac).max() < tt * np.abs(tac).max(), (e, t)
                 k += 1
             lifted = max(lifted, q[8])
