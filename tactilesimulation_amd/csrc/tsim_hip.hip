@@ -413,13 +413,14 @@ template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int
 // number of records; per record: primitive type, contact pair) is a MODEL constant: the host builds it once (build_sched, ts_tax_table)
 // so that the prologue is one cooperative copy instead of a serial walk of dependent global loads by thread 0.
 enum { TX_MAXS = 16, TX_MAXK = 64 };
-// the three outputs of a taxel.  -DTS_TAX_NT (A/B): as non-temporal stores — the read-out is a pure write stream (1.97 GB at 4096 environments,
-// 7 x the Infinity Cache) that nothing on the device reads back
+// the three outputs of a taxel, as NON-TEMPORAL stores: the read-out is a pure write stream (0.49 GB at 1024 environments, 1.97 GB at 4096: 2 - 7 x
+// the Infinity Cache) that nothing on the device reads back.  Measured (profiles/r04_readout_hbm.md): 1024 environments 4.45 -> 5.40 TB/s,
+// 4096 environments 4.4 - 4.8 -> 4.7 - 5.0 TB/s; -DTS_TAX_PLAIN restores ordinary stores (A/B).
 template <class R> __device__ __forceinline__ void ts_store3(R* o, R a, R b, R c) {
-#ifdef TS_TAX_NT
-  __builtin_nontemporal_store(a, o); __builtin_nontemporal_store(b, o + 1); __builtin_nontemporal_store(c, o + 2);
-#else
+#ifdef TS_TAX_PLAIN
   o[0] = a; o[1] = b; o[2] = c;
+#else
+  __builtin_nontemporal_store(a, o); __builtin_nontemporal_store(b, o + 1); __builtin_nontemporal_store(c, o + 2);
 #endif
 }
 #ifndef TS_TAX_UNROLL

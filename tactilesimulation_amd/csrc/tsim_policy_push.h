@@ -83,14 +83,17 @@ __device__ __forceinline__ void pp_dense64(const R* W, int nrows, int wrows, con
   }
 }
 
-// MFMA A/B (-DTS_PP_MFMA; fp32, four environments per wavefront only).  The dense layers are the one contraction-shaped piece of this
+// MFMA (fp32, four environments per wavefront; -DTS_PP_NO_MFMA builds the vector-ALU form for every shape: A/B).  The dense layers are the one contraction-shaped piece of this
 // path with a non-trivial K: out[unit j][env s] = sum_k W[k][j] x_s[k], i.e. per wavefront a (64 x K) (K x 4) product, K = 393 / 64.
 // v_mfma_f32_4x4x1_16b_f32 does one k of it per instruction: 16 blocks of (4 x 1)(1 x 4); block b takes A from lanes 4b .. 4b+3 (lane l: W[k][l],
 // exactly what the coalesced row load leaves in the lanes) and B from the same lanes (lane l: x_{l % 4}[k], one LDS read with a per-lane
 // address), and lane 4b + s accumulates D_b[0..3][s] = units 4b .. 4b+3 of environment s in four registers.  Per weight row: 1 global load,
 // 1 LDS read, 1 MFMA (8 cycles) against 1 load, 4 broadcast reads and 4 FMAs (16 cycles) on the vector ALU.  Full fp32 FMAs, another
 // summation order.  Result layout differs from pp_dense64 (lane = unit): lane 4b + s holds ITS environment's units 4b + i.
-// Measured: profiles/r04_mfma_ab.md.
+// Measured: profiles/r04_mfma_ab.md (closed GD epoch 55.8 -> 55.4 ms, +0.8 %: kept).
+#ifndef TS_PP_NO_MFMA
+#define TS_PP_MFMA 1
+#endif
 #ifdef TS_PP_MFMA
 typedef float pp_v4f __attribute__((ext_vector_type(4)));
 template <int ROWS>

@@ -46,7 +46,7 @@ def _case(name):
 
 
 @pytest.mark.parametrize("episode", [False, True])
-@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 5e-6, 2e-4)])
+@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 5e-6, 1e-4)])
 @pytest.mark.parametrize("name", ["pusher", "ball_push", "tactile_pad"])
 def test_bdf2_adjoint_matches_the_oracle(name, dtype, tol_q, tol_g, episode):
     from tactilesimulation_amd.host.batch import BatchSim
@@ -89,8 +89,12 @@ def test_bdf2_adjoint_matches_the_oracle(name, dtype, tol_q, tol_g, episode):
         rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
         assert np.abs(Go).max() > 1e-6                               # the loss does depend on the actions
         assert rel(G[:, e], Go) < tol_g, (name, e, rel(G[:, e], Go))
-        # dL/dq0, dL/dqd0 over 120 sub-steps of the rolling ball in fp32: the rotation-vector exponential is evaluated in fp32 and the
-        # ball's contact is stiff — 5.5e-3 / 5.5e-4 measured (fp64: 1e-9); everything else holds the gradient tolerance
+        # Measured (profiles/r04_fp32_tolerance_sites.md), fp32: dL/du 1.4e-5 (pusher), 1.1e-5 (ball_push), 6.2e-6 (tactile_pad); dL/dq0 /
+        # dL/dqd0 6.6e-5 / 3.1e-5, 4.3e-5 / 2.4e-5 — all inside the 1e-4 of BASELINE.json, asserted as such.  The ONE exception is stated with
+        # its number: dL/dq0 / dL/dqd0 of the rolling ball (tactile_pad.xml) over 120 fp32 sub-steps, 5.5e-3 / 5.5e-4 (fp64: 2.9e-10): the
+        # adjoint of the ball's initial ORIENTATION goes through 120 products of fp32 rotation-vector exponentials (the joint's own arithmetic
+        # is in R; the pose chain around it is double) while the ball rolls without slipping on a stiff contact; dL/du of the same run, which
+        # does not pass through the initial orientation, is at 6.2e-6.  The reference never differentiates this model (test_sim_speed.py:51).
         _rep("site2_bdf2", name=name, dtype=str(dtype), episode=int(episode), env=e, g=rel(G[:, e], Go), lq=rel(lq[e], alq), lv=rel(lv[e], alv))
         tol_l = 2e-2 if (name == "tactile_pad" and dtype == torch.float32) else tol_g
         assert rel(lq[e], alq) < tol_l and rel(lv[e], alv) < tol_l, (name, e, rel(lq[e], alq), rel(lv[e], alv))

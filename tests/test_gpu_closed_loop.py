@@ -24,7 +24,7 @@ def _episode(B, T, seed):
 
 @pytest.mark.parametrize("observation_type", ["no_tactile", "privilege"])
 @pytest.mark.parametrize("lanes", [16, 64])
-@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-3)])
+@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-5)])      # policy gradient, fused vs per-step autograd, per parameter: measured 5.3e-7 (fp32), 1.3e-15 (fp64)
 def test_fused_episode_with_the_other_observation_types(pusher_model, dtype, tol_q, tol_g, lanes, observation_type):
     """cfg/gd_no_tactile.yaml / gd_privilege.yaml on the fused path: 3 / 6 policy inputs; the privileged observation adds a path from
     the box pose of the state before a frame to the policy, which the adjoint launch returns to that state's adjoint."""
@@ -32,7 +32,7 @@ def test_fused_episode_with_the_other_observation_types(pusher_model, dtype, tol
 
 
 @pytest.mark.parametrize("lanes", [16, 32, 64])
-@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-3)])
+@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-5)])      # policy gradient, fused vs per-step autograd, per parameter: measured 5.3e-7 (fp32), 1.3e-15 (fp64)
 def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes, observation_type="tactile_flatten"):
     from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
     from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode
@@ -97,7 +97,7 @@ def test_fused_epoch_b4096_trains_and_matches_the_graphed_loop(pusher_model):
     assert abs(float(loss) - float(total)) < 1e-4 * abs(float(total))
     for (n, p), r in zip(named, ref):
         _rep("site5_closed_loop_b4096", param=n, rel=float((p.grad - r).norm()) / float(r.norm()))
-        assert float((p.grad - r).norm()) <= 2e-3 * float(r.norm()), (n, float((p.grad - r).norm()) / float(r.norm()))
+        assert float((p.grad - r).norm()) <= 2e-5 * float(r.norm()), (n, float((p.grad - r).norm()) / float(r.norm()))      # measured 2.8e-7
     opt = torch.optim.Adam(actor.parameters(), lr=5e-3, betas=(0.7, 0.95))
     losses = [float(train_epoch_fused(ep, opt, q0, goal, dist, B)) / B for _ in range(4)]
     assert losses[-1] < losses[0], losses
@@ -138,7 +138,9 @@ def test_simulator_gradients_in_the_regime_a_trained_policy_reaches():
     import trained_regime_grad_check as T
     out = T.run(40)
     f32, f64 = out["f32"], out["f64"]
-    assert f32["q_err_max"] < 5e-6 and f64["q_err_max"] < 1e-10, (f32, f64)
+    # (the trained policy, hence the regime, depends on the summation order of the in-kernel policy: 3.5e-6 with the vector-ALU layers,
+    # 5.3e-6 with the MFMA layers of round 4 — another 40-epoch trajectory, the same simulator)
+    assert f32["q_err_max"] < 1e-5 and f64["q_err_max"] < 1e-10, (f32, f64)
     assert f32["branch_agree"] >= out["subset"] - 2 and f64["branch_agree"] == out["subset"], (f32, f64)
     assert f32["grad_err_max_agreeing"] < 1e-4 and f64["grad_err_max_agreeing"] < 1e-8, (f32, f64)
 

@@ -167,7 +167,9 @@ def test_baseline_worded_sizes_run_and_match_the_oracle(name, B_, T, S, dtype, t
         st = np.zeros((n, m.ndof_tactile)); st[S - 1::S] = wt
         g = o.backward_steps(n, None, None, st).reshape(T, S, m.ndof_u).sum(1)
         _rep("site1_layout_grad", name=name, dtype=str(dtype), env=e, rel=np.abs(du[:, e] - g).max() / max(np.abs(g).max(), 1e-12))
-        assert np.abs(du[:, e] - g).max() < (1e-6 if dtype == torch.float64 else 2e-2) * max(np.abs(g).max(), 1e-12), (name, e)
+        # BASELINE.json's "gradients within 1e-4 rel of CPU", asserted as stated.  Measured (profiles/r04_fp32_tolerance_sites.md): fp32 1.9e-6
+        # (13 x 13 pad), 1.1e-6 (9 x 9 per finger), 3.7e-5 (32 x 32 pads); fp64 1.5e-12.  (Round 3 stated 2e-2 here, from the round-2 solver.)
+        assert np.abs(du[:, e] - g).max() < (1e-10 if dtype == torch.float64 else 1e-4) * max(np.abs(g).max(), 1e-12), (name, e)
     assert tmax > 1e-4, "no taxel touched anything in %s" % name
 
 

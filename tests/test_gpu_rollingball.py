@@ -53,7 +53,7 @@ def test_exponential_joint_residual_and_newton_matrix(dtype, tol):
         assert np.abs(H[e] - Ho).max() <= tol * np.abs(Ho).max(), (e, np.abs(H[e] - Ho).max() / np.abs(Ho).max())
 
 
-@pytest.mark.parametrize("dtype,newton_tol,tq,tt", [(torch.float64, 1e-13, 1e-8, 1e-5), (torch.float32, None, 5e-4, 5e-2)])
+@pytest.mark.parametrize("dtype,newton_tol,tq,tt", [(torch.float64, 1e-13, 1e-8, 1e-5), (torch.float32, None, 2e-6, 1e-4)])      # measured fp32: q 2.9e-7, tactile 2.2e-5 of the frame's maximum, the same taxels in contact in all 70 read-outs
 def test_sim_speed_script_sequence(dtype, newton_tol, tq, tt):
     import redmax_py as redmax
     from oracle.oracle import OracleSim

@@ -132,7 +132,7 @@ def _grasp_actions(gp, q0):
     return np.array([(tq[s + 1] - tq[s]) / ns[s] * (i + 1) + tq[s] for s in range(len(ns)) for i in range(ns[s])])
 
 
-@pytest.mark.parametrize("dtype,tq,tt", [(torch.float64, 1e-8, 1e-6), (torch.float32, 2e-4, 2e-2)])
+@pytest.mark.parametrize("dtype,tq,tt", [(torch.float64, 1e-8, 1e-6), (torch.float32, 1e-6, 1e-4)])      # measured fp32: q 1.2e-8, tactile 2.0e-5 (same taxels in contact)
 def test_stable_grasp_episode_matches_oracle(dtype, tq, tt):
     """StableGrasp (stable_grasp.xml: 12 dofs, position-controlled gripper, 11 rigidly joined boxes, 2 pads): the env's
     grasp episode through BatchedEpisodicSimFunction with a tactile capture mask, against the oracle frame by frame."""

@@ -254,3 +254,107 @@ def test_insertion_relative_shear_sits_where_the_reference_renders_it():
         mx.append(insertion_relative_shear(fr))
     assert 6e-6 < np.median(mx) < 6e-4, np.median(mx)                  # within a decade of 30 px x 2e-6
     assert 2e-5 < np.median(mx) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------ numbers the reference hard-codes
+def stable_grasp_settled_state(step500):
+    """generate_initial_state() (envs/stable_grasp_env.py:171-188): q_init with height 0.2 and the fingers at -0.03, target = q_init[:6] with
+    3 mm of feed-forward on z, 500 sub-steps.  `step500(q, u)` runs them and returns the final q."""
+    q = np.zeros(12); q[2], q[4], q[5] = 0.2, -0.03, -0.03
+    u = q[:6].copy(); u[2] += 0.003
+    return step500(q, u)
+
+
+def test_stable_grasp_settles_at_the_height_the_reference_hard_codes():
+    """envs/stable_grasp_env.py:198-199 hard-codes `grasp_height = 0.2029862`: the height at which ITS simulator left the position-controlled
+    gripper after generate_initial_state() — seven digits produced by DiffRedMax.  Statics: z = (0.2 + 0.003) - m g / P with P = 400
+    (stable_grasp.xml motor) and m the whole gripper: the base mesh at its stated density 1 (4.910e-4 kg), plus the guide, finger and pad
+    bodies, which state NO density.  The constant therefore measures their mass: (0.203 - 0.2029862) x 400 / 9.8 = 5.633e-4 kg in all,
+    7.2e-5 kg for the six default-density bodies, i.e. default density 1.00 +- 0.06 (a rounding of +-5e-8 m in the constant is +-2e-6 kg).
+    This pins the [CHOICE] "default body density 1.0", the mesh mass properties, gravity on composite links and the position-motor law to a
+    number the reference holds.  (Massless fingers would settle at 0.2029880, density 10 at 0.2029704.)"""
+    m = load_model(W.asset("stable_grasp"))
+    o = OracleSim(m)
+
+    def step500(q, u):
+        o.reset(q)
+        assert o.forward(u, 500) == 0
+        return o.state()[0]
+    q = stable_grasp_settled_state(step500)
+    assert abs(q[2] - 0.2029862) < 6e-8, q[2]                          # all seven digits of the reference's constant
+    mass = (0.203 - q[2]) * 400.0 / 9.8
+    assert abs(mass - (4.910e-4 + 2 * (9.129e-6 + 2.374e-5 + math.pi * 0.018 ** 2 * 0.003))) < 2e-6      # SURVEY App. D volumes at density 1
+    assert np.abs(q[[0, 1, 3]]).max() < 1e-9 and abs(q[4] + 0.03) < 1e-6 and abs(q[5] + 0.03) < 1e-6
+
+
+def stable_grasp_episode(reset, step, q_ref, gp):
+    """grasp() (envs/stable_grasp_env.py:197-246) at grasp position gp: the seven stages, 180 sub-steps; returns q at capture frame 60."""
+    lift, gh, fp = 0.2029862 + 0.03, 0.2029862, -0.008
+    qi = np.array(q_ref, dtype=np.float64); qi[1] = gp
+    tq = [qi[:6].copy()] + [np.array([0.0, gp, h, 0.0, f, f]) for h, f in ((gh, fp), (gh, fp), (lift, fp), (lift, fp), (gh, fp), (gh, fp))] + [np.array([0.0, gp, gh, 0.0, qi[4], qi[5]])]
+    ns = [20, 10, 50, 20, 50, 10, 20]
+    rows = [(tq[s + 1] - tq[s]) / ns[s] * (i + 1) + tq[s] for s in range(7) for i in range(ns[s])]
+    return rows, qi
+
+
+@pytest.mark.parametrize("gp,level", [(0.0, True), (0.01, False), (0.04, False), (-0.05, False)])
+def test_stable_grasp_lifts_level_only_at_the_centre_of_mass(gp, level):
+    """The env's success test (envs/stable_grasp_env.py:262-266): at capture frame 60 the bar's rotation vector is shorter than 0.02 rad and it
+    is more than 5 mm off the table.  The XML's bar is uniform (11 boxes of density 600, stable_grasp.xml:52-88): gripped at its centre it
+    lifts level (|rotvec| < 1e-3); 1 cm off-centre it hangs at 0.065 rad."""
+    m = load_model(W.asset("stable_grasp"))
+    o = OracleSim(m)
+
+    def step500(q, u):
+        o.reset(q); assert o.forward(u, 500) == 0
+        return o.state()[0]
+    q_ref = stable_grasp_settled_state(step500)
+    rows, qi = stable_grasp_episode(None, None, q_ref, gp)
+    o.reset(qi)
+    for t in range(61):
+        assert o.forward(rows[t], 1) == 0
+    q60 = o.state()[0]
+    ang = np.linalg.norm(q60[9:12])
+    assert q60[8] > 0.005                                              # lifted either way
+    assert (ang < 0.02) == level, ang
+    assert ang < 1e-3 if level else ang > 0.05
+
+
+ROLLING_BALL_ACTIONS = [[0, 0, .2]] * 100 + [[.1, 0, .2]] * 50 + [[-.2, 0, .2]] * 50 + [[0, .1, .2]] * 50 + [[0, -.2, .2]] * 100      # test_sim_speed.py:43-48
+
+
+def rolling_ball_peaks(frames):
+    """frames: the 200 x 200 x 3 read-outs of test_sim_speed.py:77-80 (every 5th step) -> per read-out the largest compression (-normal) and the
+    largest shear component, and the number of taxels with a POSITIVE normal component."""
+    mxn, mxs, npos = [], [], 0
+    for t in frames:
+        t = np.asarray(t).reshape(200, 200, 3)
+        mxn.append(float((-t[..., 2]).max())); mxs.append(float(np.abs(t[..., :2]).max())); npos += int((t[..., 2] > 0).sum())
+    return np.array(mxn), np.array(mxs), npos
+
+
+def check_rolling_ball_peaks(mxn, mxs, npos):
+    # utils/tactile_utils.py:28 — the depth image is min(1, -normal / 0.0012): the reference's authors set full white where the ball presses
+    # hardest; :4,18 — the force image turns fully red at -normal = 8e-4 and draws one cell length of arrow at shear = 1.5e-4
+    assert npos == 0                                                   # compression is NEGATIVE in the taxel frame (:18,28)
+    pressed = mxn[mxn > 0]
+    assert 0.8e-3 < np.median(pressed) < 1.5e-3, np.median(pressed)    # oracle: 1.02e-3 — the image is just short of white most of the time
+    assert 1.0e-3 < pressed.max() < 1.8e-3, pressed.max()              # oracle: 1.29e-3 — and saturates (>= 1.2e-3) at the hardest moments
+    sheared = mxs[mxs > 0]
+    assert 0.7e-4 < np.median(sheared) < 3e-4, np.median(sheared)      # oracle: 1.46e-4 against the reference's 1.5e-4 arrow scale
+    assert sheared.max() < 5e-4
+
+
+def test_rolling_ball_peaks_sit_at_the_thresholds_of_the_reference_images():
+    """examples/RollingBallExp/test_sim_speed.py renders its read-outs with utils/tactile_utils.py's fixed scales: 1.2e-3 (depth image white),
+    8e-4 (force image red), 1.5e-4 (one cell of shear arrow).  The oracle's peaks over the script's 350 steps: compression 1.0e-3 median /
+    1.3e-3 maximum, shear 1.5e-4 median — the scales of the reference's own pictures, to 20 %.  Pins the tactile law's kn / damping, the
+    taxel sign [CHOICE: n = a1 x a0], the BDF2 pad dynamics and the 40 000-taxel layout to numbers the reference holds."""
+    m = load_model(W.asset("tactile_pad"))
+    o = OracleSim(m); o.reset(np.zeros(9))
+    frames = []
+    for i, a in enumerate(ROLLING_BALL_ACTIONS):
+        assert o.forward(np.array(a, dtype=np.float64), 1) == 0
+        if i % 5 == 0:
+            frames.append(o.outputs()[1].copy())
+    check_rolling_ball_peaks(*rolling_ball_peaks(frames))
