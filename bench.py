@@ -90,14 +90,17 @@ def usable_cores():
 WORKLOADS = {
     # name: (model asset, environments per GPU, env-steps per episode, forward-only, BASELINE.json config)
     "push": ("pusher", 4096, 100, False, "configs[2]: TactilePush gd_tactile fwd+adjoint, batch 4096 on one MI355X"),
-    "dclaw": ("dclaw_position_control", 2048, 20, True, "configs[3]: D'Claw rotate, 16 384 environments over 8 GPUs = 2048 per GPU, forward-only (PPO roll-out)"),
+    "push_fwd": ("pusher_13x13", 1024, 20, True, "configs[1]: TactilePush with a 13 x 13 taxel pad (the XML's 13 x 10 pad re-gridded: workloads.synthetic_variant), batch 1024, forward-only on one MI355X"),
+    "dclaw": ("dclaw_position_control", 2048, 50, True, "configs[3]: D'Claw rotate, 16 384 environments over 8 GPUs = 2048 per GPU, forward-only (PPO roll-out): q_init + 0.05 N(0, 1), "
+                                                        "random policy under relative position control (SURVEY.md §8d config 4; envs/dclaw_rotate_env.py:74-77,163,201-204), 50 of the "
+                                                        "episode's 200 env-steps per launch"),
     "insertion": ("tactile_insertion", 4096, 45, True, "configs[4]: TactileInsertion, 32 768 environments over 8 GPUs = 4096 per GPU, one 45-sub-step insertion attempt per "
                                                        "episode from the settled grasp moved by U(+-6 mm, +-6 mm, +-10 deg) (SURVEY.md §8d config 5; envs/tactile_insertion_env.py:"
                                                        "200-216,344-357), six captured tactile frames, forward-only + the 118 296-B policy-gradient all-reduce per episode"),
 }
 # TactileInsertion's episode is 45 frames of ONE sub-step (envs/tactile_insertion_env.py:53,359: frame_skip 1, a new joint target every
 # sub-step); to keep the unit of the metric (one env-step = 5 sub-steps) 5 of its frames count as one env-step
-FRAMES_PER_ENV_STEP = {"push": 1, "dclaw": 1, "insertion": 5}
+FRAMES_PER_ENV_STEP = {"push": 1, "push_fwd": 1, "dclaw": 1, "insertion": 5}
 
 
 _T0 = time.perf_counter()
@@ -132,11 +135,11 @@ def make_workload(name, B, T, S, rank, dev, tdt):
     """Synthetic inputs of one BASELINE config, resident in HBM (seed differs per rank so that ranks do different work)."""
     from tactilesimulation_amd.model.compiler import load_model
     from tactilesimulation_amd import workloads as W
-    model = load_model(W.asset(WORKLOADS[name][0]))
-    if name == "push":
+    model = W.synthetic_variant(WORKLOADS[name][0]) if name == "push_fwd" else load_model(W.asset(WORKLOADS[name][0]))
+    if name in ("push", "push_fwd"):
         q0, u, _ = W.push_workload(B, T, seed=rank)
     elif name == "dclaw":
-        q0, u = W.dclaw_workload(B, T, seed=7 + rank)
+        q0, u = W.dclaw_random_workload(B, T, seed=7 + rank)
     else:
         q0, u = W.insertion_attempt_workload(B, seed=7 + rank)
         u, S = u[:, :T], 1
@@ -340,7 +343,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="push", choices=sorted(WORKLOADS), help="push = the headline (BASELINE configs[2]); dclaw / insertion = "
+    ap.add_argument("--workload", default="push", choices=["push", "dclaw", "insertion"], help="push = the headline (BASELINE configs[2]); dclaw / insertion = "
                     "configs[3] / [4] at their per-GPU share, forward-only (reported as sub-records of the default N = 1 line too)")
     ap.add_argument("--batch", type=int, default=None, help="environments per GPU (default: the workload's per-GPU share)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -556,7 +559,7 @@ def main():
             if args.workload == "push" and not args.no_sub_records:
                 # the reference's arithmetic type (envs/tactile_push_env.py:29 torch.double) and the other two multi-GPU configs, each a
                 # short leg with its own roofline
-                for key, (nm, dty) in {"f64": ("push", "f64"), "dclaw": ("dclaw", args.dtype), "insertion": ("insertion", args.dtype)}.items():
+                for key, (nm, dty) in {"f64": ("push", "f64"), "push_forward_only_b1024": ("push_fwd", args.dtype), "dclaw": ("dclaw", args.dtype), "insertion": ("insertion", args.dtype)}.items():
                     if key == "f64" and (args.dtype == "f64" or forward_only):
                         continue
                     try:
@@ -846,8 +849,8 @@ def cpu_baseline(workload, model, S, with_backward):
     import threading
     from oracle.oracle import OracleSim
     from tactilesimulation_amd import workloads as W
-    nstep = {"push": 100, "dclaw": 20, "insertion": 45}[workload]
-    gen = {"push": lambda n, seed: W.push_workload(n, nstep, seed=seed)[:2], "dclaw": lambda n, seed: W.dclaw_workload(n, nstep, seed=7 + seed),
+    nstep = {"push": 100, "dclaw": 50, "insertion": 45}[workload]
+    gen = {"push": lambda n, seed: W.push_workload(n, nstep, seed=seed)[:2], "dclaw": lambda n, seed: W.dclaw_random_workload(n, nstep, seed=7 + seed),
            "insertion": lambda n, seed: W.insertion_attempt_workload(n, seed=7 + seed)}[workload]
     unit = 1.0 / FRAMES_PER_ENV_STEP[workload]                 # TactileInsertion: frames of one sub-step, 5 of them = one env-step
     nenv = 8

@@ -383,8 +383,12 @@ __host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu, int esz)
 // the host says so (kernel argument stage_cpt, decided per launch: they are small and do not cost the launch its lanes-per-environment shape):
 // every residual evaluation reads all of them, and a lone wavefront cannot hide ~600-cycle L2 latencies.
 #define TS_CPT_LDS_BYTES 8192
+// (Round 4: also next to per-environment tables — the tables hold the float RECORDS of an environment; the contact-point arrays are geometry
+// of the general bodies, shared by every environment, and one copy per block serves all its slots.  Before, a batch with domain
+// randomisation read all its contact points from L2 in every evaluation: D'Claw collection fell from 1.76 M to 0.90 M env-steps/s.)
 __host__ __device__ inline int ts_cpt_staged(int ncpt, bool env_tables, bool stage) {
-  return (!env_tables && stage) ? 3 * ncpt : 0;
+  (void)env_tables;
+  return stage ? 3 * ncpt : 0;
 }
 // reals of the staged-table region of a block, a multiple of 4 (what follows holds doubles: keep it 8-byte aligned)
 __host__ __device__ inline int ts_tab_reals(int nfrec, int ncpt, int nslot, bool env_tables, bool stage_cpt) {
@@ -440,9 +444,13 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
   const int nfrec = I[TSIM_IH_FOFF_CPT];
   {
     R* mf = lds;
-    if (Fenv) {                                  // per-environment float tables (domain randomisation): one copy per slot
+    R* cpt_l = lds + nfrec;                      // shared tables: the contact points follow the records, as in the blob
+    if (Fenv) {                                  // per-environment float tables (domain randomisation): one copy per slot ...
       mf += slot * (nfrec + 2);
       for (int i = lane; i < nfrec; i += lpe) mf[i] = Fenv[i];
+      cpt_l = lds + nslot * (nfrec + 2);         // ... and ONE copy of the (shared) contact-point arrays behind them
+      const int nc = ts_cpt_staged(I[TSIM_IH_NCPT], true, stage_cpt);
+      for (int i = threadIdx.x; i < nc; i += TS_WAVE) cpt_l[i] = F[nfrec + i];
     } else {
       const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, stage_cpt);   // tables (+ contact points)
       for (int i = threadIdx.x; i < nst; i += TS_WAVE) mf[i] = F[i];
@@ -465,7 +473,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     c.Fg = F; c.F = mf;
     c.cpt_lds = ts_u(ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt)) != 0;
     c.CPT = F + I[TSIM_IH_FOFF_CPT];
-    c.CPTl = (__attribute__((address_space(3))) const R*)(mf + (c.cpt_lds ? I[TSIM_IH_FOFF_CPT] : 0));
+    c.CPTl = (__attribute__((address_space(3))) const R*)(c.cpt_lds ? cpt_l : mf);
     F = mf;
   }
   c.stamps = nullptr; c.nstamp = 0;

@@ -1194,6 +1194,15 @@ static LaunchShape launch_shape(const tsim_batch* b) {
   L.lds = lds_bytes_for(b, ns);
   return L;
 }
+// Stage the contact-point arrays in LDS (one copy per block) if they are small and the launch keeps its lanes-per-environment shape with
+// them; re-decided whenever what the shape depends on changes (forced lanes, per-environment tables on / off).
+static void decide_stage_cpt(tsim_batch* b) {
+  b->stage_cpt = 0;
+  if ((size_t)3 * b->I[TSIM_IH_NCPT] * b->esz > TS_CPT_LDS_BYTES) return;
+  const int lpe0 = launch_shape(b).lpe;
+  b->stage_cpt = 1;
+  if (launch_shape(b).lpe != lpe0 || lds_bytes_for(b, 1) > 64 * 1024) b->stage_cpt = 0;
+}
 // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
 // compiled out otherwise: it costs registers in every evaluation); LPE as above
 #define TS_LAUNCH_L(KERNEL, R, NRM, L, st, a) do {                                                                       \
@@ -1298,11 +1307,8 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   }
   b->stage_cpt = 0;
   if (lds_bytes_for(b, 1) > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
-  if ((size_t)3 * I[TSIM_IH_NCPT] * b->esz <= TS_CPT_LDS_BYTES) {      // stage the contact points if the shape survives it
-    const int lpe0 = launch_shape(b).lpe;
-    b->stage_cpt = 1;
-    if (launch_shape(b).lpe != lpe0) b->stage_cpt = 0;
-  } b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0; b->poseR = nullptr; b->poseD = nullptr; b->nspt = b->I[TSIM_IH_NSPRIM];
+  decide_stage_cpt(b);
+  b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0; b->poseR = nullptr; b->poseD = nullptr; b->nspt = b->I[TSIM_IH_NSPRIM];
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)2 * B * nr * b->esz) != hipSuccess ||
@@ -1344,15 +1350,7 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
   if (lanes != 0 && lanes != 16 && lanes != 32 && lanes != 64) return fail("set_lanes_per_env: 0 (automatic), 16, 32 or 64");
   b->lpe_forced = lanes;
   b->order_valid = 0; b->order_ep_n = 0;
-  // the contact-point staging decision depends on the shape: redo it, the flag lives in the device copy of the schedule
-  const int old = b->stage_cpt;
-  b->stage_cpt = 0;
-  if ((size_t)3 * b->I[TSIM_IH_NCPT] * b->esz <= TS_CPT_LDS_BYTES) {
-    const int lpe0 = launch_shape(b).lpe;
-    b->stage_cpt = 1;
-    if (launch_shape(b).lpe != lpe0) b->stage_cpt = 0;
-  }
-  (void)old;      // the flag travels with every launch as a kernel argument: nothing on the device to update
+  decide_stage_cpt(b);      // depends on the shape; the flag travels with every launch as a kernel argument: nothing on the device to update
   return 0;
 }
 int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {
@@ -1378,16 +1376,16 @@ int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* st
   TS_DEVICE(b);
   pose_invalidate(b, (hipStream_t)stream);
   b->I.assign(I, I + I[TSIM_IH_NI]); b->F.assign(F, F + I[TSIM_IH_NF]);
-  if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; }     // per-environment tables refer to the old model
+  if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; decide_stage_cpt(b); }     // per-environment tables refer to the old model
   return upload_model(b, (hipStream_t)stream);
 }
 
 int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream) {
   TS_DEVICE(b);
   pose_invalidate(b, (hipStream_t)stream);
-  if (!tables) { if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; } return 0; }
+  if (!tables) { if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; decide_stage_cpt(b); } return 0; }
   size_t bytes = (size_t)b->B * b->nfrec * b->esz;
-  if (!b->dFenv) HIPCHK(hipMalloc(&b->dFenv, bytes));
+  if (!b->dFenv) { HIPCHK(hipMalloc(&b->dFenv, bytes)); decide_stage_cpt(b); }      // the block's LDS layout changes with per-environment tables
   HIPCHK(hipMemcpyAsync(b->dFenv, tables, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }

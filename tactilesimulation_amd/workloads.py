@@ -32,7 +32,8 @@ def push_workload(B, T, seed=0, q_init=None):
 
 
 def dclaw_workload(B, T, seed=7):
-    """BASELINE configs[3] inputs (D'Claw, dclaw_position_control.xml): q0 [B, 10], u [B, T, 9] absolute joint targets.
+    """A scripted stand-in kept from rounds 1-3 for the parity tests (NOT the bench's inputs since round 4: dclaw_random_workload below is
+    what SURVEY.md §8d words): q0 [B, 10], u [B, T, 9] absolute joint targets.
     A grasp of the cap: all three fingertips close on the cylinder and twist it (joint order per finger: base abduction, proximal,
     distal; limits and relative-target stepping as in envs/dclaw_rotate_env.py:23,86-96,201-207)."""
     rng = np.random.default_rng(seed)
@@ -70,6 +71,28 @@ def _rotvec_mul_z(r, angle):
     n = np.linalg.norm(v, axis=1)
     ang = 2 * np.arctan2(n, w)
     return np.where(n[:, None] > 1e-12, v / np.maximum(n, 1e-300)[:, None], 0.0) * ang[:, None]
+
+
+DCLAW_DOF_LIMIT = ((-0.45, 1.35), (-2.0, 2.0), (1.0, 2.0)) * 3        # envs/dclaw_rotate_env.py:78-88
+
+
+def dclaw_random_workload(B, T, seed=0):
+    """BASELINE configs[3] inputs as SURVEY.md §8d words them: q0 [B, 10] = the env's q_init (proximal joints -0.5, distal 0.8,
+    envs/dclaw_rotate_env.py:74-77) + 0.05 N(0, 1) on the nine hand joints (:163); u [B, T, 9] = absolute joint targets of a random
+    policy under relative position control: a ~ U(-1, 1)^9, target <- clip(target + 0.06 a, dof_limit) (:23,201-204).  (The env steps from
+    the SIMULATED joint angles; an open-loop table steps from the previous target, which the PD motors track.)  On this walk the fingertips
+    do meet the cap: by the env's own criterion — a finger's summed taxel force >= 1.0 (:131-133) — 15 % of the (finger, read-out) pairs of a
+    200-step episode are in contact and the cap gets turned (oracle, 16 environments)."""
+    rng = np.random.default_rng(seed)
+    lim = np.asarray(DCLAW_DOF_LIMIT)
+    q0 = np.zeros((B, 10)); q0[:, [1, 4, 7]] = -0.5; q0[:, [2, 5, 8]] = 0.8
+    q0[:, :9] += 0.05 * rng.normal(size=(B, 9))
+    u = np.zeros((B, T, 9))
+    cur = q0[:, :9].copy()
+    for t in range(T):
+        cur = np.clip(cur + 0.06 * rng.uniform(-1.0, 1.0, size=(B, 9)), lim[:, 0], lim[:, 1])
+        u[:, t] = cur
+    return q0, u
 
 
 def insertion_attempt_workload(B, seed=7, max_error=(0.006, 0.006, np.pi / 18.0), grasp_force=1.0):

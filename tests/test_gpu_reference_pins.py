@@ -214,3 +214,27 @@ def test_rolling_ball_peaks_on_the_kernels(dt):
         if i % 5 == 0:
             frames.append(sim.readout(want_var=False)[1][0].double().cpu().numpy())
     check_rolling_ball_peaks(*rolling_ball_peaks(frames))
+
+
+def test_config4_dclaw_random_policy_b2048_converges_touches_and_matches_the_oracle():
+    """BASELINE configs[3] as SURVEY.md §8d words it, at one GPU's share (2048 environments, fp32, forward only): q_init + 0.05 N(0, 1), random
+    relative position control for 50 env-steps.  Every environment converges, fingers do meet the cap by the env's own criterion (summed taxel
+    force >= 1.0, envs/dclaw_rotate_env.py:131-133), and a subset of the batch matches the fp64 oracle."""
+    from oracle.oracle import OracleSim
+    B, T, S = 2048, 50, 5
+    m = load_model(W.asset("dclaw_position_control"))
+    q0, u = W.dclaw_random_workload(B, T, seed=7)
+    dt = torch.float32
+    sim = BatchSim(m, B, dtype=dt, tape_capacity=0)
+    sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None)
+    ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous(), S)
+    assert int((ro["status"] != 0).sum()) == 0
+    tot = ro["tactile"].reshape(T, B, 3, 302, 3).norm(dim=-1).sum(-1)                 # [T, B, finger]
+    assert float((tot >= 1.0).double().mean()) > 0.01                                # measured 0.06 over the first 50 env-steps
+    for e in np.linspace(5, B - 9, 4).astype(int):
+        o = OracleSim(m); o.reset(q0[e])
+        for t in range(T):
+            assert o.forward(u[e, t], S) == 0
+            q = o.state()[0]; tac = o.outputs()[1]
+            assert np.abs(ro["q"][t, e].double().cpu().numpy() - q).max() < 2e-5 * max(1.0, np.abs(q).max()), (e, t)
+            assert np.abs(ro["tactile"][t, e].double().cpu().numpy() - tac).max() < 2e-3 * max(np.abs(tac).max(), 1e-3), (e, t)

@@ -358,3 +358,26 @@ def test_rolling_ball_peaks_sit_at_the_thresholds_of_the_reference_images():
         if i % 5 == 0:
             frames.append(o.outputs()[1].copy())
     check_rolling_ball_peaks(*rolling_ball_peaks(frames))
+
+
+def test_dclaw_random_workload_meets_the_envs_contact_criterion_and_cap_geometry():
+    """envs/dclaw_rotate_env.py:89-90 states the cap's geometry (`cap_center = (0, 0, 0.035)`, `cap_top_surface_z = 0.05`) and :131-133 its
+    contact criterion (a finger's summed taxel force >= 1.0).  The compiled model puts the cap end-effector (`pos = 0.04 0 0` in the cap frame,
+    dclaw_position_control.xml:148) at (0.04, 0, 0.035) — bottle joint at z = -0.04, cap joint 0.075 above it — and on SURVEY.md §8d's
+    config-4 walk fingers do cross the 1.0 threshold, every sub-step converged."""
+    m = load_model(W.asset("dclaw_position_control"))
+    o = OracleSim(m)
+    o.reset(np.zeros(10))
+    var = o.outputs(tactile=False)[0].reshape(-1, 3)
+    assert np.allclose(var[3], (0.04, 0.0, 0.035), atol=1e-12)
+    assert abs((0.035 + 0.03 / 2) - 0.05) < 1e-15                      # cap length 0.03 (:115): the top surface the env guards fingertips against
+    q0, u = W.dclaw_random_workload(3, 120, seed=0)
+    touched, peak = 0, 0.0
+    for e in range(3):
+        o.reset(q0[e])
+        for t in range(120):
+            assert o.forward(u[e, t], 5) == 0
+            if t % 10 == 9:
+                tot = np.linalg.norm(o.outputs()[1].reshape(3, 302, 3), axis=-1).sum(1)
+                touched += int((tot >= 1.0).sum()); peak = max(peak, tot.max())
+    assert touched >= 2 and 1.0 < peak < 1e3, (touched, peak)
