@@ -1199,6 +1199,7 @@ static LaunchShape launch_shape(const tsim_batch* b) {
 static void decide_stage_cpt(tsim_batch* b) {
   b->stage_cpt = 0;
   if ((size_t)3 * b->I[TSIM_IH_NCPT] * b->esz > TS_CPT_LDS_BYTES) return;
+  if (b->dFenv && getenv("TSIM_NO_ENVTAB_CPT")) return;      // A/B: the round-3 behaviour (contact points from global memory next to per-environment tables)
   const int lpe0 = launch_shape(b).lpe;
   b->stage_cpt = 1;
   if (launch_shape(b).lpe != lpe0 || lds_bytes_for(b, 1) > 64 * 1024) b->stage_cpt = 0;

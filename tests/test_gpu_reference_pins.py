@@ -218,7 +218,7 @@ def test_rolling_ball_peaks_on_the_kernels(dt):
 
 def test_config4_dclaw_random_policy_b2048_converges_touches_and_matches_the_oracle():
     """BASELINE configs[3] as SURVEY.md §8d words it, at one GPU's share (2048 environments, fp32, forward only): q_init + 0.05 N(0, 1), random
-    relative position control for 50 env-steps.  Every environment converges, fingers do meet the cap by the env's own criterion (summed taxel
+    relative position control for 50 env-steps.  The kernels flag the environments the oracle flags (3 of 2048), fingers do meet the cap by the env's own criterion (summed taxel
     force >= 1.0, envs/dclaw_rotate_env.py:131-133), and a subset of the batch matches the fp64 oracle."""
     from oracle.oracle import OracleSim
     B, T, S = 2048, 50, 5
@@ -228,7 +228,15 @@ def test_config4_dclaw_random_policy_b2048_converges_touches_and_matches_the_ora
     sim = BatchSim(m, B, dtype=dt, tape_capacity=0)
     sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None)
     ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous(), S)
-    assert int((ro["status"] != 0).sum()) == 0
+    # The XML's Newton loop itself gives up on one sub-step of 3 of these 2048 random walks (a fingertip jammed against the cap: max_iter
+    # after ~1 200 evaluations) — the fp64 oracle flags exactly environments 529, 700, 1855 on the same inputs (165 s of CPU for the whole
+    # batch; profiles/r04_dclaw_config4.md), and a quarter of the environments have a sub-step of >= 100 evaluations.  The kernels must flag
+    # the same three and nothing else.
+    flagged = torch.nonzero(ro["status"] != 0).flatten().tolist()
+    assert flagged == [529, 700, 1855], flagged
+    for e in flagged:                                                                 # ... and the oracle does give up on each of them
+        o = OracleSim(m); o.reset(q0[e])
+        assert sum(o.forward(u[e, t], S) != 0 for t in range(T)) == 1, e
     tot = ro["tactile"].reshape(T, B, 3, 302, 3).norm(dim=-1).sum(-1)                 # [T, B, finger]
     assert float((tot >= 1.0).double().mean()) > 0.01                                # measured 0.06 over the first 50 env-steps
     for e in np.linspace(5, B - 9, 4).astype(int):
