@@ -384,8 +384,9 @@ __host__ __device__ inline int ts_lds_env_reals(int nl, int nr, int nu, int esz)
 // every residual evaluation reads all of them, and a lone wavefront cannot hide ~600-cycle L2 latencies.
 #define TS_CPT_LDS_BYTES 8192
 // (Round 4: also next to per-environment tables — the tables hold the float RECORDS of an environment; the contact-point arrays are geometry
-// of the general bodies, shared by every environment, and one copy per block serves all its slots.  Before, a batch with domain
-// randomisation read all its contact points from L2 in every evaluation: D'Claw collection fell from 1.76 M to 0.90 M env-steps/s.)
+// of the general bodies, shared by every environment, and one copy per block serves all its slots.  Measured on D'Claw collection with 16
+// randomised variants: 0.63 M env-steps/s either way (TSIM_NO_ENVTAB_CPT=1 restores the global loads) — what randomisation costs there is
+// Newton effort on the randomised models, 871 of 204 800 env-steps at the evaluation budget, not these loads.)
 __host__ __device__ inline int ts_cpt_staged(int ncpt, bool env_tables, bool stage) {
   (void)env_tables;
   return stage ? 3 * ncpt : 0;
