@@ -168,6 +168,15 @@ int tsim_launch_info(const tsim_batch* b, int32_t* out);
 /* Force 16 / 32 / 64 lanes per environment (0 = automatic again).  For callers that split a batch into groups on several
  * streams: each group is then small, but the groups together should still fill the device. */
 int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes effect with the next launch */
+/* Statically known models.  The library carries, next to the generic kernels, instantiations of the forward / adjoint kernels for models
+ * whose compiled blob it was built with (csrc/tsim_static.h; round 4: TactilePush, envs/assets/pusher/pusher.xml): tree, joint types, joint
+ * frames and axes are compile-time constants there and the link sweep folds to what the model's structure leaves.  They are used when the
+ * batch's blob equals the compiled-in one bit for bit (checked at tsim_batch_create / tsim_update_model), the batch is fp32 at four
+ * environments per wavefront and has no per-environment tables; results equal the generic kernels' (tests/test_gpu_static_model.py).
+ * tsim_static_model returns the id of the instantiation the NEXT launch will use (0: generic, 1: TactilePush); tsim_set_static(b, 0)
+ * keeps a batch on the generic kernels (also: environment variable TSIM_NO_STATIC at creation), tsim_set_static(b, 1) allows them again. */
+int tsim_static_model(const tsim_batch* b);
+int tsim_set_static(tsim_batch* b, int allow);
 
 /* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */
 int tsim_last_evals(tsim_batch* b, int32_t* host_out);

@@ -52,6 +52,21 @@ enum { PP_RPA = 0, PP_PPA = 9, PP_WREL = 12, PP_VREL = 15, PP_RP = 18, PP_PP = 2
 // staged pair, per direction: relative displacement (P frame), d(relative twist), d(wrench sum)
 enum { PT_DTH = 0, PT_DRHO = 3, PT_DW = 6, PT_DV = 9, PT_WN = 12, PT_WF = 15, PT_SIZE = 18 };
 
+// Finite tests on the BIT PATTERN, laundered through an empty asm: the translation unit of the statically specialised kernels is built with
+// -ffinite-math-only -fno-signed-zeros (tsim_static.h), under which the compiler may assume that no floating-point value is ever a NaN or an
+// infinity — x == x, x - x == 0, !(a < b), even a mask test on the bits of a COMPUTED value may then be folded to "finite".  Every place
+// that must notice a NaN / inf (a non-finite control, a residual norm that blew up, a bad multiplier in the pivot-free solve) asks these: the
+// asm makes the bits opaque to the optimiser.
+__device__ __forceinline__ bool ts_finite(float x) {
+  unsigned b = __builtin_bit_cast(unsigned, x);
+  asm volatile("" : "+v"(b));
+  return (b & 0x7f800000u) != 0x7f800000u;
+}
+__device__ __forceinline__ bool ts_finite(double x) {
+  unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32);
+  asm volatile("" : "+v"(hi));
+  return (hi & 0x7ff00000u) != 0x7ff00000u;
+}
 __device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ void t_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }

@@ -10,6 +10,8 @@
 // and are verified against the oracle's dual-number Jacobian to round-off (tests/test_gpu_parity.py).
 #pragma once
 #include "tsim_device.h"
+#include "tsim_static.h"
+#include <type_traits>
 
 // ================================================================================================ phase 1 (+ 1t)
 // One root -> leaf sweep does both the values and, on lanes k < nr, the tangents w.r.t. dof k (seeds: q_k += eps*sq,
@@ -627,7 +629,7 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
 // 4/3 q0 - 1/3 q_1 + 8/9 h qd0 - 2/9 h qd_1), not q1 itself: qd1 = qdp + cv dl, qdd1 = ca dl keep full relative
 // precision in fp32 (no q1 - q0 cancellation).  forward seeds: (1, cv, ca) -> H = dg/dq1 ;  adjoint seeds (1, 0, 0)
 // -> H = (1/ca) dr/dq  (BDF1: h^2 dr/dq).
-template <class R, int NRM, bool EXPJ, int LPE>
+template <class R, int NRM, bool EXPJ, int LPE, class MS = void>
 __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   if (lane < c.nr) {
     const R d = c.dl[lane];
@@ -638,7 +640,8 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
   }
   TS_SYNC();
   TS_STAMP(c);
-  phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
+  if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
+  else phase1_static<R, MS, true>(c, lane, sq, sv, sa);              // a statically known model: tsim_static.h
   TS_STAMP(c);
   phase2<R, NRM, LPE>(c, lane, sq);
   TS_STAMP(c);
@@ -705,6 +708,71 @@ __device__ __forceinline__ void solve_lanes(const R* A, const R* b, R* x, int n,
   }
   if (write && row && mycol >= 0) x[mycol] = (R)(rb * fast_rcp(mypiv));
   TS_SYNC();
+}
+
+// ---- the same system without pivoting and without the LDS crossbar (round 4; fp32 kernels) ----------------------------------------
+// With the pivot of column c fixed to row c, the source lane of every broadcast is a compile-time lane of the slot's first 16-lane row, and
+// gfx90a+ has a DPP control for exactly that: row_newbcast:c — one VALU instruction per dword instead of a ds_bpermute round trip, and
+// no pivot search (4 DPP maxima + one more round trip per column).  solve_lanes spends ~3.9 k of an evaluation round's 50.6 k cycles, most
+// of it waiting for those round trips (two dependent ones per column); this form is ~45 instructions per column.
+// The Newton matrix H = M + h D + h^2 K has the mass matrix on its diagonal and is solved in double, so elimination in the natural order is
+// normally fine; it is CHECKED, not assumed: a multiplier that is not finite or exceeds 1e6 flags the lane, and the caller then repeats the
+// solve with partial pivoting (solve_lanes) for the whole wavefront.  The fp64 kernels keep the pivoted solve — they are the ones that walk
+// the oracle's iterates to round-off, and the oracle pivots.
+template <int L> __device__ __forceinline__ double row_bcast(double x) {            // value of lane L of the caller's 16-lane row
+  const long long b = __builtin_bit_cast(long long, x);
+  const int lo = dpp_i<0x150 + L, 0xf>((int)(b & 0xffffffffll)), hi = dpp_i<0x150 + L, 0xf>((int)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int COL, int NRM>
+__device__ __forceinline__ void gj_step_nopivot(double (&a)[NRM], double& rb, double& mypiv, bool& bad, int n, bool row, int lane) {
+  if (COL < n) {                                   // wave-uniform
+    double prow[NRM];
+#pragma unroll
+    for (int j = COL; j < NRM; ++j) prow[j] = row_bcast<COL>(a[j]);
+    const double pb = row_bcast<COL>(rb);
+    const double piv = prow[COL];
+    const bool elim = row && lane != COL;          // identity rows (lanes >= n, other 16-lane rows of a wide slot) take no part
+    const double f = elim ? a[COL] * fast_rcp(piv) : 0.0;
+    bad = bad || (elim && (!ts_finite(f) || fabs(f) >= 1e6));      // also catches a zero / non-finite pivot
+#pragma unroll
+    for (int j = COL; j < NRM; ++j) a[j] -= f * prow[j];
+    rb -= f * pb;
+    if (lane == COL) mypiv = piv;
+  }
+  if constexpr (COL + 1 < NRM) gj_step_nopivot<COL + 1, NRM>(a, rb, mypiv, bad, n, row, lane);
+}
+// Solves A x = b (or A^T x = b) as solve_lanes does; returns false in the lanes of a slot whose elimination met a bad multiplier (x is then
+// NOT written for that slot: the caller falls back to solve_lanes).
+template <class R, int NRM, int LPE>
+__device__ __forceinline__ bool solve_lanes_nopivot(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
+  double a[NRM], rb, mypiv = 1.0;
+  const bool row = lane < n;
+  const int r = min(lane, n - 1);
+#pragma unroll
+  for (int j = 0; j < NRM; ++j) {
+    const int jj = min(j, n - 1);
+    const double v = (double)(transpose ? A[jj * n + r] : A[r * n + jj]);
+    a[j] = (row && j < n) ? v : ((j == lane) ? 1.0 : 0.0);
+  }
+  rb = row ? (double)b[r] : 0.0;
+  bool bad = false;
+  gj_step_nopivot<0, NRM>(a, rb, mypiv, bad, n, row, lane);
+  const bool slot_bad = seg_max<LPE>(bad ? 1.0f : 0.0f) > 0.0f;
+  if (write && row && !slot_bad) x[lane] = (R)(rb * fast_rcp(mypiv));
+  TS_SYNC();
+  return !slot_bad;
+}
+// the solve the kernels call: fp32 kernels try the pivot-free DPP form first (-DTS_SOLVE_PIVOT_ONLY: A/B), fp64 kernels always pivot
+template <class R, int NRM, int LPE>
+__device__ __forceinline__ void solve_newton(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
+#ifndef TS_SOLVE_PIVOT_ONLY
+  if (sizeof(R) == 4) {
+    const bool ok = solve_lanes_nopivot<R, NRM, LPE>(A, b, x, n, transpose, lane, write);
+    if (__all(ok || !write)) return;
+  }
+#endif
+  solve_lanes<R, NRM, LPE, double>(A, b, x, n, transpose, lane, write);
 }
 
 template <int LPE, class R> __device__ __forceinline__ R block_norm2(const R* v, int n, int lane) {

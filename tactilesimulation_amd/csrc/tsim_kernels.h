@@ -1,0 +1,613 @@
+// tsim_kernels.h — the two simulation kernels (k_forward, k_backward) with their argument structs and the helpers only they use.
+// A header, not a translation unit: the generic instantiations are compiled in tsim_hip.hip, the instantiations for statically known models
+// (tsim_static.h) in their own translation unit (tsim_static_pusher.hip), which is built with -ffinite-math-only -fno-signed-zeros so that
+// the structural zeros and ones of the compiled-in model fold away — flags the generic kernels, whose fp64 instantiations walk the
+// oracle's iterates to round-off, are NOT built with.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/tsim.h"
+#include "tsim_eval.h"
+#include "tsim_policy_push.h"
+
+// tape record per (sub-step, env), in reals: q[nr] as DOUBLE (the pose chain is double also in the fp32 kernels),
+// qd[nr], H[nr*nr], u[nu]; padded to an even count so that every record starts 8-byte aligned
+__host__ __device__ inline int ts_qw(int esz) { return 8 / esz; }                      // reals per double
+__host__ __device__ inline int ts_rec(int nr, int nu, int esz) { return (ts_qw(esz) * nr + nr + nr * nr + nu + 1) & ~1; }
+template <class R> __device__ __forceinline__ double* rec_q(R* rec) { return reinterpret_cast<double*>(rec); }
+template <class R> __device__ __forceinline__ const double* rec_q(const R* rec) { return reinterpret_cast<const double*>(rec); }
+template <class R> __device__ __forceinline__ int rec_qd(int nr) { return ts_qw((int)sizeof(R)) * nr; }           // offset of qd
+template <class R> __device__ __forceinline__ int rec_H(int nr) { return ts_qw((int)sizeof(R)) * nr + nr; }
+template <class R> __device__ __forceinline__ int rec_u(int nr) { return ts_qw((int)sizeof(R)) * nr + nr + nr * nr; }
+
+// ================================================================================================ read-out
+// variables: lanes = end-effector points; tactile: lanes = taxels (coalesced SoA loads of position / frame,
+// 12 B per lane contiguous stores).  Each taxel is evaluated in the frame of the primitive it is tested against.
+template <int LPE, class R>
+__device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool wr_var, bool wr, bool has_var, bool has_tac, R* var_out, R* tac_out, int tb = 0, int te = 0x7fffffff) {
+  // has_var / has_tac are wave-uniform (the loops below contain fences); wr_var / wr are per slot: in k_forward the slots of a
+  // wavefront reach the end of a frame in different rounds, and only those that did write
+  if (has_var && wr_var) {
+    for (int e = lane; e < c.nvar; e += LPE) {
+      const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
+      const V3<R> x = mulMv(ldm(c.LP + l * LK_SIZE + LK_R), ldv(c.F + c.foff_var + e * TSIM_VF_SIZE)) + ldv(c.LP + l * LK_SIZE + LK_P);
+      R* o = var_out + (size_t)env * 3 * c.nvar + 3 * e;
+      o[0] = x.x; o[1] = x.y; o[2] = x.z;
+    }
+  }
+  if (!has_tac) return;
+  for (int s = 0; s < c.nsensor; ++s) {
+    const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
+    const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
+    const int t0 = ts_u(si[TSIM_SI_TAX0]), nt = ts_u(si[TSIM_SI_NTAX]), sp0 = ts_u(si[TSIM_SI_SPRIM0]), nsp = ts_u(si[TSIM_SI_NSPRIM]);
+    for (int j0 = 0; j0 < nsp || j0 == 0; j0 += TS_PAIR_GROUP) {
+      const int je = min(j0 + TS_PAIR_GROUP, nsp);
+      TS_SYNC();
+      for (int j = j0; j < je; ++j) pair_stage_value(c, ts_u(c.I[c.off_sprim + sp0 + j]), j - j0, lane == 0);
+      TS_SYNC();
+      // this block's slice [tb, te) of the global taxel range, intersected with the sensor
+      const int lo = max(tb, t0) - t0, hi = min(te, t0 + nt) - t0;
+      for (int base = lo; base < hi; base += LPE) {
+        const int t = t0 + base + lane;
+        if (base + lane >= hi || !wr) continue;
+        const R* tp = c.Fg + c.foff_tax + t;
+        const V3<R> xa = mk3<R>(tp[0], tp[c.ntax], tp[2 * c.ntax]);
+        V3<R> Fl = zero3<R>();                          // force on the taxel, sensor-link frame
+        for (int j = j0; j < je; ++j) {
+          const int pk = ts_u(c.I[c.off_sprim + sp0 + j]);
+          const int prim = ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_PRIM]);
+          const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+          const R* S = c.PP + (j - j0) * PP_SIZE;
+          const M3<R> RPA = ldm(S + PP_RPA);
+          const V3<double> xPd = mulMv(ldm(c.PPd + (j - j0) * 12), cvt3<double>(xa)) + ldv(c.PPd + (j - j0) * 12 + 9);
+          const V3<R> xP = cvt3<R>(xPd);
+          V3<R> F; M3<R> Jx, Jv;
+          if (contact_law<R, false>(prim, pf + TSIM_PF_SHAPE, sf, xP, ldv(S + PP_VREL) + cross3(ldv(S + PP_WREL), xP), F, Jx, Jv, xPd))
+            Fl = Fl + mulMtv(RPA, F);
+        }
+        R* o = tac_out + (size_t)env * 3 * c.ntax + 3 * t;
+        R o0 = R(0), o1 = R(0), o2 = R(0);
+        if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {       // the nine axis constants only for taxels that carry a force
+          o0 = Fl.x * tp[3 * c.ntax] + Fl.y * tp[4 * c.ntax] + Fl.z * tp[5 * c.ntax];
+          o1 = Fl.x * tp[6 * c.ntax] + Fl.y * tp[7 * c.ntax] + Fl.z * tp[8 * c.ntax];
+          o2 = Fl.x * tp[9 * c.ntax] + Fl.y * tp[10 * c.ntax] + Fl.z * tp[11 * c.ntax];
+        }
+        if (j0 == 0) { o[0] = o0; o[1] = o1; o[2] = o2; } else { o[0] += o0; o[1] += o1; o[2] += o2; }
+      }
+    }
+  }
+}
+
+// ================================================================================================ forward kernel
+enum { TP_R_SIZE = 18, TP_D_SIZE = 12 };      // pose record of a (sensor, primitive) combination: R part, double part (k_readout)
+template <class R> struct FwdArgs {
+  const int* I; const R* F; const R* Fenv; int fstride;
+  int B, nsub, record, t0;
+  int nframes;            // env-steps in this launch; frame f reads u[f][B][nu] and writes *_out[f][B][...] (tsim_rollout)
+  const int* tac_slot;    // [nframes] slot of frame f in tac_out, < 0: no tactile read-out for that frame; null: slot f
+  R* tape; const R* u;
+  R *q_out, *qd_out, *var_out, *tac_out; int* status; int* evals;
+  const int* order;       // block -> environment map (longest-processing-time-first scheduling), or null
+  double* prev; int has_prev;  // state before the previous sub-step [B][2 nr] doubles (BDF2 history across launches)
+  int stage_cpt;               // contact-point arrays staged in LDS with the shared tables (sized into the launch's LDS)
+  int cross_kinks;             // full Newton step at an exhausted line search close to convergence (tsim_set_solver_options)
+  int eval_budget;             // residual evaluations a sub-step may take before it is flagged and left (0: the XML's max_iter / max_ls only)
+  float* gnorm;                // [B] largest ||g|| a sub-step of this launch ended with (diagnostics, tsim_last_gnorm)
+  PushPolicy<R> pol;           // POLICY instantiations only (tsim_push_closed_rollout): the TactilePush policy between the frames
+  R* poseR = nullptr; double* poseD = nullptr; int nspt = 0;   // large pads: pose records of the final state for tsim_readout's k_taxels (see k_readout)
+};
+
+// -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
+#ifdef TS_WAVES_PER_EU
+#define TS_KLB __launch_bounds__(TS_WAVE, TS_WAVES_PER_EU)
+#else
+#define TS_KLB __launch_bounds__(TS_WAVE)
+#endif
+template <class R, int NRM, bool EXPJ, int LPE, bool POLICY = false, class MS = void>
+__global__ void TS_KLB k_forward(FwdArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R* lds = reinterpret_cast<R*>(smem_raw);
+  constexpr int NS = TS_WAVE / LPE;
+  const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;       // lane: inside the slot
+  // Stragglers set the kernel time (all environments wait for the one with the most Newton work), so environments that
+  // were expensive in the previous env-step are dispatched first: slot s of block b runs environment order[b NS + s]
+  // (neighbours in that order have similar work, which also keeps the slots of one wavefront together).
+  const int eidx = blockIdx.x * NS + slot;
+  const bool valid = eidx < a.B;                                        // a batch that is no multiple of NS: idle slot
+  const int env = a.order ? a.order[min(eidx, a.B - 1)] : min(eidx, a.B - 1);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
+  init_world(c, lane, LPE);
+  {
+    const R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
+    if (lane < nr) { c.q0D[lane] = rec_q(st)[lane]; c.q0[lane] = (R)c.q0D[lane]; c.qd0[lane] = st[rec_qd<R>(nr) + lane]; }
+  }
+  TS_SYNC();
+  R* dlbase = c.dq + nr;
+  int bad = 0; bool nonfinite = false;
+  int evals = 0;
+  R gmax = R(0);
+  const bool bdf2_model = ts_u(c.I[TSIM_IH_INTEGRATOR]) == 2;
+  // BDF2 history (the state before the previous sub-step).  While recording it is tape record t0 - 1 — so taped sub-step t is a BDF2
+  // step exactly when t >= 2, which is what the adjoint kernel assumes (also after the tape was swapped by the backward cache);
+  // without a tape it is the batch's `prev` buffer.
+  bool has_prev = a.record ? a.t0 >= 1 : a.has_prev != 0;
+  if (bdf2_model && has_prev && lane < nr) {
+    if (a.record) {
+      const R* pr = a.tape + ((size_t)(a.t0 - 1) * a.B + env) * REC;
+      c.qm1D[lane] = rec_q(pr)[lane]; c.qm1[lane] = (R)c.qm1D[lane]; c.qdm1[lane] = pr[rec_qd<R>(nr) + lane];
+    } else {
+      c.qm1D[lane] = a.prev[(size_t)env * 2 * nr + lane]; c.qm1[lane] = (R)c.qm1D[lane];
+      c.qdm1[lane] = (R)a.prev[(size_t)env * 2 * nr + nr + lane];
+    }
+  }
+  TS_SYNC();
+  // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
+  // environment of the batch between env-steps: Newton stragglers average out over the episode.
+#ifdef TS_PP_TIME      // A/B builds only: share of the launch spent in the policy call, left in gnorm (tools/closed_loop_breakdown.py)
+  long long pp_cycles_ = 0; const long long pp_t0_ = clock64();
+#endif
+  for (int f = 0; f < a.nframes; ++f) {
+  {
+    R uv = R(0);
+    if (POLICY) {
+      // closed loop: the action comes from the policy, evaluated by this slot on the observation the previous frame left
+      // (tsim_policy_push.h).  The tactile frame was written by this slot: make the stores visible to its own loads first.
+      ts_own_stores_visible();
+      const R* tprev = a.pol.mode != TSIM_PUSH_OBS_TACTILE ? nullptr : (f == 0 ? a.pol.tac0 + (size_t)env * PP_NTAC : a.tac_out + ((size_t)(f - 1) * a.B + env) * PP_NTAC);
+#ifdef TS_PP_TIME
+      const long long tp0_ = clock64();
+#endif
+      push_policy_forward<LPE>(c, lane, valid, a.pol, (size_t)f * a.B + env, env, tprev);
+      TS_SYNC();
+#ifdef TS_PP_TIME
+      pp_cycles_ += clock64() - tp0_;
+#endif
+      if (lane < nu) uv = c.u[lane];
+    } else
+    if (lane < nu) { uv = a.u[((size_t)f * a.B + env) * nu + lane]; c.u[lane] = uv; }
+    // a NaN / inf control would be clamped away silently by the motor law's fmin / fmax: flag it (status bit 30) instead
+    if (seg_sum<LPE>(ts_finite(uv) ? R(0) : R(1)) > R(0)) nonfinite = true;
+  }
+  TS_SYNC();
+  for (int s = 0; s < a.nsub; ++s) {
+    // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment
+    if (bdf2_model && has_prev) {
+      c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h);
+      if (lane < nr) {
+        const double hD = (double)c.h;
+        const double qp = 4.0 / 3 * c.q0D[lane] - 1.0 / 3 * c.qm1D[lane] + hD * (8.0 / 9 * (double)c.qd0[lane] - 2.0 / 9 * (double)c.qdm1[lane]);
+        c.qpD[lane] = qp; c.qp[lane] = (R)qp;
+        c.qdp[lane] = (R)((3.0 * qp - 4.0 * c.q0D[lane] + c.qm1D[lane]) / (2.0 * hD));
+      }
+    } else {
+      c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
+      if (lane < nr) { c.qpD[lane] = c.q0D[lane] + (double)c.h * (double)c.qd0[lane]; c.qp[lane] = (R)c.qpD[lane]; c.qdp[lane] = c.qd0[lane]; }
+    }
+    const R sq = R(1), sv = c.cv, sa = c.ca;
+    if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
+    TS_SYNC();
+    // Newton with backtracking EXACTLY as the model file states it (<solver_option tol max_iter max_ls>, pusher.xml:4): up to max_iter
+    // iterations; each halves the step until ||g|| decreases, at most max_ls times, and takes the last trial if none did; converged when
+    // ||g||_2 < tol.  Nothing else: no non-monotone steps, no restart, no trust region (rounds 1-2 had all three, tuned for the slowest
+    // wavefront; on the stiff TactileInsertion grasp their full Newton step across a kink "converged" to a root 0.15 rad away from the one
+    // plain backtracking reaches — found by the oracle's literal solver in round 3).  The oracle (oracle/tsim_oracle.cpp
+    // substep_literal) is the same loop in fp64; the fp64 kernels take its iterates.
+    // Written as a state machine around ONE evaluate call site (code size matters: the evaluation is ~6k instructions and two inlined
+    // copies overflow the instruction cache): an accepted trial's evaluation is the next iteration's Jacobian evaluation.  The state
+    // is per slot (identical in all lanes of a slot); a slot that has finished its sub-step keeps evaluating at its final iterate
+    // (same numbers again) until every slot of the wavefront has finished.
+    // Around that loop, two options (tsim_set_solver_options), both visible to the caller and both OFF for fp64 batches by default —
+    // the fp64 kernels ARE the loop:
+    //  * cross_kinks (fp32 default: on).  ||g|| has non-smooth local minima at contact / friction kinks: the iterate sits on the kink,
+    //    every step along the Newton direction lands on the other piece with a larger ||g||.  The literal loop halves its way down to
+    //    step lengths of 1e-6, takes the last trial anyway (it IS non-monotone there), which puts the iterate just across the kink, and
+    //    converges from the other side — after 130 - 190 evaluations in fp64 (18 of 819 200 TactilePush sub-steps).  In fp32 the
+    //    comparisons at those step lengths drown in rounding: noise-sized "decreases" are accepted for up to max_iter iterations (8 of
+    //    those 18 sub-steps ended non-converged after ~2000 evaluations each, k_forward 5x slower; profiles/r03_solver_probe.md).
+    //    With the option, and ONLY close to convergence (||g|| < TSIM_KINK_FACTOR x tol, where the Newton step is small: <= 1.3e-3 on
+    //    those 18), a trial still rejected after TSIM_KINK_LS halvings is followed by the FULL Newton step across the kink, at most
+    //    TSIM_KINK_MAX times per sub-step: ~20 evaluations, the same root as the literal loop wherever that converges
+    //    (tests/test_gpu_literal.py).  Far from convergence nothing changes: rounds 1-2 took such steps anywhere, and on the stiff
+    //    TactileInsertion grasp (||g|| ~ 1e-3, steps of 0.02 - 0.5) that reached roots 0.15 rad away from the literal one.
+    //  * eval_budget (default 0 = none): an upper bound on the evaluations of one sub-step for throughput-minded roll-out collection;
+    //    a sub-step cut short is flagged non-converged in status.
+    R gn = R(0), alpha = R(1);
+    int iter = 0, ls = -1, sub_evals = 0, crossings = 0;       // ls < 0: the evaluation just done is not a line-search trial
+    bool conv = false, fin = false, forced = false;
+    while (true) {
+      evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, sq, sv, sa);
+      const R gnew = block_norm2<LPE>(c.g, nr, lane);
+      bool solve = false;
+      if (!fin) {
+        ++evals; ++sub_evals;
+        bool take = false;                     // the point just evaluated becomes the iterate
+        if (ls >= 0 && !forced && (!ts_finite(gnew) || gnew >= gn)) {              // a rejected trial (a non-finite one is rejected too)
+          if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) {
+            ++crossings; forced = true;        // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
+            if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+          } else if (ls < c.max_ls) {          // halve the step
+            alpha *= R(0.5); ++ls;
+            if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
+          } else take = true;                  // the literal loop: the last trial is taken anyway
+        } else take = true;                    // the first evaluation of the sub-step, an accepted trial, or the step across a kink
+        if (take) {
+          forced = false;
+          if (ls >= 0) ++iter;
+          gn = gnew;
+          if (!ts_finite(gn)) { nonfinite = true; fin = true; }
+          else if (gn < c.tol) { conv = true; fin = true; }
+          else if (iter >= c.max_iter || (a.eval_budget > 0 && sub_evals >= a.eval_budget)) fin = true;
+          else {
+            solve = true;
+            if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
+          }
+        }
+      }
+      TS_SYNC();
+      if (__any(solve)) {
+        solve_newton<R, NRM, LPE>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+        if (solve) {
+          alpha = R(1); ls = 0;
+          if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+        }
+        TS_SYNC();
+      }
+      if (__all(fin)) break;
+    }
+    if (!conv) ++bad;
+    gmax = t_max(gmax, gn);
+    // commit the sub-step: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
+    if (a.record && valid) {
+      R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
+      if (lane < nr) { rec_q(rec)[lane] = c.qD[lane]; rec[rec_qd<R>(nr) + lane] = c.qd[lane]; }
+      for (int e = lane; e < nr * nr; e += LPE) rec[rec_H<R>(nr) + e] = c.H[e];
+      if (lane < nu) rec[rec_u<R>(nr) + lane] = c.u[lane];
+    }
+    TS_SYNC();
+    if (lane < nr) {
+      c.qm1[lane] = c.q0[lane]; c.qm1D[lane] = c.q0D[lane]; c.qdm1[lane] = c.qd0[lane];
+      c.q0[lane] = c.q[lane]; c.q0D[lane] = c.qD[lane]; c.qd0[lane] = c.qd[lane];
+    }
+    has_prev = true;
+    TS_SYNC();
+  }
+  if (lane < nr && valid) {
+    const size_t o = ((size_t)f * a.B + env) * nr + lane;
+    if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
+    if (a.qd_out) a.qd_out[o] = c.qd0[lane];
+  }
+  // link poses / velocities in LDS are those of the accepted state (last evaluation)
+  const int tslot = a.tac_slot ? a.tac_slot[f] : f;
+  readout<LPE>(c, lane, env, valid, valid && tslot >= 0, a.var_out != nullptr, a.tac_out != nullptr && tslot >= 0,
+               a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
+               (a.tac_out && tslot >= 0) ? a.tac_out + (size_t)tslot * a.B * 3 * c.ntax : nullptr);
+  TS_SYNC();
+  }
+  if (a.poseR) {
+    // Large pads are read out on demand (tsim_readout), by a kernel whose lanes are taxels and which needs, per (sensor, primitive)
+    // combination, the pose of the sensor link in the primitive's frame and the relative twist there.  The link records in LDS are those
+    // of the state this launch ends in: leave the pose records here and the read-out needs no kinematics kernel of its own.
+    int k = 0;
+    for (int s = 0; s < c.nsensor; ++s) {
+      const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
+      const int nsp = ts_u(si[TSIM_SI_NSPRIM]), sp0 = ts_u(si[TSIM_SI_SPRIM0]);
+      for (int j = 0; j < nsp; ++j, ++k) {
+        TS_SYNC();
+        pair_stage_value(c, ts_u(c.I[c.off_sprim + sp0 + j]), 0, lane == 0);
+        TS_SYNC();
+        const size_t rec = (size_t)env * a.nspt + k;
+        if (valid) {
+          for (int e = lane; e < TP_R_SIZE; e += LPE) a.poseR[rec * TP_R_SIZE + e] = c.PP[e];
+          if (lane < TP_D_SIZE) a.poseD[rec * TP_D_SIZE + lane] = c.PPd[lane];
+        }
+      }
+    }
+  }
+  if (valid) {
+    if (bdf2_model && lane < nr) { a.prev[(size_t)env * 2 * nr + lane] = c.qm1D[lane]; a.prev[(size_t)env * 2 * nr + nr + lane] = (double)c.qdm1[lane]; }
+    if (!a.record) {
+      R* st = a.tape + ((size_t)a.t0 * a.B + env) * REC;
+      if (lane < nr) { rec_q(st)[lane] = c.q0D[lane]; st[rec_qd<R>(nr) + lane] = c.qd0[lane]; }
+    }
+    if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
+    if (a.evals && lane == 0) a.evals[env] = evals;
+    if (a.gnorm && lane == 0) a.gnorm[env] = (float)gmax;
+#ifdef TS_PP_TIME
+    if (a.gnorm && lane == 0) a.gnorm[env] = (float)((double)pp_cycles_ / (double)(clock64() - pp_t0_));
+#endif
+  }
+}
+
+
+// ================================================================================================ backward kernel
+template <class R> struct BwdArgs {
+  const int* I; const R* F; const R* Fenv; int fstride;
+  int B, n, t_end;
+  int seed_stride;        // sub-step j (0 = oldest of the n) carries direct loss partials iff (j + 1) % seed_stride == 0
+  int frames;             // 0: seeds [B][n / seed_stride][.], df_du [B][n][nu] per sub-step (tsim_backward_steps)
+                          // 1: seeds [n / seed_stride][B][.], df_du [n / seed_stride][B][nu] summed per env-step (tsim_backward_episode)
+  const int* tac_slot;    // frames mode: slot of frame f in df_dtac (< 0: no tactile seed), null: slot f
+  const R* tape;
+  const R *df_dq, *df_dvar, *df_dtac;
+  R *lamq, *lamv, *df_du;
+  int stage_cpt;
+  long long* cyc;         // diagnostics: shader-clock stamps of the first sub-steps of wavefront 0 (tsim_debug_stamps), or null
+  PushPolicy<R> pol;      // POLICY instantiations only (tsim_push_closed_backward)
+};
+
+// (M z)_j for lane j, M = sum_i J_i^T I_i J_i:  lanes = links form f_i = I_i (sum_{k above i} W_k z_k) in the (idle) pair-staging
+// scratch, then lanes = dofs add up W_j . f_i over the links below dof j.  (The direct double loop per lane was ~600
+// instructions, a tenth of an adjoint sub-step.)
+template <int LPE, class R>
+__device__ __forceinline__ R mass_times_z(const Ctx<R>& c, int lane) {
+  const int* LR = c.LI + ts_sched_rec(c.LI);
+  R* fi = c.PT;                                    // [nl + 1][6], free between phase 2 and the next staging
+  for (int i = 1 + lane; i <= c.nl; i += LPE) {
+    const int anc = LR[(i - 1) * TS_LR_SIZE + TS_LR_ANCMASK];
+    S6<R> A = zero6<R>();
+    for (int k = 0; k < c.nr; ++k)
+      if ((anc >> k) & 1) A = A + ld6(c.WP + k * 6) * c.z[k];
+    const R* X = c.LP + i * LK_SIZE;
+    st6(fi + i * 6, imul(c.F[c.foff_link + (i - 1) * TSIM_LF_SIZE + TSIM_LF_MASS], ldv(X + LK_C), X + LK_IC, A));
+  }
+  TS_SYNC();
+  R tau = R(0);
+  if (lane < c.nr) {
+    const S6<R> Wj = ld6(c.WP + lane * 6);
+    for (int i = 1; i <= c.nl; ++i)
+      if ((LR[(i - 1) * TS_LR_SIZE + TS_LR_ANCMASK] >> lane) & 1) tau += dot6(Wj, ld6(fi + i * 6));
+  }
+  TS_SYNC();
+  return tau;
+}
+
+// lam_q += (dvar/dq)^T w_var + (dtac/dq)^T w_tac ; lam_v += (dtac/dqd)^T w_tac, at the state whose link values and
+// q-tangents (seeds (1,0,0)) are in LDS.  Tactile: reverse mode at the taxel level — each lane forms the gradient of
+// w . out w.r.t. the pair's relative displacement and relative twist (12 numbers, primitive frame); one reduction
+// per (sensor, primitive); lanes = directions then dot it with the pair's per-direction records.
+template <int LPE, class R>
+__device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac) {
+  const int nr = c.nr;
+  if (wvar && lane < nr) {
+    R acc = R(0);
+    const S6<R> Wk = ld6(c.WP + lane * 6);
+    for (int e = 0; e < c.nvar; ++e) {
+      const int l = c.I[c.off_var + e * TSIM_VI_SIZE + TSIM_VI_LINK];
+      if (!((anc_of(c.I, c.off_link, l) >> lane) & 1)) continue;
+      const V3<R> x = mulMv(ldm(c.LP + l * LK_SIZE + LK_R), ldv(c.F + c.foff_var + e * TSIM_VF_SIZE)) + ldv(c.LP + l * LK_SIZE + LK_P);
+      const V3<R> J = cross3(Wk.a, x) + Wk.l;
+      acc += wvar[3 * e] * J.x + wvar[3 * e + 1] * J.y + wvar[3 * e + 2] * J.z;
+    }
+    c.lamq[lane] += acc;
+  }
+  TS_SYNC();
+  if (!wtac) return;
+  for (int s = 0; s < c.nsensor; ++s) {
+    const int* si = c.I + c.off_sensor + s * TSIM_SI_SIZE;
+    const R* sf = c.F + c.foff_sensor + s * TSIM_SF_SIZE;
+    const int t0 = ts_u(si[TSIM_SI_TAX0]), nt = ts_u(si[TSIM_SI_NTAX]), sp0 = ts_u(si[TSIM_SI_SPRIM0]), nsp = ts_u(si[TSIM_SI_NSPRIM]);
+    for (int j = 0; j < nsp; ++j) {
+      const int pk = ts_u(c.I[c.off_sprim + sp0 + j]);
+      const int prim = ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_PRIM]);
+      const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+      TS_SYNC();
+      pair_stage_value(c, pk, 0, lane == 0);
+      TS_SYNC();
+      const R* S = c.PP;
+      const M3<R> RPA = ldm(S + PP_RPA);
+      const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+      R g[12];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) g[e] = R(0);
+      bool any_live = false;
+      // the seed and the position of a chunk's taxels are fetched one chunk ahead: a lone wavefront cannot hide the two dependent
+      // global-memory latencies per chunk (seed -> live? -> position) otherwise
+      R nw0 = R(0), nw1 = R(0), nw2 = R(0), nx0 = R(0), nx1 = R(0), nx2 = R(0);
+      if (lane < nt) {
+        const int t = t0 + lane; const R* tp = c.Fg + c.foff_tax + t;
+        nw0 = wtac[3 * t]; nw1 = wtac[3 * t + 1]; nw2 = wtac[3 * t + 2]; nx0 = tp[0]; nx1 = tp[c.ntax]; nx2 = tp[2 * c.ntax];
+      }
+      for (int base = 0; base < nt; base += LPE) {
+        const bool valid = base + lane < nt;
+        const int t = t0 + (valid ? base + lane : 0);
+        const R* tp = c.Fg + c.foff_tax + t;
+        const R w0 = valid ? nw0 : R(0), w1 = valid ? nw1 : R(0), w2 = valid ? nw2 : R(0);
+        const R x0 = nx0, x1 = nx1, x2 = nx2;
+        if (base + LPE + lane < nt) {
+          const int tn = t0 + base + LPE + lane; const R* tq = c.Fg + c.foff_tax + tn;
+          nw0 = wtac[3 * tn]; nw1 = wtac[3 * tn + 1]; nw2 = wtac[3 * tn + 2]; nx0 = tq[0]; nx1 = tq[c.ntax]; nx2 = tq[2 * c.ntax];
+        }
+        bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
+        V3<R> xP, F; M3<R> Jx, Jv;
+        if (live) {
+          const V3<double> xPd = mulMv(ldm(c.PPd), mk3<double>((double)x0, (double)x1, (double)x2)) + ldv(c.PPd + 9);
+          xP = cvt3<R>(xPd);
+          live = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
+        }
+        if (!__any(live)) continue;
+        any_live = true;
+        if (live) {
+          // weight in the sensor-link frame, then in the primitive frame:  s = wP . F
+          const V3<R> wl = mk3<R>(w0 * tp[3 * c.ntax] + w1 * tp[6 * c.ntax] + w2 * tp[9 * c.ntax],
+                                  w0 * tp[4 * c.ntax] + w1 * tp[7 * c.ntax] + w2 * tp[10 * c.ntax],
+                                  w0 * tp[5 * c.ntax] + w1 * tp[8 * c.ntax] + w2 * tp[11 * c.ntax]);
+          const V3<R> wP = mulMv(RPA, wl);
+          const V3<R> gv = mulMtv(Jv, wP);
+          const V3<R> gx = mulMtv(Jx, wP) + cross3(gv, wrel);       // d s / d(point displacement)
+          const V3<R> ath = cross3(xP, gx) + cross3(wP, F);         // d s / d(relative rotation)
+          const V3<R> bw = cross3(xP, gv);                           // d s / d(relative angular velocity)
+          g[0] += ath.x; g[1] += ath.y; g[2] += ath.z; g[3] += gx.x; g[4] += gx.y; g[5] += gx.z;
+          g[6] += bw.x; g[7] += bw.y; g[8] += bw.z; g[9] += gv.x; g[10] += gv.y; g[11] += gv.z;
+        }
+      }
+      if (!any_live) continue;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) g[e] = seg_sum<LPE>(g[e]);
+      // lanes = directions
+      pair_stage_tangent(c, pk, 0, lane, R(1), 0);
+      if (lane < nr) {
+        const R* T = c.PT + lane * PT_SIZE;
+        R sq_ = R(0);
+#pragma unroll
+        for (int e = 0; e < 12; ++e) sq_ += g[e] * T[e];
+        c.lamq[lane] += sq_;
+      }
+      pair_stage_tangent(c, pk, 0, lane, R(1), 1);
+      if (lane < nr) {
+        const R* T = c.PT + lane * PT_SIZE;
+        R sv_ = R(0);
+#pragma unroll
+        for (int e = 6; e < 12; ++e) sv_ += g[e] * T[e];
+        c.lamv[lane] += sv_;
+      }
+    }
+  }
+  TS_SYNC();
+}
+
+template <class R, int NRM, bool EXPJ, int LPE, bool POLICY = false, class MS = void>
+__global__ void TS_KLB k_backward(BwdArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R* lds = reinterpret_cast<R*>(smem_raw);
+  constexpr int NS = TS_WAVE / LPE;
+  const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
+  const bool valid = (int)blockIdx.x * NS + slot < a.B;
+  const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
+  const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
+  R* H2 = c.H2;    // taped Newton matrix of the sub-step
+  init_world(c, lane, LPE);
+  if (a.cyc && blockIdx.x == 0) c.stamps = a.cyc;
+  if (lane < nr) { c.lamq[lane] = a.lamq[(size_t)env * nr + lane]; c.lamv[lane] = a.lamv[(size_t)env * nr + lane]; }
+  // BDF2 models: taped sub-step t >= 2 is a BDF2 step (the first one after a reset is the BDF1 start-up, k_forward).  Its new state
+  // depends on the TWO states before it, so next to the adjoint of the state one step back (lamq, lamv) the kernel carries what later
+  // sub-steps already contributed to the state two steps back (lq1, lv1: one value per lane, in registers; second half of the buffers).
+  const bool bdf2_model = ts_u(c.I[TSIM_IH_INTEGRATOR]) == 2;
+  const size_t half = (size_t)a.B * nr;
+  R lq1 = R(0), lv1 = R(0);
+  if (bdf2_model && lane < nr) { lq1 = a.lamq[half + (size_t)env * nr + lane]; lv1 = a.lamv[half + (size_t)env * nr + lane]; }
+  TS_SYNC();
+  R du_frame = R(0);
+  R pol_dq = R(0); bool pol_have = false;      // POLICY: what the NEXT frame's observation put on this frame's final state (q[0..2]; tactile: pol.dobs_tac)
+  // The tape record of sub-step t (q1, qd1, u, H) and the state before it (q, qd of record t - 1) are fetched ONE ITERATION AHEAD
+  // into registers: a lone wavefront cannot hide the ~2 x 1.5 k cycles of HBM latency of dependent loads at the top of every
+  // sub-step, but the loads for the next sub-step fly during the whole of this one.  (Record t - 1 supplies q0, qd0 now and
+  // q1, qd1 of the next iteration, so each iteration fetches u, H of record t - 1 and q, qd of record t - 2.)
+  constexpr int NHL = (NRM * NRM + LPE - 1) / LPE;
+  const int oqd = rec_qd<R>(nr), oH = rec_H<R>(nr), ou = rec_u<R>(nr);
+  double pq1 = 0.0, pq0 = 0.0; R pqd1 = R(0), pqd0 = R(0), pqdm = R(0), pu = R(0), pH[NHL];     // pqdm: qd two records back (BDF2)
+  {
+    const R* r1 = a.tape + ((size_t)a.t_end * a.B + env) * REC;
+    const R* r0 = a.tape + ((size_t)(a.t_end - 1) * a.B + env) * REC;
+    if (lane < nr) { pq1 = rec_q(r1)[lane]; pqd1 = r1[oqd + lane]; pq0 = rec_q(r0)[lane]; pqd0 = r0[oqd + lane]; }
+    if (bdf2_model && a.t_end >= 2 && lane < nr) pqdm = a.tape[((size_t)(a.t_end - 2) * a.B + env) * REC + oqd + lane];
+    if (lane < nu) pu = r1[ou + lane];
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; pH[i] = e < nr * nr ? r1[oH + e] : R(0); }
+  }
+  for (int j = a.n - 1; j >= 0; --j) {
+    const int t = a.t_end - (a.n - 1 - j);
+    const bool bdf2 = bdf2_model && t >= 2;
+    c.cv = bdf2 ? R(1.5) / c.h : R(1) / c.h;
+    c.ca = bdf2 ? R(2.25) / (c.h * c.h) : R(1) / (c.h * c.h);
+    if (lane < nr) {
+      c.qD[lane] = pq1; c.q[lane] = (R)pq1; c.q0[lane] = (R)pq0; c.qd0[lane] = pqd0;
+      c.qd[lane] = pqd1;                              // taped velocity of the new state
+      // discrete acceleration from the taped velocities, no position cancellation: BDF1 (qd1 - qd0) / h, BDF2 (3 qd1 - 4 qd0 + qd_1) / 2h
+      c.qa[lane] = bdf2 ? (R(3) * pqd1 - R(4) * pqd0 + pqdm) / (R(2) * c.h) : (pqd1 - pqd0) / c.h;
+    }
+    if (lane < nu) c.u[lane] = pu;
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; if (e < nr * nr) H2[e] = pH[i]; }
+    TS_STAMP(c);
+    if (j > 0) {                                      // next iteration: sub-step t - 1
+      const R* r1 = a.tape + ((size_t)(t - 1) * a.B + env) * REC;
+      const R* r0 = a.tape + ((size_t)(t - 2) * a.B + env) * REC;
+      pq1 = pq0; pqd1 = pqd0;
+      if (lane < nr) { pq0 = rec_q(r0)[lane]; pqd0 = r0[oqd + lane]; }
+      if (bdf2_model && t >= 3 && lane < nr) pqdm = a.tape[((size_t)(t - 3) * a.B + env) * REC + oqd + lane];
+      if (lane < nu) pu = r1[ou + lane];
+#pragma unroll
+      for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; pH[i] = e < nr * nr ? r1[oH + e] : R(0); }
+    }
+    TS_SYNC();
+    TS_STAMP(c);
+    if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
+    else phase1_static<R, MS, true>(c, lane, R(1), R(0), R(0));
+    TS_STAMP(c);
+    // direct partials of the loss w.r.t. this sub-step's outputs
+    const bool seeded = (j + 1) % a.seed_stride == 0;
+    if (seeded) {
+      const int fr = j / a.seed_stride;
+      const size_t so = a.frames ? (size_t)fr * a.B + env : (size_t)env * (a.n / a.seed_stride) + fr;
+      const int tslot = (a.frames && a.tac_slot) ? a.tac_slot[fr] : 0;
+      const size_t sot = (a.frames && a.tac_slot) ? (size_t)max(tslot, 0) * a.B + env : so;
+      if (a.df_dq && lane < nr) c.lamq[lane] += a.df_dq[so * nr + lane];
+      if (POLICY && pol_have && lane < nr) c.lamq[lane] += pol_dq;       // state part of the next frame's observation (goal; privilege: box pose)
+      TS_SYNC();
+      const R* wtac_ = (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr;
+      if (POLICY) wtac_ = (pol_have && a.pol.mode == TSIM_PUSH_OBS_TACTILE) ? a.pol.dobs_tac + ((size_t)(fr + 1) * a.B + env) * PP_NTAC : nullptr;   // tactile part (frame fr + 1's observation)
+      output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, wtac_);
+    }
+    TS_STAMP(c);
+    if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.cv * c.lamv[lane];      // d qd1 / d q1 = cv
+    TS_SYNC();
+    solve_newton<R, NRM, LPE>(H2, c.rhs, c.z, nr, true, lane);
+    TS_STAMP(c);
+    phase2<R, NRM, LPE>(c, lane, R(1));
+    TS_STAMP(c);
+    phase3<R, EXPJ, LPE>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
+    TS_STAMP(c);
+    const R ym = mass_times_z<LPE>(c, lane);
+    TS_STAMP(c);
+    if (lane < nr) {
+      R yq = R(0);
+      for (int i = 0; i < nr; ++i) yq += c.z[i] * c.H[i * nr + lane];
+      if (!bdf2) {                                    // BDF1: new state from (q0, qd0) only
+        c.lamq[lane] = c.lamq[lane] - yq + lq1;       // lq1, lv1: what a later BDF2 step put on this sub-step's (q0, qd0) as ITS (q_1, qd_1)
+        c.lamv[lane] = c.h * ym + lv1;
+        lq1 = R(0); lv1 = R(0);
+      } else {
+        // BDF2 in predictor form: with a_w = d qd1 / d p_w and dqp_w = d qpred / d p_w for p = (q0, qd0, q_1, qd_1),
+        //   -(dg/dp_w)^T z + a_w lam_v = a_w (lam_v - R_v^T z / ca) + dqp_w M z ,   R_v^T z / ca = (rhs - K^T z - M z) / cv
+        // (H = K + (cv R_v + ca M) / ca; rhs = H^T z).  a = (-2/h, 0, 1/2h, 0), dqp = (4/3, 8h/9, -1/3, -2h/9).
+        const R d = c.lamv[lane] - (c.rhs[lane] - yq - ym) / c.cv;
+        const R o0 = R(-2) / c.h * d + R(4.0 / 3) * ym, o1 = R(8.0 / 9) * c.h * ym;
+        const R o2 = R(0.5) / c.h * d - R(1.0 / 3) * ym, o3 = R(-2.0 / 9) * c.h * ym;
+        c.lamq[lane] = o0 + lq1; c.lamv[lane] = o1 + lv1;
+        lq1 = o2; lv1 = o3;
+      }
+    }
+    if (lane < nu) {
+      const int* mi = ts_motor_rec(c, lane);
+      const R* mf = c.F + c.foff_motor + lane * TSIM_MF_SIZE;
+      R dtu;
+      if (mi[TSIM_MI_CTRL] == 0) dtu = (c.u[lane] >= R(-1) && c.u[lane] <= R(1)) ? R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]) : R(0);
+      else dtu = mf[TSIM_MF_P];
+      const R du = c.z[mi[TSIM_MI_DOF]] * dtu / c.ca;         // -(dg/du)^T z, g = r / ca
+      if (!a.frames) { if (valid) a.df_du[((size_t)env * a.n + j) * nu + lane] = du; }
+      else {
+        du_frame += du;
+        if (j % a.seed_stride == 0 && valid && a.df_du) a.df_du[((size_t)(j / a.seed_stride) * a.B + env) * nu + lane] = du_frame;
+      }
+    }
+    if (a.frames && j % a.seed_stride == 0) {              // a frame is undone
+      if (POLICY) {
+        // ... and so is the policy call in front of it: dL/d(action) -> MLP -> observation -> the state / tactile frame before it
+        TS_SYNC();
+        const int fr0 = j / a.seed_stride;
+        pol_dq = push_policy_backward<LPE>(c, lane, valid, a.pol, (size_t)fr0 * a.B + env, env, du_frame, c.q0);
+        pol_have = true;
+        ts_own_stores_visible();                           // dobs_tac is read back by this slot as the previous frame's tactile seed
+      }
+      du_frame = R(0);
+    }
+    TS_SYNC();
+  }
+  if (lane < nr && valid) {
+    a.lamq[(size_t)env * nr + lane] = c.lamq[lane]; a.lamv[(size_t)env * nr + lane] = c.lamv[lane];
+    if (bdf2_model) { a.lamq[half + (size_t)env * nr + lane] = lq1; a.lamv[half + (size_t)env * nr + lane] = lv1; }
+  }
+}
+

@@ -1,0 +1,14 @@
+// tsim_static_pusher.hip — the forward / adjoint kernels instantiated for the TactilePush model (envs/assets/pusher/pusher.xml) with its
+// compiled blob as compile-time constants (tsim_static_pusher.h, generated; tsim_static.h: what that buys).  Its own translation unit because
+// it is built with -ffinite-math-only -fno-signed-zeros — x * 0 -> 0, x + 0 -> x fold away the model's identity joint frames and unit axes —
+// and the generic kernels (tsim_hip.hip) are not.  fp32, four environments per wavefront: the shape of BASELINE.json's headline batch.
+#include <hip/hip_runtime.h>
+#include "tsim_kernels.h"
+#include "tsim_static_pusher.h"
+
+void ts_static_pusher_launch(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_forward<float, 8, false, 16, false, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+}
+void ts_static_pusher_launch(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_backward<float, 8, false, 16, false, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+}

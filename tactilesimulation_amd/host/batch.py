@@ -267,6 +267,13 @@ class BatchSim:
         """16 / 32 / 64 lanes per environment, 0 = automatic (include/tsim.h tsim_set_lanes_per_env)."""
         capi.check(capi.lib().tsim_set_lanes_per_env(self._h, int(lanes)))
 
+    def static_model(self):
+        """Id of the statically specialised kernel instantiation the next launch uses (include/tsim.h tsim_static_model; 0: generic)."""
+        return capi.lib().tsim_static_model(self._h)
+
+    def set_static(self, allow):
+        capi.check(capi.lib().tsim_set_static(self._h, int(bool(allow))))
+
     def launch_info(self):
         out = (C.c_int32 * 4)()
         capi.lib().tsim_launch_info(self._h, out)

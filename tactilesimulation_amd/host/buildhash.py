@@ -48,7 +48,25 @@ HIP_SO = os.path.join(CSRC, "libtsim_hip.so")
 #   13 % fewer static instructions measured 1 - 2 % faster on every bench leg (profiles/r03_pmc_wait_decomposition.md)
 # -fno-slp-vectorize: packing scalar fp32 math into v_pk_* pairs costs more v_mov than it saves FMAs here and pushes the kernels over
 #   256 registers (measured: +9 %, profiles/r01_launch_shape_ab.txt)
-HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-function-calls=false"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-function-calls=false"]
+# Translation units of the library and the extra flags of each.  -ffinite-math-only -fno-signed-zeros (x * 0 -> 0 and x + 0 -> x may be folded:
+# exact for every finite x, only the sign of a zero can differ) go ONLY to the kernels instantiated for a statically known model
+# (csrc/tsim_static.h): there they turn the generic link sweep into the handful of operations the model's structure leaves; the generic
+# kernels — whose fp64 instantiations walk the oracle's iterates to round-off — are built without them.
+HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros"])]
+
+
+def hip_build_commands(hipcc, out_so=None):
+    """[(argv, cwd)] that build libtsim_hip.so: one compile per translation unit into csrc/build/, then the link."""
+    out_so = out_so or HIP_SO
+    bdir = os.path.join(CSRC, "build")
+    cmds, objs = [], []
+    for src, extra in HIP_UNITS:
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        cmds.append(([hipcc] + HIP_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj], CSRC))
+        objs.append(obj)
+    cmds.append(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_so] + objs, CSRC))
+    return bdir, cmds
 
 
 def hip_sources():
@@ -58,4 +76,4 @@ def hip_sources():
 
 
 def hip_digest():
-    return digest(hip_sources(), HIP_FLAGS)
+    return digest(hip_sources(), HIP_FLAGS + [u + ":" + " ".join(f) for u, f in HIP_UNITS])
