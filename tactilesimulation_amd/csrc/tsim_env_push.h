@@ -155,6 +155,9 @@ static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, i
 }
 #define TS_LAUNCH_POLICY(KERNEL, R, b, st, a) do {                                                                                   \
     const LaunchShape L = launch_shape(b);                                                                                           \
+    if constexpr (sizeof(R) == 4) {      /* the statically specialised TactilePush instantiation (tsim_static_pusher.hip) */           \
+      if (b->static_id == 1 && L.lpe == 16 && !b->dFenv && !b->no_static) { ts_static_pusher_launch_policy(a, L.grid, L.lds, st); break; }   \
+    }                                                                                                                                 \
     if (L.lpe == 64) hipLaunchKernelGGL((KERNEL<R, 8, false, 64, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                  \
     else if (L.lpe == 32) hipLaunchKernelGGL((KERNEL<R, 8, false, 32, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);             \
     else hipLaunchKernelGGL((KERNEL<R, 8, false, 16, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                              \

@@ -625,6 +625,8 @@ static void decide_stage_cpt(tsim_batch* b) {
 // launchers of the statically specialised instantiations (tsim_static_pusher.hip)
 void ts_static_pusher_launch(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 void ts_static_pusher_launch(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
+void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);      // ... with the policy between the frames
+void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
 // compiled out otherwise: it costs registers in every evaluation); LPE as above
 #define TS_LAUNCH_L(KERNEL, R, NRM, L, st, a) do {                                                                       \

@@ -12,3 +12,10 @@ void ts_static_pusher_launch(const FwdArgs<float>& a, unsigned grid, size_t lds,
 void ts_static_pusher_launch(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((k_backward<float, 8, false, 16, false, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
 }
+// closed loop: the TactilePush policy between the frames (tsim_policy_push.h)
+void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_forward<float, 8, false, 16, true, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+}
+void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_backward<float, 8, false, 16, true, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+}
