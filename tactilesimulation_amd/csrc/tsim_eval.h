@@ -641,7 +641,11 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
   TS_SYNC();
   TS_STAMP(c);
   if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
-  else phase1_static<R, MS, true, false>(c, lane, sq, sv, sa);       // a statically known model: tsim_static.h (forward: no COM / inertia records)
+#ifdef TS_STATIC_BRANCH_BLOCKS
+  else phase1_static<R, MS, true, false>(c, lane, sq, sv, sa);       // A/B: the block-per-branch form
+#else
+  else phase1_static_levels<R, MS, true, false>(c, lane, sq, sv, sa);      // a statically known model: tsim_static.h (forward: no COM / inertia records)
+#endif
   TS_STAMP(c);
   phase2<R, NRM, LPE>(c, lane, sq);
   TS_STAMP(c);

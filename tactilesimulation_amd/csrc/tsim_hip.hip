@@ -337,44 +337,6 @@ __global__ void __launch_bounds__(TS_WAVE) k_signature(SigArgs<R> a) {
   }
 }
 
-// ================================================================================================ debug evaluation
-template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; int stage_cpt; };
-
-template <class R, int LPE>
-__global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  R* lds = reinterpret_cast<R*>(smem_raw);
-  constexpr int NS = TS_WAVE / LPE;
-  const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
-  const bool valid = (int)blockIdx.x * NS + slot < a.B;
-  const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
-  const int nr = c.nr, nu = c.nu;
-  init_world(c, lane, LPE);
-  if (lane < nr) {
-    c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane];
-    c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane];
-    c.dl[lane] = a.q1[(size_t)env * nr + lane] - c.qp[lane];
-    c.qpD[lane] = (double)a.q1[(size_t)env * nr + lane] - (double)c.dl[lane];      // so that qD = qpD + dl is the given q1
-  }
-  if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
-  TS_SYNC();
-  if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve; one row
-                 // per wavefront (the row of its first environment), the other rows stay zero
-    c.stamps = a.cyc + (size_t)env * 32;
-    evaluate<R, 8, false, LPE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
-    if (lane < nr) c.rhs[lane] = -c.g[lane];
-    TS_SYNC();
-    solve_newton<R, 8, LPE>(c.H, c.rhs, c.dq, nr, false, lane);
-    TS_STAMP(c);
-    if (lane == 0 && valid) for (int i = (slot == 0 ? c.nstamp : 0); i < 32; ++i) c.stamps[i] = 0;
-  } else {
-    evaluate<R, 16, true, LPE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
-  }
-  if (lane < nr && valid) a.g[(size_t)env * nr + lane] = c.g[lane];
-  if (valid) for (int e = lane; e < nr * nr; e += LPE) a.H[(size_t)env * nr * nr + e] = c.H[e];
-}
-
 // ================================================================================================ host side
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
@@ -627,6 +589,7 @@ void ts_static_pusher_launch(const FwdArgs<float>& a, unsigned grid, size_t lds,
 void ts_static_pusher_launch(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);      // ... with the policy between the frames
 void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
+void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
 // compiled out otherwise: it costs registers in every evaluation); LPE as above
 #define TS_LAUNCH_L(KERNEL, R, NRM, L, st, a) do {                                                                       \
@@ -1055,7 +1018,8 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
   const size_t lds = lds_bytes_for(b, ns);
   if (b->dtype == TSIM_F32) {
     DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles, b->stage_cpt};
-    if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<float, 16>), grid, blk, lds, (hipStream_t)stream, a);
+    if (lpe == 16 && b->static_id == 1 && !b->dFenv && !b->no_static) ts_static_pusher_launch_debug(a, grid.x, lds, (hipStream_t)stream);      // the static sweep's g and H
+    else if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<float, 16>), grid, blk, lds, (hipStream_t)stream, a);
     else if (lpe == 32) hipLaunchKernelGGL((k_debug_eval<float, 32>), grid, blk, lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_debug_eval<float, 64>), grid, blk, lds, (hipStream_t)stream, a);
   } else {

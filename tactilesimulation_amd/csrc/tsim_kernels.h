@@ -534,7 +534,11 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     TS_SYNC();
     TS_STAMP(c);
     if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
+#ifdef TS_STATIC_BRANCH_BLOCKS
     else phase1_static<R, MS, true>(c, lane, R(1), R(0), R(0));
+#else
+    else phase1_static_levels<R, MS, true>(c, lane, R(1), R(0), R(0));
+#endif
     TS_STAMP(c);
     // direct partials of the loss w.r.t. this sub-step's outputs
     const bool seeded = (j + 1) % a.seed_stride == 0;
@@ -609,5 +613,46 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     a.lamq[(size_t)env * nr + lane] = c.lamq[lane]; a.lamv[(size_t)env * nr + lane] = c.lamv[lane];
     if (bdf2_model) { a.lamq[half + (size_t)env * nr + lane] = lq1; a.lamv[half + (size_t)env * nr + lane] = lv1; }
   }
+}
+
+
+// ================================================================================================ debug evaluation
+template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; int stage_cpt; };
+
+template <class R, int LPE, class MS = void>
+__global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  R* lds = reinterpret_cast<R*>(smem_raw);
+  constexpr int NS = TS_WAVE / LPE;
+  const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
+  const bool valid = (int)blockIdx.x * NS + slot < a.B;
+  const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
+  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  const int nr = c.nr, nu = c.nu;
+  init_world(c, lane, LPE);
+  if (lane < nr) {
+    c.q0[lane] = a.q0[(size_t)env * nr + lane]; c.qd0[lane] = a.qd0[(size_t)env * nr + lane];
+    c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane];
+    c.dl[lane] = a.q1[(size_t)env * nr + lane] - c.qp[lane];
+    c.qpD[lane] = (double)a.q1[(size_t)env * nr + lane] - (double)c.dl[lane];      // so that qD = qpD + dl is the given q1
+  }
+  if (lane < nu) c.u[lane] = a.u[(size_t)env * nu + lane];
+  TS_SYNC();
+  if (a.cyc) {   // shader-clock stamps (s_memtime) at the TS_STAMP points of one evaluation + the dense solve; one row
+                 // per wavefront (the row of its first environment), the other rows stay zero
+    c.stamps = a.cyc + (size_t)env * 32;
+    evaluate<R, 8, false, LPE, MS>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+    if (lane < nr) c.rhs[lane] = -c.g[lane];
+    TS_SYNC();
+    solve_newton<R, 8, LPE>(c.H, c.rhs, c.dq, nr, false, lane);
+    TS_STAMP(c);
+    if (lane == 0 && valid) for (int i = (slot == 0 ? c.nstamp : 0); i < 32; ++i) c.stamps[i] = 0;
+  } else if constexpr (std::is_void<MS>::value) {
+    evaluate<R, 16, true, LPE>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+  } else {
+    evaluate<R, 8, false, LPE, MS>(c, lane, R(1), R(1) / c.h, R(1) / (c.h * c.h));
+  }
+  if (lane < nr && valid) a.g[(size_t)env * nr + lane] = c.g[lane];
+  if (valid) for (int e = lane; e < nr * nr; e += LPE) a.H[(size_t)env * nr * nr + e] = c.H[e];
 }
 

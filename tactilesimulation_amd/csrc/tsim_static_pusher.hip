@@ -19,3 +19,7 @@ void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size
 void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((k_backward<float, 8, false, 16, true, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
 }
+// one residual + Newton-matrix evaluation (tsim_debug_eval: parity tests, shader-clock stamps)
+void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((k_debug_eval<float, 16, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+}
