@@ -310,6 +310,14 @@ template <int LPE, class R> __device__ __forceinline__ R seg_sum(R x) {
   x += dpp_r<0x143, 0xc>(x);   // row_bcast:31    -> rows 2 and 3 add the total of rows 0-1; lane 63 has the sum
   return lane_bcast(x, 63);
 }
+// sum over lanes 0..7 of each 8-lane half of a 16-lane row (three DPP steps): for per-pair sums whose points all sit in the first 8 lanes of
+// the slot (the other lanes hold zeros), result in lanes 0..7
+template <class R> __device__ __forceinline__ R half_row_sum(R x) {
+  x += dpp_r<0xB1, 0xf>(x);    // quad_perm [1,0,3,2]
+  x += dpp_r<0x4E, 0xf>(x);    // quad_perm [2,3,0,1]
+  x += dpp_r<0x141, 0xf>(x);   // row_half_mirror
+  return x;
+}
 // maximum over the LPE lanes of the caller's slot, result in every lane of the slot (x >= 0)
 template <int LPE, class R> __device__ __forceinline__ R seg_max(R x) {
   x = t_max(x, dpp_r<0xB1, 0xf>(x));

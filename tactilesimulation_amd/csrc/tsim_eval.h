@@ -284,18 +284,22 @@ __device__ __forceinline__ void pair_stage_tangent(const Ctx<R>& c, int pk, int 
 // dv) — independent of the number of directions; one segmented reduction per pair; then lanes = directions apply M to
 // their own 12-vector.  (The first version evaluated dF, dn per point AND per direction: 7 x 54 FMA per point on
 // TactilePush against ~170 here.)
-template <class R, int NRM, int LPE>
+// PRIMC / FLAGSC >= 0: the pair's primitive type and flags as compile-time constants (a statically known model, tsim_static.h): the type switch
+// of contact_law disappears and, for the flat-faced primitives (plane, cuboid: no curvature term), so does every product with it
+// NPTC >= 0: the pair's point count, also static — used only to narrow the reduction when all points sit in the first 8 lanes of the slot
+template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
 __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
   const int pt0 = ts_u(pi[TSIM_PI_PT0]), npt = ts_u(pi[TSIM_PI_NPT]);
-  const int prim = ts_u(pi[TSIM_PI_PRIM]);
-  const bool sphere_plane = (ts_u(pi[TSIM_PI_FLAGS]) & 2) != 0;
+  const int prim = PRIMC >= 0 ? PRIMC : ts_u(pi[TSIM_PI_PRIM]);
+  const bool sphere_plane = ((FLAGSC >= 0 ? FLAGSC : ts_u(pi[TSIM_PI_FLAGS])) & 2) != 0;
   R* S = c.PP + slot * PP_SIZE;
   const M3<double> RPAd = ldm(c.PPd + slot * 12);
   const V3<double> pPAd = ldv(c.PPd + slot * 12 + 9);
   const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+  const M3<R> RPA = ldm(S + PP_RPA); const V3<R> pPA = ldv(S + PP_PPA);      // R-precision copy of the staged pose (the far test of static models)
   R w0[6], M[6][12];               // value wrench (n; F) and d(n; F) / d(dth, drho, dw, dv)
 #pragma unroll
   for (int e = 0; e < 6; ++e) {
@@ -311,11 +315,17 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
     M3<R> Jx, Jv;
     if (pidx < npt) {
       const V3<R> cp = ld_cpt(c, pt0 + pidx);                // SoA: consecutive lanes -> consecutive addresses
-      V3<double> xPd = mulMv(RPAd, cvt3<double>(cp)) + pPAd;
-      cP = cvt3<R>(xPd);
-      if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
-      xP = cvt3<R>(xPd);
-      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
+      // "certainly outside" in the kernel's own precision first (static models: TS_FAR_MARGIN is far above the rounding of an R-precision
+      // pose product, so the set of points contact_law accepts is unchanged): the far cap of a pad never gets to the double-precision part
+      bool near_ = true;
+      if (PRIMC >= 0 && sizeof(R) == 4 && !sphere_plane) near_ = prim_distance<R>(prim, pf + TSIM_PF_SHAPE, mulMv(RPA, cp) + pPA) < R(TS_FAR_MARGIN);
+      if (near_) {
+        V3<double> xPd = mulMv(RPAd, cvt3<double>(cp)) + pPAd;
+        cP = cvt3<R>(xPd);
+        if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
+        xP = cvt3<R>(xPd);
+        hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
+      }
     }
     if (!__any(hit)) continue;
     any_hit = true;
@@ -365,11 +375,12 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
   }
   TS_STAMP2(c);
   if (!any_hit) return;
+  constexpr bool kHalfRow = NPTC >= 0 && NPTC <= 8 && NRM <= 8;      // all points (and all directions) in the first 8 lanes of the slot
 #pragma unroll
   for (int e = 0; e < 6; ++e) {
-    w0[e] = seg_sum<LPE>(w0[e]);
+    w0[e] = kHalfRow ? half_row_sum(w0[e]) : seg_sum<LPE>(w0[e]);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) M[e][j] = seg_sum<LPE>(M[e][j]);
+    for (int j = 0; j < 12; ++j) M[e][j] = kHalfRow ? half_row_sum(M[e][j]) : seg_sum<LPE>(M[e][j]);
   }
   TS_STAMP2(c);
   if (lane == 0) {
@@ -473,10 +484,20 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
   }
 }
 
-template <class R, int NRM, int LPE>
+template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
 __device__ __forceinline__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
-  if (sizeof(R) == 4) pair_contacts_matrix<R, NRM, LPE>(c, pk, slot, lane);
+  if (sizeof(R) == 4) pair_contacts_matrix<R, NRM, LPE, PRIMC, FLAGSC, NPTC>(c, pk, slot, lane);
   else pair_contacts_per_direction<R, NRM, LPE>(c, pk, slot, lane);
+}
+// the contact loops of a group of pairs with each pair's primitive type / flags taken from the static model (template recursion over the pairs)
+template <class R, int NRM, int LPE, class MS, int PK>
+__device__ __forceinline__ void pair_contacts_static(const Ctx<R>& c, int p0, int pe, int lane) {
+  constexpr int NP = MS::Iv(TSIM_IH_NPAIR);
+  if constexpr (PK < NP) {
+    constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + PK * TSIM_PI_SIZE, flags = MS::Iv(o + TSIM_PI_FLAGS), prim = MS::Iv(o + TSIM_PI_PRIM), npt = MS::Iv(o + TSIM_PI_NPT);
+    if constexpr ((flags & 1) != 0) { if (PK >= p0 && PK < pe) pair_contacts<R, NRM, LPE, prim, flags, npt>(c, PK, PK - p0, lane); }
+    pair_contacts_static<R, NRM, LPE, MS, PK + 1>(c, p0, pe, lane);
+  }
 }
 
 // lanes = directions: bring the staged pair's wrench (value + tangent k) to the world frame and fold it into the links
@@ -503,7 +524,7 @@ __device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int
   }
 }
 
-template <class R, int NRM, int LPE>
+template <class R, int NRM, int LPE, class MS = void>
 __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
   for (int p0 = 0; p0 < c.npair; p0 += TS_PAIR_GROUP) {
     const int pe = min(p0 + TS_PAIR_GROUP, c.npair), np = pe - p0;
@@ -527,8 +548,10 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
     }
     TS_SYNC();
     TS_STAMP(c);
-    for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
-      if (ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
+    if constexpr (std::is_void<MS>::value) {
+      for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
+        if (ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
+    } else pair_contacts_static<R, NRM, LPE, MS, 0>(c, p0, pe, lane);
     TS_SYNC();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = directions; serial over pairs: two pairs may touch the same link
@@ -647,7 +670,7 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
   else phase1_static_levels<R, MS, true, false>(c, lane, sq, sv, sa);      // a statically known model: tsim_static.h (forward: no COM / inertia records)
 #endif
   TS_STAMP(c);
-  phase2<R, NRM, LPE>(c, lane, sq);
+  phase2<R, NRM, LPE, MS>(c, lane, sq);
   TS_STAMP(c);
   phase3<R, EXPJ, LPE>(c, lane, sq, sv);
   TS_STAMP(c);

@@ -559,7 +559,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     TS_SYNC();
     solve_newton<R, NRM, LPE>(H2, c.rhs, c.z, nr, true, lane);
     TS_STAMP(c);
-    phase2<R, NRM, LPE>(c, lane, R(1));
+    phase2<R, NRM, LPE, MS>(c, lane, R(1));
     TS_STAMP(c);
     phase3<R, EXPJ, LPE>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
     TS_STAMP(c);
