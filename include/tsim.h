@@ -171,8 +171,8 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes
 /* Statically known models.  The library carries, next to the generic kernels, instantiations of the forward / adjoint kernels for models
  * whose compiled blob it was built with (csrc/tsim_static.h; round 4: TactilePush, envs/assets/pusher/pusher.xml): tree, joint types, joint
  * frames and axes are compile-time constants there and the link sweep folds to what the model's structure leaves.  They are used when the
- * batch's blob equals the compiled-in one bit for bit (checked at tsim_batch_create / tsim_update_model), the batch is fp32 at four
- * environments per wavefront and has no per-environment tables; results equal the generic kernels' (tests/test_gpu_static_model.py).
+ * batch's blob equals the compiled-in one bit for bit (checked at tsim_batch_create / tsim_update_model), the batch is fp32 and has no
+ * per-environment tables; results equal the generic kernels' to fp32 rounding (tests/test_gpu_static_model.py).
  * tsim_static_model returns the id of the instantiation the NEXT launch will use (0: generic, 1: TactilePush); tsim_set_static(b, 0)
  * keeps a batch on the generic kernels (also: environment variable TSIM_NO_STATIC at creation), tsim_set_static(b, 1) allows them again. */
 int tsim_static_model(const tsim_batch* b);

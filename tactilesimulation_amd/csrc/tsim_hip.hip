@@ -585,8 +585,8 @@ static void decide_stage_cpt(tsim_batch* b) {
   if (launch_shape(b).lpe != lpe0 || lds_bytes_for(b, 1) > 64 * 1024) b->stage_cpt = 0;
 }
 // launchers of the statically specialised instantiations (tsim_static_pusher.hip)
-void ts_static_pusher_launch(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
-void ts_static_pusher_launch(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
+void ts_static_pusher_launch(const FwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
+void ts_static_pusher_launch(const BwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
 void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);      // ... with the policy between the frames
 void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
@@ -600,8 +600,8 @@ void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_
 #define TS_LAUNCH(KERNEL, R, b, st, a) do {                                                                              \
     const LaunchShape L = launch_shape(b);                                                                               \
     if constexpr (sizeof(R) == 4) {      /* a statically known model (tsim_static.h): instantiated in its own translation unit */ \
-      if (b->static_id == 1 && L.lpe == 16 && !b->dFenv && !b->no_static) {                                               \
-        ts_static_pusher_launch(a, L.grid, L.lds, st);                                                                    \
+      if (b->static_id == 1 && !b->dFenv && !b->no_static) {                                                              \
+        ts_static_pusher_launch(a, L.lpe, L.grid, L.lds, st);                                                             \
         break;                                                                                                            \
       }                                                                                                                   \
     }                                                                                                                     \
@@ -747,7 +747,7 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
   return 0;
 }
 int tsim_static_model(const tsim_batch* b) {
-  return (b->static_id == 1 && !b->no_static && b->dtype == TSIM_F32 && !b->dFenv && launch_shape(b).lpe == 16) ? 1 : 0;
+  return (b->static_id == 1 && !b->no_static && b->dtype == TSIM_F32 && !b->dFenv) ? 1 : 0;
 }
 int tsim_set_static(tsim_batch* b, int allow) { b->no_static = allow ? 0 : 1; return 0; }
 int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {

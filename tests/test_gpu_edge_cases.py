@@ -131,14 +131,23 @@ def test_on_demand_readout_equals_the_step_outputs(name, dtype):
     else:                                                            # stable_grasp: close the fingers on the stack
         q0 = np.zeros((B, m.ndof_r)); u = np.zeros((B, T, m.ndof_u)); u[:, :, -2:] = 1.0
     sim = BatchSim(m, B, dtype=dtype, tape_capacity=0)
-    sim.reset(torch.tensor(q0), None, backward_flag=False)
-    steps = 60 if name == "tactile_pad" else T                       # the pad needs ~100 BDF2 steps to reach the ball: 60 x 2
-    for t in range(steps):
-        o = sim.step(torch.tensor(u[:, min(t, T - 1)]), 2 if name == "tactile_pad" else S)
-    var, tac = sim.readout()
-    assert torch.equal(tac, o["tactile"])
-    if var is not None:
-        assert torch.equal(var, o["var"])
+    # The statement is about the GENERIC kernels: the read-out kernels are generic ones.  A batch on the statically specialised TactilePush
+    # kernels (fp32; csrc/tsim_static.h) is another fp32 rounding of the same link poses: there the two agree to 1e-6 of the frame's maximum
+    # (second pass below), not bit for bit.  (tolerance 1e-5 of the frame maximum)
+    for static in ([False, True] if sim.static_model() else [False]):
+        sim.set_static(static)
+        sim.reset(torch.tensor(q0), None, backward_flag=False)
+        steps = 60 if name == "tactile_pad" else T                   # the pad needs ~100 BDF2 steps to reach the ball: 60 x 2
+        for t in range(steps):
+            o = sim.step(torch.tensor(u[:, min(t, T - 1)]), 2 if name == "tactile_pad" else S)
+        var, tac = sim.readout()
+        if not static:
+            assert torch.equal(tac, o["tactile"])
+            if var is not None:
+                assert torch.equal(var, o["var"])
+        else:
+            assert float((tac - o["tactile"]).abs().max()) <= 1e-5 * float(tac.abs().max())
+            assert float((var - o["var"]).abs().max()) <= 1e-6
     if name in ("pusher", "tactile_pad", "tactile_insertion"):       # scenarios known to load taxels (the other two compare zeros and variables)
         assert float(tac.abs().max()) > 0, "the scenario never loaded a taxel: nothing was compared"
 
