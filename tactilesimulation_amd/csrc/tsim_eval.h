@@ -287,20 +287,15 @@ __device__ __forceinline__ void pair_stage_tangent(const Ctx<R>& c, int pk, int 
 // PRIMC / FLAGSC >= 0: the pair's primitive type and flags as compile-time constants (a statically known model, tsim_static.h): the type switch
 // of contact_law disappears and, for the flat-faced primitives (plane, cuboid: no curvature term), so does every product with it
 // NPTC >= 0: the pair's point count, also static — used only to narrow the reduction when all points sit in the first 8 lanes of the slot
-template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
-__device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane) {
-  const int nd = c.nd;
-  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
-  const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
-  const int pt0 = ts_u(pi[TSIM_PI_PT0]), npt = ts_u(pi[TSIM_PI_NPT]);
-  const int prim = PRIMC >= 0 ? PRIMC : ts_u(pi[TSIM_PI_PRIM]);
-  const bool sphere_plane = ((FLAGSC >= 0 ? FLAGSC : ts_u(pi[TSIM_PI_FLAGS])) & 2) != 0;
-  R* S = c.PP + slot * PP_SIZE;
-  const M3<double> RPAd = ldm(c.PPd + slot * 12);
-  const V3<double> pPAd = ldv(c.PPd + slot * 12 + 9);
-  const V3<R> wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
-  const M3<R> RPA = ldm(S + PP_RPA); const V3<R> pPA = ldv(S + PP_PPA);      // R-precision copy of the staged pose (the far test of static models)
-  R w0[6], M[6][12];               // value wrench (n; F) and d(n; F) / d(dth, drho, dw, dv)
+// the staged pose of a pair as VALUES: pose of link A in the primitive's frame (double and R precision), relative twist there
+template <class R> struct PairPose { M3<double> RPAd; V3<double> pPAd; M3<R> RPA; V3<R> pPA; V3<R> wrel, vrel; };
+// The point loop of the matrix form: lanes = contact points; accumulates, per lane, the value wrench w0 and the 6 x 12 matrix M of its points.
+// Returns whether any lane of the WAVEFRONT had a penetrating point (wave-uniform).  pf: the pair's float record (shape at TSIM_PF_SHAPE,
+// penalty parameters from TSIM_PF_KN) — LDS for the generic kernels, an array of compile-time constants for a static model.
+template <class R, int LPE, int PRIMC, int FLAGSC>
+__device__ __forceinline__ bool pair_points_matrix(const Ctx<R>& c, int pt0, int npt, int prim, bool sphere_plane, const R* pf, const PairPose<R>& P, int lane, R (&w0)[6], R (&M)[6][12]) {
+  const M3<double> RPAd = P.RPAd; const V3<double> pPAd = P.pPAd;
+  const M3<R> RPA = P.RPA; const V3<R> pPA = P.pPA, wrel = P.wrel, vrel = P.vrel;
 #pragma unroll
   for (int e = 0; e < 6; ++e) {
     w0[e] = R(0);
@@ -373,6 +368,24 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
       M[0][5] -= F.y; M[1][5] += F.x;
     }
   }
+  return any_hit;
+}
+
+template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
+__device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane) {
+  const int nd = c.nd;
+  const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
+  const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
+  const int pt0 = ts_u(pi[TSIM_PI_PT0]), npt = ts_u(pi[TSIM_PI_NPT]);
+  const int prim = PRIMC >= 0 ? PRIMC : ts_u(pi[TSIM_PI_PRIM]);
+  const bool sphere_plane = ((FLAGSC >= 0 ? FLAGSC : ts_u(pi[TSIM_PI_FLAGS])) & 2) != 0;
+  R* S = c.PP + slot * PP_SIZE;
+  PairPose<R> P;
+  P.RPAd = ldm(c.PPd + slot * 12); P.pPAd = ldv(c.PPd + slot * 12 + 9);
+  P.wrel = ldv(S + PP_WREL); P.vrel = ldv(S + PP_VREL);
+  P.RPA = ldm(S + PP_RPA); P.pPA = ldv(S + PP_PPA);      // R-precision copy of the staged pose (the far test of static models)
+  R w0[6], M[6][12];               // value wrench (n; F) and d(n; F) / d(dth, drho, dw, dv)
+  const bool any_hit = pair_points_matrix<R, LPE, PRIMC, FLAGSC>(c, pt0, npt, prim, sphere_plane, pf, P, lane, w0, M);
   TS_STAMP2(c);
   if (!any_hit) return;
   constexpr bool kHalfRow = NPTC >= 0 && NPTC <= 8 && NRM <= 8;      // all points (and all directions) in the first 8 lanes of the slot
@@ -560,6 +573,40 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
   }
 }
 
+// joint-space forces: damping, limits, motor (lanes = dofs; the motor of a dof comes from the schedule in LDS), and the
+// 1 / ca scaling of g and H (each lane scales its own column)
+template <class R>
+__device__ __forceinline__ void phase3_joint_space(const Ctx<R>& c, int lane, R sq, R sv, R h2) {
+  const int nr = c.nr;
+  const bool act = lane < nr;
+  if (act) {
+    const int j = lane;
+    const R* df = c.F + c.foff_dof + j * TSIM_DF_SIZE;
+    R gj = c.g[j], hjj = R(0);                       // hjj: joint-space part of H[j][j], added (scaled) at the end
+    gj += df[TSIM_DF_DAMPING] * c.qd[j]; hjj += df[TSIM_DF_DAMPING] * sv;
+    if (df[TSIM_DF_LIM_K] > R(0)) {
+      if (c.q[j] < df[TSIM_DF_LIM_LO]) { gj -= df[TSIM_DF_LIM_K] * (df[TSIM_DF_LIM_LO] - c.q[j]); hjj += df[TSIM_DF_LIM_K] * sq; }
+      else if (c.q[j] > df[TSIM_DF_LIM_HI]) { gj += df[TSIM_DF_LIM_K] * (c.q[j] - df[TSIM_DF_LIM_HI]); hjj += df[TSIM_DF_LIM_K] * sq; }
+    }
+    const int dm = ts_dof_motor(c)[j];
+    for (int m = (dm == -2 ? 0 : dm); m >= 0 && m < c.nu; ++m) {
+      const int* mi = ts_motor_rec(c, m);
+      if (mi[TSIM_MI_DOF] == j) {
+        const R* mf = c.F + c.foff_motor + m * TSIM_MF_SIZE;
+        if (mi[TSIM_MI_CTRL] == 0) {
+          R uc = fmin(fmax(c.u[m], R(-1)), R(1));
+          gj -= mf[TSIM_MF_LO] + (uc + R(1)) * (R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]));
+        } else {
+          gj -= mf[TSIM_MF_P] * (c.u[m] - c.q[j]) - mf[TSIM_MF_D] * c.qd[j];
+          hjj += mf[TSIM_MF_P] * sq + mf[TSIM_MF_D] * sv;
+        }
+      }
+      if (dm != -2) break;             // the usual case: exactly one motor on this dof
+    }
+    c.g[j] = gj * h2; c.H[j * nr + j] += hjj * h2;
+  }
+}
+
 // ================================================================================================ phase 3
 // lanes = directions.  Leaf -> root: tau_j = W_j . F_subtree(link(j)); fold each link's wrench into its
 // parent; then the joint-space forces.  Result: g (value, LDS) and H[j][k] = d g_j / d dir_k (lane k owns
@@ -616,36 +663,11 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   }
   TS_SYNC();
   TS_STAMP2(c);
-  // joint-space forces: damping, limits, motor (lanes = dofs; the motor of a dof comes from the schedule in LDS), and the
-  // 1 / ca scaling of g and H (each lane scales its own column)
-  if (act) {
-    const int j = lane;
-    const R* df = c.F + c.foff_dof + j * TSIM_DF_SIZE;
-    R gj = c.g[j], hjj = R(0);                       // hjj: joint-space part of H[j][j], added (scaled) at the end
-    gj += df[TSIM_DF_DAMPING] * c.qd[j]; hjj += df[TSIM_DF_DAMPING] * sv;
-    if (df[TSIM_DF_LIM_K] > R(0)) {
-      if (c.q[j] < df[TSIM_DF_LIM_LO]) { gj -= df[TSIM_DF_LIM_K] * (df[TSIM_DF_LIM_LO] - c.q[j]); hjj += df[TSIM_DF_LIM_K] * sq; }
-      else if (c.q[j] > df[TSIM_DF_LIM_HI]) { gj += df[TSIM_DF_LIM_K] * (c.q[j] - df[TSIM_DF_LIM_HI]); hjj += df[TSIM_DF_LIM_K] * sq; }
-    }
-    const int dm = ts_dof_motor(c)[j];
-    for (int m = (dm == -2 ? 0 : dm); m >= 0 && m < c.nu; ++m) {
-      const int* mi = ts_motor_rec(c, m);
-      if (mi[TSIM_MI_DOF] == j) {
-        const R* mf = c.F + c.foff_motor + m * TSIM_MF_SIZE;
-        if (mi[TSIM_MI_CTRL] == 0) {
-          R uc = fmin(fmax(c.u[m], R(-1)), R(1));
-          gj -= mf[TSIM_MF_LO] + (uc + R(1)) * (R(0.5) * (mf[TSIM_MF_HI] - mf[TSIM_MF_LO]));
-        } else {
-          gj -= mf[TSIM_MF_P] * (c.u[m] - c.q[j]) - mf[TSIM_MF_D] * c.qd[j];
-          hjj += mf[TSIM_MF_P] * sq + mf[TSIM_MF_D] * sv;
-        }
-      }
-      if (dm != -2) break;             // the usual case: exactly one motor on this dof
-    }
-    c.g[j] = gj * h2; c.H[j * nr + j] += hjj * h2;
-  }
+  phase3_joint_space<R>(c, lane, sq, sv, h2);
   TS_SYNC();
 }
+
+#include "tsim_static_eval.h"
 
 // full evaluation at the trial increment held in c.dl (with c.q0, c.qd0, c.u): fills c.q, c.qd, c.qa, link state, g, H.
 // The Newton unknown is the increment  dl = q1 - qp  over the force-free predictor qp (BDF1: q0 + h qd0; BDF2:
@@ -663,6 +685,13 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
   }
   TS_SYNC();
   TS_STAMP(c);
+#ifndef TS_STATIC_UNFUSED      // (A/B: the static link sweep followed by the generic phases 2 / 3)
+  if constexpr (!std::is_void<MS>::value && sizeof(R) == 4) {
+    evaluate_static_fused<R, NRM, LPE, MS, false>(c, lane, sq, sv, sa);      // a statically known model: one register-resident pass (tsim_static_eval.h)
+    TS_STAMP(c);
+    return;
+  }
+#endif
   if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
 #ifdef TS_STATIC_BRANCH_BLOCKS
   else phase1_static<R, MS, true, false>(c, lane, sq, sv, sa);       // A/B: the block-per-branch form

@@ -95,6 +95,9 @@ __global__ void __launch_bounds__(TS_WAVE) k_readout(ReadArgs<R> a) {
 }
 
 template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int fstride; const R* poseR; const double* poseD; int nspt; R* tac_out; int slice;
+  // blockIdx.x = frame * B + environment: the pose records are [frames][B][nspt] (one frame for tsim_readout; all frames of an episode
+  // launch whose read-out was deferred, launch_forward); frame f goes to slot tac_slot[f] of tac_out (null: slot f; < 0: not read out)
+  int B; const int* tac_slot;
   // model constants the host knows (header entries and the offset of the staging table): as kernel arguments they cost the prologue no
   // dependent global loads (header -> table offset -> table -> record was four L2 round trips per block, ~2 us of a 28 us kernel)
   int ntax, nsensor, foff_sensor, foff_pair, foff_taxel, tt_off; };
@@ -117,12 +120,63 @@ template <class R> __device__ __forceinline__ void ts_store3(R* o, R a, R b, R c
   __builtin_nontemporal_store(a, o); __builtin_nontemporal_store(b, o + 1); __builtin_nontemporal_store(c, o + 2);
 #endif
 }
+// One taxel against the staged tables of its environment (LDS): per sensor the end of its taxel range, its first (sensor, primitive)
+// record and their number, its penalty parameters; per record the primitive type, its shape, the pose record (R part, double part) and
+// the bounding sphere in the sensor-link frame.  The three outputs go out as ONE 12-byte (fp64: 24-byte) store per lane.
+template <class R>
+__device__ __forceinline__ void taxel_eval(int t, V3<R> xa, int nsensor, const int* sEnd, const int* sKb, const int* sNsp, const int* sPrim, const R* sSf,
+                                           const R* sShape, const R* sP, const double* sD, const R* sC, const R* tax, int ntax, R* out) {
+  int s = 0;                                                         // sensor of taxel t
+  while (s < nsensor - 1 && t >= sEnd[s]) ++s;
+  const int kb = sKb[s], nsp = sNsp[s];
+  const R* sf = sSf + s * TSIM_SF_SIZE;
+  const R* tp = tax + t;
+  V3<R> Fl = zero3<R>();                                             // force on the taxel, sensor-link frame
+  for (int j = 0; j < nsp; ++j) {
+    const R* Cc = sC + (kb + j) * 4;
+    const V3<R> dc = xa - ldv(Cc);
+    if (Cc[3] >= R(0) && dot3(dc, dc) > Cc[3]) continue;              // outside the primitive's bounding sphere (+ margin)
+    const int prim = sPrim[kb + j];
+    const R* shape = sShape + (kb + j) * 4;
+    const R* P = sP + (kb + j) * TP_R_SIZE;
+    const double* D = sD + (kb + j) * TP_D_SIZE;
+    const M3<R> RPA = ldm(P);
+    // fp32 kernels: the exact shape's distance from an fp32 position, before the double-precision one
+    if (sizeof(R) == 4 && !(prim_distance<R>(prim, shape, mulMv(RPA, xa) + ldv(P + 9)) < R(TS_FAR_MARGIN))) continue;
+    const V3<double> xPd = mulMv(ldm(D), cvt3<double>(xa)) + ldv(D + 9);
+    const V3<R> xP = cvt3<R>(xPd);
+    V3<R> Fc; M3<R> Jx, Jv;
+    if (contact_law<R, false>(prim, shape, sf, xP, ldv(P + 15) + cross3(ldv(P + 12), xP), Fc, Jx, Jv, xPd)) Fl = Fl + mulMtv(RPA, Fc);
+  }
+  R o0 = R(0), o1 = R(0), o2 = R(0);
+  if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {                // the nine axis constants only for taxels that carry a force
+    o0 = Fl.x * tp[3 * ntax] + Fl.y * tp[4 * ntax] + Fl.z * tp[5 * ntax];
+    o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
+    o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
+  }
+#ifdef TS_TAX_ZEROS        // A/B only: the store pattern alone (no taxel arithmetic) — the ceiling of this write stream
+  o0 = o1 = o2 = R(0);
+#endif
+  ts_store3(out + 3 * t, o0, o1, o2);
+}
+// bounding sphere of a (sensor, primitive) record in the sensor-link frame: centre c_A = -R_PA^T p_PA and (radius + margin)^2, < 0 for planes
+template <class R> __device__ __forceinline__ void taxel_bound(const R* P, int prim, const R* sh, R* C) {
+  const V3<R> cA = mulMtv(ldm(P), ldv(P + 9)) * R(-1);
+  R rb = R(-1);
+  if (prim == TSIM_P_SPHERE) rb = sh[0];
+  else if (prim == TSIM_P_CUBOID) rb = t_sqrt(sh[0] * sh[0] + sh[1] * sh[1] + sh[2] * sh[2]);
+  else if (prim == TSIM_P_CYLINDER) rb = t_sqrt(sh[0] * sh[0] + sh[1] * sh[1]);
+  C[0] = cA.x; C[1] = cA.y; C[2] = cA.z;
+  C[3] = rb < R(0) ? R(-1) : (rb + R(TS_FAR_MARGIN)) * (rb + R(TS_FAR_MARGIN));
+}
 #ifndef TS_TAX_UNROLL
 #define TS_TAX_UNROLL 2      // taxels per thread and loop iteration: their loads are in flight together (A/B: profiles/r03_readout_ab.md)
 #endif
 template <class R>
 __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
-  const int env = blockIdx.x;
+  const int rec_env = blockIdx.x, env = rec_env % a.B, frame = rec_env / a.B;
+  const int tslot = a.tac_slot ? a.tac_slot[frame] : frame;
+  if (tslot < 0) return;                                                // block-uniform
   const int* I = a.I;
   const R* F = a.Fenv ? a.Fenv + (size_t)env * a.fstride : a.F;        // this environment's float records (domain randomisation)
   const int ntax = a.ntax, nsensor = a.nsensor;
@@ -137,68 +191,24 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
     for (int i = threadIdx.x; i < a.nspt; i += 256) sPrim[i] = TT[3 * nsensor + 2 * i];
     for (int i = threadIdx.x; i < a.nspt * 4; i += 256) sShape[i] = F[foff_pair + TT[3 * nsensor + 2 * (i >> 2) + 1] * TSIM_PF_SIZE + TSIM_PF_SHAPE + (i & 3)];
     for (int i = threadIdx.x; i < nsensor * TSIM_SF_SIZE; i += 256) sSf[i] = F[foff_sensor + i];
-    for (int i = threadIdx.x; i < a.nspt * TP_R_SIZE; i += 256) sP[i] = a.poseR[(size_t)env * a.nspt * TP_R_SIZE + i];
-    for (int i = threadIdx.x; i < a.nspt * TP_D_SIZE; i += 256) sD[i] = a.poseD[(size_t)env * a.nspt * TP_D_SIZE + i];
+    for (int i = threadIdx.x; i < a.nspt * TP_R_SIZE; i += 256) sP[i] = a.poseR[(size_t)rec_env * a.nspt * TP_R_SIZE + i];
+    for (int i = threadIdx.x; i < a.nspt * TP_D_SIZE; i += 256) sD[i] = a.poseD[(size_t)rec_env * a.nspt * TP_D_SIZE + i];
     __syncthreads();
     // "Certainly outside" in 7 instructions: a taxel at x_A (sensor-link frame) cannot touch a primitive whose bounding sphere (centre
     // c_A = -R_PA^T p_PA, radius r_b) it is farther from than r_b + TS_FAR_MARGIN.  Most taxels of a large pad are nowhere near the
     // primitive, and for them this replaces the rotation into the primitive's frame (12 LDS reads, ~25 instructions); the margin is
     // far above the rounding of the test, so the set of taxels contact_law accepts is unchanged.  Planes have no bound (radius < 0).
-    for (int k = threadIdx.x; k < a.nspt; k += 256) {
-      const R* P = sP + k * TP_R_SIZE;
-      const V3<R> cA = mulMtv(ldm(P), ldv(P + 9)) * R(-1);
-      const R* sh = sShape + k * 4;
-      const int prim = sPrim[k];
-      R rb = R(-1);
-      if (prim == TSIM_P_SPHERE) rb = sh[0];
-      else if (prim == TSIM_P_CUBOID) rb = t_sqrt(sh[0] * sh[0] + sh[1] * sh[1] + sh[2] * sh[2]);
-      else if (prim == TSIM_P_CYLINDER) rb = t_sqrt(sh[0] * sh[0] + sh[1] * sh[1]);
-      sC[4 * k] = cA.x; sC[4 * k + 1] = cA.y; sC[4 * k + 2] = cA.z;
-      sC[4 * k + 3] = rb < R(0) ? R(-1) : (rb + R(TS_FAR_MARGIN)) * (rb + R(TS_FAR_MARGIN));
-    }
+    for (int k = threadIdx.x; k < a.nspt; k += 256) taxel_bound<R>(sP + k * TP_R_SIZE, sPrim[k], sShape + k * 4, sC + 4 * k);
     __syncthreads();
   }
   const R* tax = a.F + a.foff_taxel;                          // SoA planes: position (3), axis0, axis1, normal (9); shared
-  R* out = a.tac_out + (size_t)env * 3 * ntax;
+  R* out = a.tac_out + ((size_t)tslot * a.B + env) * 3 * ntax;
   const int te = min(ntax, ((int)blockIdx.y + 1) * a.slice);
   // One taxel: its three outputs go out as ONE 12-byte (fp64: 24-byte) store per lane — consecutive lanes, consecutive addresses: a
   // wavefront's store instruction covers 768 contiguous bytes (global_store_dwordx3 in the ISA).  Routing them through LDS for 16-byte
   // vectors instead was measured twice and is slower both ways (block-wide with barriers: round 2; wave-private without: round 3,
   // 2.45 -> 2.12 TB/s on the bench leg, profiles/r03_readout_ab.md).
-  auto taxel = [&](int t, V3<R> xa) {
-    int s = 0;                                                         // sensor of taxel t
-    while (s < nsensor - 1 && t >= sEnd[s]) ++s;
-    const int kb = sKb[s], nsp = sNsp[s];
-    const R* sf = sSf + s * TSIM_SF_SIZE;
-    const R* tp = tax + t;
-    V3<R> Fl = zero3<R>();                                             // force on the taxel, sensor-link frame
-    for (int j = 0; j < nsp; ++j) {
-      const R* Cc = sC + (kb + j) * 4;
-      const V3<R> dc = xa - ldv(Cc);
-      if (Cc[3] >= R(0) && dot3(dc, dc) > Cc[3]) continue;              // outside the primitive's bounding sphere (+ margin)
-      const int prim = sPrim[kb + j];
-      const R* shape = sShape + (kb + j) * 4;
-      const R* P = sP + (kb + j) * TP_R_SIZE;
-      const double* D = sD + (kb + j) * TP_D_SIZE;
-      const M3<R> RPA = ldm(P);
-      // fp32 kernels: the exact shape's distance from an fp32 position, before the double-precision one
-      if (sizeof(R) == 4 && !(prim_distance<R>(prim, shape, mulMv(RPA, xa) + ldv(P + 9)) < R(TS_FAR_MARGIN))) continue;
-      const V3<double> xPd = mulMv(ldm(D), cvt3<double>(xa)) + ldv(D + 9);
-      const V3<R> xP = cvt3<R>(xPd);
-      V3<R> Fc; M3<R> Jx, Jv;
-      if (contact_law<R, false>(prim, shape, sf, xP, ldv(P + 15) + cross3(ldv(P + 12), xP), Fc, Jx, Jv, xPd)) Fl = Fl + mulMtv(RPA, Fc);
-    }
-    R o0 = R(0), o1 = R(0), o2 = R(0);
-    if (Fl.x != R(0) || Fl.y != R(0) || Fl.z != R(0)) {                // the nine axis constants only for taxels that carry a force
-      o0 = Fl.x * tp[3 * ntax] + Fl.y * tp[4 * ntax] + Fl.z * tp[5 * ntax];
-      o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
-      o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
-    }
-#ifdef TS_TAX_ZEROS        // A/B only: the store pattern alone (no taxel arithmetic) — the ceiling of this write stream
-    o0 = o1 = o2 = R(0);
-#endif
-    ts_store3(out + 3 * t, o0, o1, o2);
-  };
+  auto taxel = [&](int t, V3<R> xa) { taxel_eval<R>(t, xa, nsensor, sEnd, sKb, sNsp, sPrim, sSf, sShape, sP, sD, sC, tax, ntax, out); };
   if (nsensor == 1 && a.nspt == 1 && sC[3] >= R(0)) {
     // One sensor against one bounded primitive (RollingBall's pad and ball, TactilePush's pad and box), in two passes per 1024 taxels:
     //   pass 1  lanes = taxels: 3 loads, the bounding-sphere test against centre / radius^2 held in registers (7 instructions), zeros
@@ -258,6 +268,51 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
 #pragma unroll
     for (int r = 0; r < TS_TAX_UNROLL; ++r)
       if (t + 256 * r < te) taxel(t + 256 * r, xa[r]);
+  }
+}
+
+// Small pads, many records (the frames of an episode launch: 81 920 records of 130 taxels on BASELINE's headline batch): one block per
+// record is all prologue (k_taxels above: ~3 us of dependent loads and two barriers for 130 taxels).  Here a block stages TXS_RPB records
+// at once — one cooperative copy, one barrier — and its threads then run over (record, taxel) items; consecutive items are consecutive
+// taxels of one record, so loads and the 12-byte stores stay contiguous.  Same taxel_eval, same tables: the same bits as k_taxels.
+enum { TXS_RPB = 16, TXS_MAXK = 8, TXS_MAXS = 4, TXS_MAX_TAXELS = 1024 };
+template <class R>
+__global__ void __launch_bounds__(256) k_taxels_small(TaxArgs<R> a, int nrec) {
+  const int rec0 = blockIdx.x * TXS_RPB, nr_ = min((int)TXS_RPB, nrec - rec0);
+  const int ntax = a.ntax, nsensor = a.nsensor, nspt = a.nspt;
+  __shared__ int sEnd[TXS_MAXS], sKb[TXS_MAXS], sNsp[TXS_MAXS], sPrim[TXS_MAXK], sPair[TXS_MAXK], sSlot[TXS_RPB];
+  __shared__ R sSf[TXS_RPB][TXS_MAXS * TSIM_SF_SIZE], sShape[TXS_RPB][TXS_MAXK * 4], sP[TXS_RPB][TXS_MAXK * TP_R_SIZE];
+  __shared__ double sD[TXS_RPB][TXS_MAXK * TP_D_SIZE];
+  __shared__ __attribute__((aligned(16))) R sC[TXS_RPB][TXS_MAXK * 4];
+  __shared__ R sX[3 * TXS_MAX_TAXELS];                                  // the taxels' positions (shared by all records): no global load left in the item loop
+  const R* tax = a.F + a.foff_taxel;
+  for (int i = threadIdx.x; i < 3 * ntax; i += 256) sX[i] = tax[i];
+  const int* TT = a.I + a.tt_off;
+  for (int i = threadIdx.x; i < nsensor; i += 256) { sEnd[i] = TT[3 * i]; sKb[i] = TT[3 * i + 1]; sNsp[i] = TT[3 * i + 2]; }
+  for (int i = threadIdx.x; i < nspt; i += 256) { sPrim[i] = TT[3 * nsensor + 2 * i]; sPair[i] = TT[3 * nsensor + 2 * i + 1]; }
+  for (int i = threadIdx.x; i < nr_; i += 256) { const int fr = (rec0 + i) / a.B; sSlot[i] = a.tac_slot ? a.tac_slot[fr] : fr; }
+  for (int i = threadIdx.x; i < nr_ * nspt * TP_R_SIZE; i += 256) { const int r = i / (nspt * TP_R_SIZE), e = i % (nspt * TP_R_SIZE); sP[r][e] = a.poseR[(size_t)(rec0 + r) * nspt * TP_R_SIZE + e]; }
+  for (int i = threadIdx.x; i < nr_ * nspt * TP_D_SIZE; i += 256) { const int r = i / (nspt * TP_D_SIZE), e = i % (nspt * TP_D_SIZE); sD[r][e] = a.poseD[(size_t)(rec0 + r) * nspt * TP_D_SIZE + e]; }
+  for (int i = threadIdx.x; i < nr_ * nsensor * TSIM_SF_SIZE; i += 256) {
+    const int r = i / (nsensor * TSIM_SF_SIZE), e = i % (nsensor * TSIM_SF_SIZE);
+    const R* F = a.Fenv ? a.Fenv + (size_t)((rec0 + r) % a.B) * a.fstride : a.F;
+    sSf[r][e] = F[a.foff_sensor + e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr_ * nspt * 4; i += 256) {
+    const int r = i / (nspt * 4), e = i % (nspt * 4);
+    const R* F = a.Fenv ? a.Fenv + (size_t)((rec0 + r) % a.B) * a.fstride : a.F;
+    sShape[r][e] = F[a.foff_pair + sPair[e >> 2] * TSIM_PF_SIZE + TSIM_PF_SHAPE + (e & 3)];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr_ * nspt; i += 256) { const int r = i / nspt, k = i % nspt; taxel_bound<R>(sP[r] + k * TP_R_SIZE, sPrim[k], sShape[r] + k * 4, sC[r] + 4 * k); }
+  __syncthreads();
+  for (int item = threadIdx.x; item < nr_ * ntax; item += 256) {
+    const int r = item / ntax, t = item - r * ntax;
+    const int tslot = sSlot[r];
+    if (tslot < 0) continue;
+    R* out = a.tac_out + ((size_t)tslot * a.B + (rec0 + r) % a.B) * 3 * ntax;
+    taxel_eval<R>(t, mk3<R>(sX[t], sX[t + ntax], sX[t + 2 * ntax]), nsensor, sEnd, sKb, sNsp, sPrim, sSf[r], sShape[r], sP[r], sD[r], sC[r], tax, ntax, out);
   }
 }
 
@@ -378,6 +433,7 @@ struct tsim_batch {
   int stage_cpt;                 // the contact-point arrays are staged in LDS with the shared tables
   int n_simd;                    // SIMDs of the device (CUs x 4)
   int static_id = 0, no_static = 0;   // the blob equals a compiled-in static model bit for bit (1: TsStaticPusher); TSIM_NO_STATIC=1 / tsim_set_static(0) keeps the generic kernels
+  void* fposeR = nullptr; double* fposeD = nullptr; int fpose_frames = 0;   // pose records per frame [fpose_frames][B][nspt] of episode launches with a deferred read-out
   int pose_valid = 0;            // the pose records are those of the current state (left by the last forward launch)
   int pose_off = 0;              // a launch of this batch was captured in a HIP graph: replays change the state behind the host's back, no reuse
   int tt_off = 0;                // offset of the taxel staging table in the device int blob (I[NI] + S[TS_SCHED_TAXTAB])
@@ -619,6 +675,38 @@ static bool pose_emit(tsim_batch* b, hipStream_t st) {
   return !b->pose_off && b->nspt > 0 && b->poseR && b->ntax >= TS_POSE_EMIT_MIN_TAXELS;
 }
 
+// k_taxels over the pose records [frames][B][nspt]: frame f -> slot tac_slot[f] (device array; null: slot f) of tac_out.
+// Taxels per block.  A block's prologue (staging the pose records and the model tables of its environment, two barriers)
+// is a chain of dependent global loads, ~3 us whatever the slice; with many short blocks per SIMD slot the kernel WAS that prologue
+// (8192 blocks of 5 taxels per thread: 4.6 rounds of ~7 us for 256 x 40 000 taxels).  So: ONE round — as many blocks as the device
+// holds at once (occupancy x CUs), each with a slice long enough to cover the batch; never less than 256 taxels per block, so the
+// single environment of test_sim_speed.py still spreads its 40 000 taxels over 157 blocks.
+static bool taxels_supported(const tsim_batch* b) { return b->ntax > 0 && b->nspt > 0 && b->nspt <= TX_MAXK && b->I[TSIM_IH_NSENSOR] <= TX_MAXS; }
+template <class R>
+static int launch_taxels(tsim_batch* b, const void* poseR, const double* poseD, int frames, const int32_t* tac_slot, void* tac_out, hipStream_t st) {
+  if (b->tax_slots == 0) {
+    int per_cu = 0;
+    const hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_taxels<R>, 256, 0);
+    b->tax_slots = (e_ == hipSuccess && per_cu > 0 ? per_cu : 4) * (b->n_simd / 4);
+  }
+  const long long nrec = (long long)frames * b->B;
+  if (nrec >= 4 * TXS_RPB && b->ntax <= TXS_MAX_TAXELS && b->nspt <= TXS_MAXK && b->I[TSIM_IH_NSENSOR] <= TXS_MAXS && !getenv("TSIM_TAXELS_PER_RECORD")) {
+    TaxArgs<R> t{b->dI, (const R*)b->dF, (const R*)b->dFenv, b->nfrec, (const R*)poseR, poseD, b->nspt, (R*)tac_out, 0, b->B, tac_slot,
+                 b->ntax, b->I[TSIM_IH_NSENSOR], b->I[TSIM_IH_FOFF_SENSOR], b->I[TSIM_IH_FOFF_PAIR], b->I[TSIM_IH_FOFF_TAXEL], b->tt_off};
+    hipLaunchKernelGGL(k_taxels_small<R>, dim3((unsigned)((nrec + TXS_RPB - 1) / TXS_RPB)), dim3(256), 0, st, t, (int)nrec);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  const int per_env = (int)std::max<long long>(1, std::min<long long>(b->tax_slots / nrec, (b->ntax + 255) / 256));
+  const int slice = ((b->ntax + per_env - 1) / per_env + 255) / 256 * 256;
+  const dim3 tgrid((unsigned)nrec, (b->ntax + slice - 1) / slice);
+  TaxArgs<R> t{b->dI, (const R*)b->dF, (const R*)b->dFenv, b->nfrec, (const R*)poseR, poseD, b->nspt, (R*)tac_out, slice, b->B, tac_slot,
+               b->ntax, b->I[TSIM_IH_NSENSOR], b->I[TSIM_IH_FOFF_SENSOR], b->I[TSIM_IH_FOFF_PAIR], b->I[TSIM_IH_FOFF_TAXEL], b->tt_off};
+  hipLaunchKernelGGL(k_taxels<R>, tgrid, dim3(256), 0, st, t);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <class R>
 static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32_t* tac_slot, int nsub, void* q_out, void* qd_out, void* var_out, void* tac_out, int32_t* status, hipStream_t st) {
   FwdArgs<R> a;
@@ -628,9 +716,28 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
   a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm;
   const bool emit = pose_emit(b, st);
-  if (emit) { a.poseR = (R*)b->poseR; a.poseD = b->poseD; a.nspt = b->nspt; }
+  a.nspt = b->nspt;
+  if (emit) { a.poseR = (R*)b->poseR; a.poseD = b->poseD; }
+  // The tactile frames of the launch: by k_taxels afterwards, from the pose records the launch leaves per frame — which is what lets the
+  // slots of a wavefront run their frames independently (k_forward, main loop).  TSIM_INKERNEL_READOUT=1 / TSIM_NO_FREE_RUN=1: A/B.
+  bool defer = tac_out && taxels_supported(b) && !getenv("TSIM_INKERNEL_READOUT");
+  if (defer && b->fpose_frames < nframes) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) defer = false;      // no allocation inside a capture: the in-kernel read-out
+    else {
+      HIPCHK(hipStreamSynchronize(st));          // an earlier launch may still be writing the old records
+      (void)hipFree(b->fposeR); (void)hipFree(b->fposeD); b->fposeR = nullptr; b->fposeD = nullptr; b->fpose_frames = 0;
+      if (hipMalloc(&b->fposeR, (size_t)nframes * b->B * b->nspt * TP_R_SIZE * b->esz) != hipSuccess ||
+          hipMalloc((void**)&b->fposeD, (size_t)nframes * b->B * b->nspt * TP_D_SIZE * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(b->fposeR); b->fposeR = nullptr; b->fposeD = nullptr; defer = false;
+      } else b->fpose_frames = nframes;
+    }
+  }
+  if (defer) { a.fposeR = (R*)b->fposeR; a.fposeD = b->fposeD; }
+  a.free_run = (defer || !tac_out || b->ntax == 0) && !getenv("TSIM_NO_FREE_RUN");
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
+  if (defer && launch_taxels<R>(b, b->fposeR, b->fposeD, nframes, tac_slot, tac_out, st)) return 1;
   b->pose_valid = emit ? 1 : 0;
   if (b->B >= 256) {
     const int ns = TS_WAVE / launch_shape(b).lpe, nsv = (b->B % ns == 0) ? ns : 1;
@@ -722,7 +829,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   DeviceGuard guard_(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
   for (void* p : b->pool) (void)hipFree(p);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD); (void)hipFree(b->fposeR); (void)hipFree(b->fposeD);
   delete b;
 }
 
@@ -848,23 +955,6 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   // taxels that are paired with no primitive (a sensor body without a general_primitive_contact) read zero, as in k_forward's read-out
   if (tac_out && b->ntax > 0 && b->nspt == 0 && zero_async(tac_out, (size_t)b->B * 3 * b->ntax * b->esz, st)) return 1;
   if (tac && (b->nspt > TX_MAXK || b->I[TSIM_IH_NSENSOR] > TX_MAXS)) return fail("readout: more than " + std::to_string((int)TX_MAXK) + " (sensor, primitive) combinations or " + std::to_string((int)TX_MAXS) + " sensors (k_taxels staging)");
-  // Taxels per block of k_taxels.  A block's prologue (staging the pose records and the model tables of its environment, two barriers)
-  // is a chain of dependent global loads, ~3 us whatever the slice; with many short blocks per SIMD slot the kernel WAS that prologue
-  // (8192 blocks of 5 taxels per thread: 4.6 rounds of ~7 us for 256 x 40 000 taxels).  So: ONE round — as many blocks as the device
-  // holds at once (occupancy x CUs), each with a slice long enough to cover the batch; never less than 256 taxels per block, so the
-  // single environment of test_sim_speed.py still spreads its 40 000 taxels over 157 blocks.
-  int slice;
-  {
-    if (b->tax_slots == 0) {
-      int per_cu = 0;
-      const hipError_t e_ = b->dtype == TSIM_F32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_taxels<float>, 256, 0)
-                                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_taxels<double>, 256, 0);
-      b->tax_slots = (e_ == hipSuccess && per_cu > 0 ? per_cu : 4) * (b->n_simd / 4);
-    }
-    const int per_env = std::max(1, std::min(b->tax_slots / b->B, (b->ntax + 255) / 256));
-    slice = ((b->ntax + per_env - 1) / per_env + 255) / 256 * 256;
-  }
-  const dim3 tgrid(b->B, tac ? (b->ntax + slice - 1) / slice : 1);
   {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { b->pose_off = 1; b->pose_valid = 0; }
@@ -873,19 +963,11 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   if (b->dtype == TSIM_F32) {
     ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, tac ? (float*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
     if (fk) hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
-    if (tac) {
-      TaxArgs<float> t{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, (const float*)b->poseR, b->poseD, b->nspt, (float*)tac_out, slice,
-                       b->ntax, b->I[TSIM_IH_NSENSOR], b->I[TSIM_IH_FOFF_SENSOR], b->I[TSIM_IH_FOFF_PAIR], b->I[TSIM_IH_FOFF_TAXEL], b->tt_off};
-      hipLaunchKernelGGL(k_taxels<float>, tgrid, dim3(256), 0, st, t);
-    }
+    if (tac && launch_taxels<float>(b, b->poseR, b->poseD, 1, nullptr, tac_out, st)) return 1;
   } else {
     ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, tac ? (double*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
     if (fk) hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
-    if (tac) {
-      TaxArgs<double> t{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, (const double*)b->poseR, b->poseD, b->nspt, (double*)tac_out, slice,
-                        b->ntax, b->I[TSIM_IH_NSENSOR], b->I[TSIM_IH_FOFF_SENSOR], b->I[TSIM_IH_FOFF_PAIR], b->I[TSIM_IH_FOFF_TAXEL], b->tt_off};
-      hipLaunchKernelGGL(k_taxels<double>, tgrid, dim3(256), 0, st, t);
-    }
+    if (tac && launch_taxels<double>(b, b->poseR, b->poseD, 1, nullptr, tac_out, st)) return 1;
   }
   HIPCHK(hipGetLastError());
   return 0;

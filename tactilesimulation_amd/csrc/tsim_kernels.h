@@ -94,6 +94,8 @@ template <class R> struct FwdArgs {
   float* gnorm;                // [B] largest ||g|| a sub-step of this launch ended with (diagnostics, tsim_last_gnorm)
   PushPolicy<R> pol;           // POLICY instantiations only (tsim_push_closed_rollout): the TactilePush policy between the frames
   R* poseR = nullptr; double* poseD = nullptr; int nspt = 0;   // large pads: pose records of the final state for tsim_readout's k_taxels (see k_readout)
+  int free_run = 0;            // the slots of a wavefront run their frames / sub-steps independently (k_forward, main loop)
+  R* fposeR = nullptr; double* fposeD = nullptr;               // [nframes][B][nspt] pose records per frame: the tactile frames are evaluated by k_taxels after the launch
 };
 
 // -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
@@ -141,50 +143,88 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     }
   }
   TS_SYNC();
-  // A launch covers nframes env-steps (1 for tsim_step).  With nframes > 1 an environment never waits for the slowest
-  // environment of the batch between env-steps: Newton stragglers average out over the episode.
+  // A launch covers nframes env-steps (1 for tsim_step) of nsub sub-steps each, and every sub-step is a Newton iteration of a few
+  // residual evaluations.  The evaluation is the one expensive thing here and it has ONE call site, in ONE loop; everything else is a
+  // state machine PER SLOT around it (the state is identical in all lanes of a slot): each of the wavefront's environments is in its own
+  // frame, its own sub-step and its own Newton iteration.  Nothing couples the environments of a batch inside a launch, so a slot whose
+  // sub-step has converged starts its next one in the very next round instead of re-evaluating its final iterate until the slowest slot of
+  // the wavefront has converged too: the wavefront lasts  max over its slots of (sum of the slot's evaluations)  instead of
+  // sum over the sub-steps of (max over its slots)  — on BASELINE's headline batch 349 instead of 403 rounds for the slowest wavefront,
+  // which is what a launch lasts (profiles/r04_free_running_slots.md).  The price: the code between two evaluations that is not
+  // evaluation (commit of a sub-step: tape record, state shift, predictor; end of a frame: outputs) now runs once per slot that needs it
+  // instead of once per wavefront.  That is why the tactile read-out is no longer part of a free-running launch: a.free_run launches leave,
+  // per frame, the pose records of the (sensor, primitive) combinations (a.fposeR / a.fposeD), and the taxels of all frames are evaluated
+  // by k_taxels afterwards, lanes = taxels, at full occupancy.
+  // Launches that need the frames' outputs INSIDE the launch (POLICY: the next action is computed from this frame's tactile image) or
+  // whose read-out cannot be deferred (a.free_run == 0) keep their slots together at the frame ends only: a slot that has finished the
+  // last sub-step of its frame re-evaluates its final iterate until the others have.
 #ifdef TS_PP_TIME      // A/B builds only: share of the launch spent in the policy call, left in gnorm (tools/closed_loop_breakdown.py)
   long long pp_cycles_ = 0; const long long pp_t0_ = clock64();
 #endif
-  for (int f = 0; f < a.nframes; ++f) {
-  {
-    R uv = R(0);
-    if (POLICY) {
-      // closed loop: the action comes from the policy, evaluated by this slot on the observation the previous frame left
-      // (tsim_policy_push.h).  The tactile frame was written by this slot: make the stores visible to its own loads first.
-      ts_own_stores_visible();
-      const R* tprev = a.pol.mode != TSIM_PUSH_OBS_TACTILE ? nullptr : (f == 0 ? a.pol.tac0 + (size_t)env * PP_NTAC : a.tac_out + ((size_t)(f - 1) * a.B + env) * PP_NTAC);
-#ifdef TS_PP_TIME
-      const long long tp0_ = clock64();
+  const bool free_run = !POLICY && a.free_run != 0 && (a.tac_out == nullptr || a.fposeR != nullptr);
+  int f = 0, s = 0, tslot = 0;
+  bool done = a.nframes <= 0;
+  bool fs = !done, ss = !done;               // this slot is at the start of a frame (fetch the action) / of a sub-step (predictor)
+  bool held = false;                         // !free_run: the last sub-step of the frame is finished, waiting for the other slots
+  R unext = R(0);                            // the next frame's action, fetched one frame ahead (a lone wavefront cannot hide the load)
+  if (!POLICY && !done && lane < nu) unext = a.u[(size_t)env * nu + lane];
+  R gn = R(0), alpha = R(1), sv = R(0), sa = R(0);
+  int iter = 0, ls = -1, sub_evals = 0, crossings = 0;       // ls < 0: the evaluation just done is not a line-search trial
+  bool conv = false, fin = false, forced = false;
+#ifdef TS_ROUND_STATS   // A/B builds only (tools/round_stats.py): rounds of this wavefront and its shader clocks, left in status / gnorm
+  int rounds_ = 0; const long long rs_t0_ = clock64();
 #endif
-      push_policy_forward<LPE>(c, lane, valid, a.pol, (size_t)f * a.B + env, env, tprev);
-      TS_SYNC();
-#ifdef TS_PP_TIME
-      pp_cycles_ += clock64() - tp0_;
+  while (!__all(done)) {
+#ifdef TS_ROUND_STATS
+    ++rounds_;
 #endif
-      if (lane < nu) uv = c.u[lane];
-    } else
-    if (lane < nu) { uv = a.u[((size_t)f * a.B + env) * nu + lane]; c.u[lane] = uv; }
-    // a NaN / inf control would be clamped away silently by the motor law's fmin / fmax: flag it (status bit 30) instead
-    if (seg_sum<LPE>(ts_finite(uv) ? R(0) : R(1)) > R(0)) nonfinite = true;
-  }
-  TS_SYNC();
-  for (int s = 0; s < a.nsub; ++s) {
-    // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment
-    if (bdf2_model && has_prev) {
-      c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h);
-      if (lane < nr) {
-        const double hD = (double)c.h;
-        const double qp = 4.0 / 3 * c.q0D[lane] - 1.0 / 3 * c.qm1D[lane] + hD * (8.0 / 9 * (double)c.qd0[lane] - 2.0 / 9 * (double)c.qdm1[lane]);
-        c.qpD[lane] = qp; c.qp[lane] = (R)qp;
-        c.qdp[lane] = (R)((3.0 * qp - 4.0 * c.q0D[lane] + c.qm1D[lane]) / (2.0 * hD));
+    if (POLICY ? __any(fs) : fs) {
+      R uv = R(0);
+      if (POLICY) {
+        // closed loop: the action comes from the policy, evaluated by this slot on the observation the previous frame left
+        // (tsim_policy_push.h).  The tactile frame was written by this slot: make the stores visible to its own loads first.
+        ts_own_stores_visible();
+        const R* tprev = a.pol.mode != TSIM_PUSH_OBS_TACTILE ? nullptr : (f == 0 ? a.pol.tac0 + (size_t)env * PP_NTAC : a.tac_out + ((size_t)(f - 1) * a.B + env) * PP_NTAC);
+#ifdef TS_PP_TIME
+        const long long tp0_ = clock64();
+#endif
+        push_policy_forward<LPE>(c, lane, valid, a.pol, (size_t)f * a.B + env, env, tprev);
+        TS_SYNC();
+#ifdef TS_PP_TIME
+        pp_cycles_ += clock64() - tp0_;
+#endif
+        if (lane < nu) uv = c.u[lane];
+      } else {
+        uv = unext;
+        if (lane < nu) {
+          c.u[lane] = uv;
+          if (f + 1 < a.nframes) unext = a.u[((size_t)(f + 1) * a.B + env) * nu + lane];
+        }
       }
-    } else {
-      c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
-      if (lane < nr) { c.qpD[lane] = c.q0D[lane] + (double)c.h * (double)c.qd0[lane]; c.qp[lane] = (R)c.qpD[lane]; c.qdp[lane] = c.qd0[lane]; }
+      // a NaN / inf control would be clamped away silently by the motor law's fmin / fmax: flag it (status bit 30) instead
+      if (seg_sum<LPE>(ts_finite(uv) ? R(0) : R(1)) > R(0)) nonfinite = true;
+      tslot = a.tac_slot ? a.tac_slot[f] : f;      // used at the end of the frame: fetched here, the load is long done by then
+      fs = false;
     }
-    const R sq = R(1), sv = c.cv, sa = c.ca;
-    if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
+    if (ss) {
+      // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment
+      if (bdf2_model && has_prev) {
+        c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h);
+        if (lane < nr) {
+          const double hD = (double)c.h;
+          const double qp = 4.0 / 3 * c.q0D[lane] - 1.0 / 3 * c.qm1D[lane] + hD * (8.0 / 9 * (double)c.qd0[lane] - 2.0 / 9 * (double)c.qdm1[lane]);
+          c.qpD[lane] = qp; c.qp[lane] = (R)qp;
+          c.qdp[lane] = (R)((3.0 * qp - 4.0 * c.q0D[lane] + c.qm1D[lane]) / (2.0 * hD));
+        }
+      } else {
+        c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
+        if (lane < nr) { c.qpD[lane] = c.q0D[lane] + (double)c.h * (double)c.qd0[lane]; c.qp[lane] = (R)c.qpD[lane]; c.qdp[lane] = c.qd0[lane]; }
+      }
+      sv = c.cv; sa = c.ca;
+      if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
+      gn = R(0); alpha = R(1); iter = 0; ls = -1; sub_evals = 0; crossings = 0; conv = false; fin = false; forced = false;
+      ss = false;
+    }
     TS_SYNC();
     // Newton with backtracking EXACTLY as the model file states it (<solver_option tol max_iter max_ls>, pusher.xml:4): up to max_iter
     // iterations; each halves the step until ||g|| decreases, at most max_ls times, and takes the last trial if none did; converged when
@@ -192,10 +232,8 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     // wavefront; on the stiff TactileInsertion grasp their full Newton step across a kink "converged" to a root 0.15 rad away from the one
     // plain backtracking reaches — found by the oracle's literal solver in round 3).  The oracle (oracle/tsim_oracle.cpp
     // substep_literal) is the same loop in fp64; the fp64 kernels take its iterates.
-    // Written as a state machine around ONE evaluate call site (code size matters: the evaluation is ~6k instructions and two inlined
-    // copies overflow the instruction cache): an accepted trial's evaluation is the next iteration's Jacobian evaluation.  The state
-    // is per slot (identical in all lanes of a slot); a slot that has finished its sub-step keeps evaluating at its final iterate
-    // (same numbers again) until every slot of the wavefront has finished.
+    // An accepted trial's evaluation is the next iteration's Jacobian evaluation.  A slot that has nothing left to do (done, or held at
+    // the end of a frame) keeps evaluating at its final iterate: the same numbers again.
     // Around that loop, two options (tsim_set_solver_options), both visible to the caller and both OFF for fp64 batches by default —
     // the fp64 kernels ARE the loop:
     //  * cross_kinks (fp32 default: on).  ||g|| has non-smooth local minima at contact / friction kinks: the iterate sits on the kink,
@@ -211,77 +249,101 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     //    TactileInsertion grasp (||g|| ~ 1e-3, steps of 0.02 - 0.5) that reached roots 0.15 rad away from the literal one.
     //  * eval_budget (default 0 = none): an upper bound on the evaluations of one sub-step for throughput-minded roll-out collection;
     //    a sub-step cut short is flagged non-converged in status.
-    R gn = R(0), alpha = R(1);
-    int iter = 0, ls = -1, sub_evals = 0, crossings = 0;       // ls < 0: the evaluation just done is not a line-search trial
-    bool conv = false, fin = false, forced = false;
-    while (true) {
-      evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, sq, sv, sa);
-      const R gnew = block_norm2<LPE>(c.g, nr, lane);
-      bool solve = false;
-      if (!fin) {
-        ++evals; ++sub_evals;
-        bool take = false;                     // the point just evaluated becomes the iterate
-        if (ls >= 0 && !forced && (!ts_finite(gnew) || gnew >= gn)) {              // a rejected trial (a non-finite one is rejected too)
-          if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) {
-            ++crossings; forced = true;        // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
-            if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-          } else if (ls < c.max_ls) {          // halve the step
-            alpha *= R(0.5); ++ls;
-            if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
-          } else take = true;                  // the literal loop: the last trial is taken anyway
-        } else take = true;                    // the first evaluation of the sub-step, an accepted trial, or the step across a kink
-        if (take) {
-          forced = false;
-          if (ls >= 0) ++iter;
-          gn = gnew;
-          if (!ts_finite(gn)) { nonfinite = true; fin = true; }
-          else if (gn < c.tol) { conv = true; fin = true; }
-          else if (iter >= c.max_iter || (a.eval_budget > 0 && sub_evals >= a.eval_budget)) fin = true;
-          else {
-            solve = true;
-            if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
+    evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, R(1), sv, sa);
+    const R gnew = block_norm2<LPE>(c.g, nr, lane);
+    bool solve = false;
+    if (!fin && !done) {
+      ++evals; ++sub_evals;
+      bool take = false;                     // the point just evaluated becomes the iterate
+      if (ls >= 0 && !forced && (!ts_finite(gnew) || gnew >= gn)) {              // a rejected trial (a non-finite one is rejected too)
+        if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) {
+          ++crossings; forced = true;        // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
+          if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+        } else if (ls < c.max_ls) {          // halve the step
+          alpha *= R(0.5); ++ls;
+          if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
+        } else take = true;                  // the literal loop: the last trial is taken anyway
+      } else take = true;                    // the first evaluation of the sub-step, an accepted trial, or the step across a kink
+      if (take) {
+        forced = false;
+        if (ls >= 0) ++iter;
+        gn = gnew;
+        if (!ts_finite(gn)) { nonfinite = true; fin = true; }
+        else if (gn < c.tol) { conv = true; fin = true; }
+        else if (iter >= c.max_iter || (a.eval_budget > 0 && sub_evals >= a.eval_budget)) fin = true;
+        else {
+          solve = true;
+          if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
+        }
+      }
+    }
+    TS_SYNC();
+    if (__any(solve)) {
+      solve_newton<R, NRM, LPE>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+      if (solve) {
+        alpha = R(1); ls = 0;
+        if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+      }
+      TS_SYNC();
+    }
+    // ---- commit the sub-steps that ended with this evaluation: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
+    bool commit = fin && !done && !held;
+    if (!free_run) {                           // the last sub-step of a frame is committed by all slots together
+      if (commit && s == a.nsub - 1) { held = true; commit = false; }
+      if (__all(held || done)) { commit = held; held = false; }
+    }
+    bool frame_end = false;
+    if (commit) {
+      if (!conv) ++bad;
+      gmax = t_max(gmax, gn);
+      if (a.record && valid) {
+        R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
+        if (lane < nr) { rec_q(rec)[lane] = c.qD[lane]; rec[rec_qd<R>(nr) + lane] = c.qd[lane]; }
+        for (int e = lane; e < nr * nr; e += LPE) rec[rec_H<R>(nr) + e] = c.H[e];
+        if (lane < nu) rec[rec_u<R>(nr) + lane] = c.u[lane];
+      }
+      TS_SYNC();
+      if (lane < nr) {
+        c.qm1[lane] = c.q0[lane]; c.qm1D[lane] = c.q0D[lane]; c.qdm1[lane] = c.qd0[lane];
+        c.q0[lane] = c.q[lane]; c.q0D[lane] = c.qD[lane]; c.qd0[lane] = c.qd[lane];
+      }
+      has_prev = true;
+      fin = false; ss = true;
+      if (++s == a.nsub) { s = 0; frame_end = true; }
+    }
+    TS_SYNC();
+    // ---- end of a frame (per slot in a free-running launch, all slots together otherwise): the link poses / velocities in LDS are
+    //      those of the accepted state (last evaluation)
+    if (__any(frame_end)) {
+      if (frame_end && lane < nr && valid) {
+        const size_t o = ((size_t)f * a.B + env) * nr + lane;
+        if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
+        if (a.qd_out) a.qd_out[o] = c.qd0[lane];
+      }
+      const bool tac_here = a.tac_out != nullptr && !a.fposeR;       // in-kernel read-out: wave-uniform, and so are f and tslot then (!free_run)
+      readout<LPE>(c, lane, env, frame_end && valid, frame_end && valid && tslot >= 0, a.var_out != nullptr, tac_here && tslot >= 0,
+                   a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
+                   (tac_here && tslot >= 0) ? a.tac_out + (size_t)tslot * a.B * 3 * c.ntax : nullptr);
+      if (a.fposeR && frame_end && tslot >= 0) {                     // deferred read-out: this frame's pose records (as k_readout leaves them)
+        int k = 0;
+        for (int sn = 0; sn < c.nsensor; ++sn) {
+          const int* si = c.I + c.off_sensor + sn * TSIM_SI_SIZE;
+          const int nsp = ts_u(si[TSIM_SI_NSPRIM]), sp0 = ts_u(si[TSIM_SI_SPRIM0]);
+          for (int j = 0; j < nsp; ++j, ++k) {
+            TS_SYNC();
+            pair_stage_value(c, ts_u(c.I[c.off_sprim + sp0 + j]), 0, lane == 0);
+            TS_SYNC();
+            const size_t rec = ((size_t)f * a.B + env) * a.nspt + k;
+            if (valid) {
+              for (int e = lane; e < TP_R_SIZE; e += LPE) a.fposeR[rec * TP_R_SIZE + e] = c.PP[e];
+              if (lane < TP_D_SIZE) a.fposeD[rec * TP_D_SIZE + lane] = c.PPd[lane];
+            }
           }
         }
       }
+      if (frame_end) { ++f; fs = true; if (f == a.nframes) { done = true; fs = false; ss = false; } }
       TS_SYNC();
-      if (__any(solve)) {
-        solve_newton<R, NRM, LPE>(c.H, c.rhs, c.dq, nr, false, lane, solve);
-        if (solve) {
-          alpha = R(1); ls = 0;
-          if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-        }
-        TS_SYNC();
-      }
-      if (__all(fin)) break;
     }
-    if (!conv) ++bad;
-    gmax = t_max(gmax, gn);
-    // commit the sub-step: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
-    if (a.record && valid) {
-      R* rec = a.tape + ((size_t)(a.t0 + f * a.nsub + s + 1) * a.B + env) * REC;
-      if (lane < nr) { rec_q(rec)[lane] = c.qD[lane]; rec[rec_qd<R>(nr) + lane] = c.qd[lane]; }
-      for (int e = lane; e < nr * nr; e += LPE) rec[rec_H<R>(nr) + e] = c.H[e];
-      if (lane < nu) rec[rec_u<R>(nr) + lane] = c.u[lane];
-    }
-    TS_SYNC();
-    if (lane < nr) {
-      c.qm1[lane] = c.q0[lane]; c.qm1D[lane] = c.q0D[lane]; c.qdm1[lane] = c.qd0[lane];
-      c.q0[lane] = c.q[lane]; c.q0D[lane] = c.qD[lane]; c.qd0[lane] = c.qd[lane];
-    }
-    has_prev = true;
-    TS_SYNC();
-  }
-  if (lane < nr && valid) {
-    const size_t o = ((size_t)f * a.B + env) * nr + lane;
-    if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
-    if (a.qd_out) a.qd_out[o] = c.qd0[lane];
-  }
-  // link poses / velocities in LDS are those of the accepted state (last evaluation)
-  const int tslot = a.tac_slot ? a.tac_slot[f] : f;
-  readout<LPE>(c, lane, env, valid, valid && tslot >= 0, a.var_out != nullptr, a.tac_out != nullptr && tslot >= 0,
-               a.var_out ? a.var_out + (size_t)f * a.B * 3 * c.nvar : nullptr,
-               (a.tac_out && tslot >= 0) ? a.tac_out + (size_t)tslot * a.B * 3 * c.ntax : nullptr);
-  TS_SYNC();
   }
   if (a.poseR) {
     // Large pads are read out on demand (tsim_readout), by a kernel whose lanes are taxels and which needs, per (sensor, primitive)
@@ -314,6 +376,9 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     if (a.gnorm && lane == 0) a.gnorm[env] = (float)gmax;
 #ifdef TS_PP_TIME
     if (a.gnorm && lane == 0) a.gnorm[env] = (float)((double)pp_cycles_ / (double)(clock64() - pp_t0_));
+#endif
+#ifdef TS_ROUND_STATS
+    if (lane == 0) { if (a.gnorm) a.gnorm[env] = (float)(clock64() - rs_t0_); if (a.status) a.status[env] = rounds_; }
 #endif
   }
 }

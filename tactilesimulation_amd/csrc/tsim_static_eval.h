@@ -1,0 +1,156 @@
+// tsim_static_eval.h — the residual evaluation of a statically known model as ONE register-resident pass (included by tsim_eval.h).
+//
+// The generic evaluation is three phases that talk through LDS records: the link sweep leaves a value record per link and a tangent
+// record per (link, direction); phase 2 stages each contact pair's pose (lanes = pairs) and per-direction 12-vectors (lanes = (pair,
+// direction)) in LDS, runs the point loops, leaves the pairs' wrenches in LDS again and folds them into the links' records (lanes =
+// directions); phase 3 reads those back leaf -> root.  Every hand-over is a store, a wait and a dependent load for a lone wavefront,
+// and every phase re-derives who it is from the schedule.
+// With the model's blob a compile-time constant (tsim_static.h) the level-parallel sweep already has every link's state in EVERY lane's
+// registers (all lanes compute all values; lane k computes the tangent w.r.t. dof k).  From there on nothing needs LDS:
+//   * a pair's pose in its primitive's frame is a function of two link states the lane holds — every lane computes it (the pair's
+//     primitive frame, its links, its point range are constants; a world-fixed link folds to the identity);
+//   * the 12-vector of (pair, direction k) is a function of that pose and of the lane's own tangents;
+//   * the point loop (pair_points_matrix, the same code as the generic kernels') reduces to the 6 x 12 matrix in every lane; lane k
+//     applies it to ITS 12-vector, brings the wrench and its tangent to the world frame and adds them to its per-link accumulators;
+//   * the leaf -> root pass is a compile-time loop over the levels on those accumulators; the parents are constants.
+// What still goes to LDS is what something ELSE reads: the link value records (read-out, the adjoint kernel's output_vjp and
+// mass_times_z), the joint screws WP, the twist tangents DT_VW (output_vjp), and the result: g and H.
+// An evaluation round of four environments (fine stamps, profiles/r04_static_model.md): 37.7 k -> see there.
+#pragma once
+
+// pair PK of the static model: pose, this lane's 12-vector, the point loop, the fold into the lane's per-link wrench accumulators
+template <class R, int NRM, int LPE, class MS, int PK>
+__device__ __forceinline__ void ts_fused_pair(const Ctx<R>& c, int lane, R sq, const TsLinkState<R>* st, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
+  using T = TsTopo<MS>;
+  constexpr int NP = MS::Iv(TSIM_IH_NPAIR);
+  if constexpr (PK < NP) {
+    constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + PK * TSIM_PI_SIZE, fo = MS::Iv(TSIM_IH_FOFF_PAIR) + PK * TSIM_PF_SIZE;
+    constexpr int flags = MS::Iv(o + TSIM_PI_FLAGS), prim = MS::Iv(o + TSIM_PI_PRIM), npt = MS::Iv(o + TSIM_PI_NPT), pt0 = MS::Iv(o + TSIM_PI_PT0);
+    constexpr int la = MS::Iv(o + TSIM_PI_LINKA), lb = MS::Iv(o + TSIM_PI_LINKB);
+    if constexpr ((flags & 1) != 0) {
+      const int k = lane;
+      // ---- the pair's float record as constants (rounded to R first: the device blob holds R)
+      R pf[TSIM_PF_SIZE];
+#pragma unroll
+      for (int e = 0; e < TSIM_PF_SIZE; ++e) pf[e] = (R)MS::Fv(fo + e);
+      M3<double> Rprim; V3<double> pprim;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rprim.m[e] = (double)pf[TSIM_PF_R + e];
+      pprim = mk3<double>((double)pf[TSIM_PF_P], (double)pf[TSIM_PF_P + 1], (double)pf[TSIM_PF_P + 2]);
+      // ---- pose of A in the primitive's frame (pair_stage_value), from the link states in registers; link 0 is the world
+      M3<double> RPd; V3<double> pPd;
+      if constexpr (lb == 0) { RPd = Rprim; pPd = pprim; }
+      else { RPd = mulMM(st[lb].Rd, Rprim); pPd = mulMv(st[lb].Rd, pprim) + st[lb].pd; }
+      PairPose<R> P;
+      if constexpr (la == 0) { P.RPAd = mulMtM(RPd, M3<double>{{1, 0, 0, 0, 1, 0, 0, 0, 1}}); P.pPAd = mulMtv(RPd, zero3<double>() - pPd); }
+      else { P.RPAd = mulMtM(RPd, st[la].Rd); P.pPAd = mulMtv(RPd, st[la].pd - pPd); }
+      const M3<R> RP = cvtm<R>(RPd);
+      const V3<R> pP = cvt3<R>(pPd);
+      S6<R> VA = zero6<R>(), VB = zero6<R>(), dVA = zero6<R>(), dVB = zero6<R>();
+      if constexpr (la != 0) { VA = st[la].V; dVA = st[la].dV; }
+      if constexpr (lb != 0) { VB = st[lb].V; dVB = st[lb].dV; }
+      const S6<R> Vrel = to_frame(RP, pP, VA - VB);
+      P.RPA = cvtm<R>(P.RPAd); P.pPA = cvt3<R>(P.pPAd); P.wrel = Vrel.a; P.vrel = Vrel.l;
+      // ---- this lane's direction (pair_stage_tangent, vmode 0): relative displacement and d(relative twist) in the primitive's frame
+      constexpr int ancA = la != 0 ? T::li(la == 0 ? 1 : la, TSIM_LI_ANCMASK) : 0, ancB = lb != 0 ? T::li(lb == 0 ? 1 : lb, TSIM_LI_ANCMASK) : 0;
+      const R inA = ((ancA >> k) & 1) ? R(1) : R(0), inB = ((ancB >> k) & 1) ? R(1) : R(0);
+      const S6<R> dxiP = to_frame(RP, pP, Wk * (sq * (inA - inB)));
+      const S6<R> dxiB = to_frame(RP, pP, Wk * (sq * inB));
+      const S6<R> dVrel = to_frame(RP, pP, dVA - dVB) - crm(dxiB, Vrel);
+      // ---- lanes = contact points
+      R w0[6], M[6][12];
+      const bool any_hit = pair_points_matrix<R, LPE, prim, flags>(c, pt0, npt, prim, (flags & 2) != 0, pf, P, lane, w0, M);
+      TS_STAMP2(c);
+      if (any_hit) {
+        constexpr bool kHalfRow = npt <= 8 && NRM <= 8;      // all points (and all directions) in the first 8 lanes of the slot
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          w0[e] = kHalfRow ? half_row_sum(w0[e]) : seg_sum<LPE>(w0[e]);
+#pragma unroll
+          for (int j = 0; j < 12; ++j) M[e][j] = kHalfRow ? half_row_sum(M[e][j]) : seg_sum<LPE>(M[e][j]);
+        }
+        TS_STAMP2(c);
+        // ---- lanes = directions: (dn; dF) = M t, to the world frame, into the links (pair_fold)
+        const R t[12] = {dxiP.a.x, dxiP.a.y, dxiP.a.z, dxiP.l.x, dxiP.l.y, dxiP.l.z, dVrel.a.x, dVrel.a.y, dVrel.a.z, dVrel.l.x, dVrel.l.y, dVrel.l.z};
+        R acc[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          R s_ = R(0);
+#pragma unroll
+          for (int j = 0; j < 12; ++j) s_ += M[e][j] * t[j];
+          acc[e] = s_;
+        }
+        const S6<R> Ww = wrench_to_world(RP, pP, mk6<R>(mk3<R>(w0[0], w0[1], w0[2]), mk3<R>(w0[3], w0[4], w0[5])));
+        const S6<R> dWw = wrench_to_world(RP, pP, mk6<R>(mk3<R>(acc[0], acc[1], acc[2]), mk3<R>(acc[3], acc[4], acc[5]))) + crf(Wk * (sq * inB), Ww);
+        if constexpr (la != 0) { Fl[la] = Fl[la] - Ww; dFl[la] = dFl[la] - dWw; }      // link 0 (world-fixed general bodies) takes no wrench
+        if constexpr (lb != 0) { Fl[lb] = Fl[lb] + Ww; dFl[lb] = dFl[lb] + dWw; }
+      } else TS_STAMP2(c);
+      TS_STAMP2(c);
+    }
+    ts_fused_pair<R, NRM, LPE, MS, PK + 1>(c, lane, sq, st, Wk, Fl, dFl);
+  }
+}
+
+// leaf -> root over the lane's accumulators: tau_j = W_j . F_subtree(link(j)), column k of H, the value g (lane 0), a link's subtree
+// wrench into its parent's — links of level LEVEL, then the levels above
+template <class R, class MS, int LEVEL, int LINK>
+__device__ __forceinline__ void ts_fused_up_links(const Ctx<R>& c, int lane, R sq, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
+  using T = TsTopo<MS>;
+  if constexpr (LINK <= T::NL) {
+    if constexpr (TsLevels<MS>::depth(LINK) == LEVEL) {
+      constexpr int i = LINK, par = T::li(i, TSIM_LI_PARENT), k0 = T::li(i, TSIM_LI_DOF0), ndj = T::li(i, TSIM_LI_NDOF), ancm = T::li(i, TSIM_LI_ANCMASK), nr = T::NR;
+      const int k = lane;
+      const S6<R> F = Fl[i], dF = dFl[i];
+      const S6<R> Wj[3] = {tmp[i].Wj0, tmp[i].Wj1, tmp[i].Wj2};
+      const R mv = ((ancm >> k) & 1) ? sq : R(0);          // does dof k move link i (its own joint's dofs included)
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj) {
+        if (jj < ndj) {
+          const R dtau = dot6(Wj[jj], dF) + mv * dot6(crm(Wk, Wj[jj]), F);
+          if (k < nr) c.H[(k0 + jj) * nr + k] = dtau * h2;                  // columns are stored scaled by 1 / ca (g = r / ca)
+          if (k == 0) c.g[k0 + jj] = dot6(Wj[jj], F);
+        }
+      }
+      if constexpr (par != 0) { Fl[par] = Fl[par] + F; dFl[par] = dFl[par] + dF; }
+    }
+    ts_fused_up_links<R, MS, LEVEL, LINK + 1>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
+  }
+}
+template <class R, class MS, int LEVEL>
+__device__ __forceinline__ void ts_fused_up(const Ctx<R>& c, int lane, R sq, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
+  if constexpr (LEVEL >= 0) {
+    ts_fused_up_links<R, MS, LEVEL, 1>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
+    ts_fused_up<R, MS, LEVEL - 1>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
+  }
+}
+template <class R, class MS, int LINK>
+__device__ __forceinline__ void ts_fused_link_wrenches(const TsLinkState<R>* st, const TsLinkTmp<R>* tmp, S6<R>* Fl) {
+  if constexpr (LINK <= TsTopo<MS>::NL) {
+    Fl[LINK] = tmp[LINK].IA + crf(st[LINK].V, tmp[LINK].h);      // the value record's LK_FN (ts_l_store_values)
+    ts_fused_link_wrenches<R, MS, LINK + 1>(st, tmp, Fl);
+  }
+}
+
+// phases 1 - 3 of one evaluation (what evaluate() runs between setting q / qd / qa and returning g, H), INERTIA: the value records carry
+// the COM / inertia entries (the adjoint kernel's mass_times_z reads them)
+template <class R, int NRM, int LPE, class MS, bool INERTIA>
+__device__ __forceinline__ void evaluate_static_fused(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+  using T = TsTopo<MS>;
+  static_assert(!T::has_exp() && T::NR <= 16, "static sweep: no rotation-vector joint, at most 16 dofs");
+  static_assert(MS::Iv(TSIM_IH_NPAIR) <= 8, "fused static evaluation: the pairs are unrolled");
+  TS_SYNC();
+  TsLinkState<R> st[T::NL + 1];
+  TsLinkTmp<R> tmp[T::NL + 1];
+  S6<R> Wk = zero6<R>(), dFl[T::NL + 1], Fl[T::NL + 1];
+  ts_l_level<R, MS, true, INERTIA, false, 0>(c, lane, sq, sv, sa, st, tmp, Wk, dFl);
+  ts_fused_link_wrenches<R, MS, 1>(st, tmp, Fl);
+  TS_STAMP(c);
+  ts_fused_pair<R, NRM, LPE, MS, 0>(c, lane, sq, st, Wk, Fl, dFl);
+  TS_STAMP(c);
+  const R h2 = R(1) / c.ca;      // g = r / ca  (BDF1: h^2 r)
+  ts_fused_up<R, MS, TsLevels<MS>::max_depth()>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
+  TS_SYNC();
+  TS_STAMP2(c);
+  phase3_joint_space<R>(c, lane, sq, sv, h2);
+  TS_SYNC();
+}

@@ -41,11 +41,11 @@ def test_static_pusher_kernels_equal_the_generic_ones_bit_for_bit(pusher_model):
     ra, rb = _run(a, q0, u, T, S, wq, wv, wt), _run(b, q0, u, T, S, wq, wv, wt)
     # Folding a structural zero out of  a0 b0 + a1 b1 + a2 b2  is exact, but the compiler is then free to contract the two products that remain
     # the other way round (fma(a0, b0, a1 b1) or fma(a1, b1, a0 b0)): the two kernels are fp32 roundings of the same arithmetic, not the same
-    # bits.  Measured at B = 4096 over 60 sub-steps: q 1e-6, tactile 9e-6 of its maximum, the same Newton work in 99.9 % of the environments,
+    # bits.  Measured at B = 4096 over 60 sub-steps: q 1e-6 - 2.4e-6, tactile 9e-6 of its maximum, the same Newton work in 99.9 % of the environments,
     # episode gradients per environment: median 1e-6 (profiles/r04_static_model.md).
     rel = lambda x, y: float((x - y).abs().max()) / max(float(y.abs().max()), 1e-30)
     assert torch.equal(ra[0]["status"], rb[0]["status"]) and int(ra[0]["status"].abs().max()) == 0
-    assert float((ra[0]["q"] - rb[0]["q"]).abs().max()) < 2e-6 and float((ra[0]["qd"] - rb[0]["qd"]).abs().max()) < 2e-4
+    assert float((ra[0]["q"] - rb[0]["q"]).abs().max()) < 5e-6 and float((ra[0]["qd"] - rb[0]["qd"]).abs().max()) < 2e-4
     assert rel(ra[0]["var"], rb[0]["var"]) < 1e-5 and rel(ra[0]["tactile"], rb[0]["tactile"]) < 1e-4
     assert float(ra[0]["tactile"].abs().max()) > 0
     assert (ra[1] == rb[1]).mean() > 0.99 and abs(int(ra[1].sum()) - int(rb[1].sum())) < 1e-3 * rb[1].sum()      # Newton work
@@ -61,6 +61,39 @@ def test_static_pusher_kernels_equal_the_generic_ones_bit_for_bit(pusher_model):
     rep("static_vs_generic", q=float((ra[0]["q"] - rb[0]["q"]).abs().max()), qd=float((ra[0]["qd"] - rb[0]["qd"]).abs().max()), tactile=rel(ra[0]["tactile"], rb[0]["tactile"]),
         du_median=float(np.median(errs["du"])), du_p999=float(np.quantile(errs["du"], 0.999)), du_max=float(errs["du"].max()), du_within_1e4=float((errs["du"] < 1e-4).mean()),
         lamq_median=float(np.median(errs["lamq"])), lamq_max=float(errs["lamq"].max()), same_evals=float((ra[1] == rb[1]).mean()))
+
+
+def test_one_static_evaluation_against_the_generic_and_the_fp64_one(pusher_model):
+    """g and H of ONE residual evaluation (tsim_debug_eval) at 512 states of the workload, a third of them with the pad on the box: the fused
+    static evaluation (tsim_static_eval.h) and the generic three-phase one are both fp32 roundings of what the fp64 kernel computes, equally close."""
+    B, T, S = 512, 8, 5
+    q0, u, _ = push_workload(B, T, seed=11)
+    d = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0)
+    d.reset(torch.tensor(q0, device=DEV, dtype=torch.float64), None, backward_flag=False)
+    ro = d.rollout(torch.tensor(u, device=DEV, dtype=torch.float64).transpose(0, 1).contiguous(), S, want_qd=True)
+    assert float((ro["tactile"][-1].abs().sum(1) > 0).float().mean()) > 0.05          # some environments are in contact at the probe state
+    q, qd = ro["q"][-1], ro["qd"][-1]
+    h = float(pusher_model.h)
+    q1 = q + h * qd + 1e-4 * torch.randn(B, 7, generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(DEV)
+    uu = torch.tensor(u[:, -1], device=DEV, dtype=torch.float64)
+    gd, Hd = d.debug_eval(q1, q, qd, uu)
+    a = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=0)
+    b = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=0)
+    b.set_static(False); a.set_lanes_per_env(16); b.set_lanes_per_env(16)
+    assert a.static_model() == 1 and b.static_model() == 0
+    f = lambda x: x.float()
+    (ga, Ha), (gb, Hb) = (s_.debug_eval(f(q1), f(q), f(qd), f(uu)) for s_ in (a, b))
+    def err(x, y):      # per environment, relative to the environment's largest entry
+        x, y = x.double().reshape(B, -1), y.reshape(B, -1)
+        return ((x - y).abs().max(1).values / y.abs().max(1).values.clamp_min(1e-30)).cpu().numpy()
+    eHa, eHb, ega, egb = err(Ha, Hd), err(Hb, Hd), err(ga, gd), err(gb, gd)
+    # H entries: stiffness x h^2 of penalty contacts (relative rounding of fp32 ~1e-7 per operation, a few hundred operations deep)
+    assert np.median(eHa) < 2e-6 and np.median(eHb) < 2e-6 and eHa.max() < 1e-3 and eHb.max() < 1e-3, (np.median(eHa), np.median(eHb), eHa.max(), eHb.max())
+    assert np.median(ega) < 1e-5 and np.median(egb) < 1e-5 and ega.max() < 1e-2 and egb.max() < 1e-2, (np.median(ega), np.median(egb), ega.max(), egb.max())
+    assert np.median(eHa) < 3 * np.median(eHb) + 1e-7 and np.median(ega) < 3 * np.median(egb) + 1e-7
+    from _report import rep
+    rep("static_eval_vs_f64", H_static_median=float(np.median(eHa)), H_generic_median=float(np.median(eHb)), H_static_max=float(eHa.max()), H_generic_max=float(eHb.max()),
+        g_static_median=float(np.median(ega)), g_generic_median=float(np.median(egb)), g_static_max=float(ega.max()), g_generic_max=float(egb.max()))
 
 
 def test_static_kernels_switch_off_for_other_blobs_shapes_and_tables(pusher_model):
