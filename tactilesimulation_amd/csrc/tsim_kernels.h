@@ -598,7 +598,15 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     }
     TS_SYNC();
     TS_STAMP(c);
-    if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
+    // a statically known model: link sweep, contacts and the leaf -> root pass (c.H = h^2 dr/dq) as one register-resident pass here
+    // (tsim_static_eval.h); what follows reads the link records, the joint screws and the twist tangents it leaves in LDS, and c.H at the end
+#ifdef TS_STATIC_UNFUSED
+    constexpr bool kFused = false;
+#else
+    constexpr bool kFused = !std::is_void<MS>::value && sizeof(R) == 4;
+#endif
+    if constexpr (kFused) evaluate_static_fused<R, NRM, LPE, MS, true>(c, lane, R(1), R(0), R(0));
+    else if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
 #ifdef TS_STATIC_BRANCH_BLOCKS
     else phase1_static<R, MS, true>(c, lane, R(1), R(0), R(0));
 #else
@@ -624,9 +632,11 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     TS_SYNC();
     solve_newton<R, NRM, LPE>(H2, c.rhs, c.z, nr, true, lane);
     TS_STAMP(c);
-    phase2<R, NRM, LPE, MS>(c, lane, R(1));
-    TS_STAMP(c);
-    phase3<R, EXPJ, LPE>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
+    if constexpr (!kFused) {
+      phase2<R, NRM, LPE, MS>(c, lane, R(1));
+      TS_STAMP(c);
+      phase3<R, EXPJ, LPE>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
+    } else TS_STAMP(c);
     TS_STAMP(c);
     const R ym = mass_times_z<LPE>(c, lane);
     TS_STAMP(c);

@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 O=gpurun_out/r04w
 rm -f ${O}_sites.jsonl
-( TSIM_TEST_REPORT=$PWD/${O}_sites.jsonl timeout 600 python -m pytest tests/test_gpu_static_model.py tests/test_gpu_closed_loop.py -m gpu -q --tb=short 2>&1 | tail -40 ) > ${O}_tests.log 2>&1
+( TSIM_TEST_REPORT=$PWD/${O}_sites.jsonl timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -40 ) > ${O}_tests.log 2>&1
 grep -n "^FAILED\|passed\|failed\|^E " ${O}_tests.log | tail -8; cat ${O}_sites.jsonl | grep static
+for i in 1 2; do python bench.py --steps 20 --warmup 5 --timed-only 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('fused', round(d['value']), round(d['ms_per_step'],4), {k: round(v,3) for k,v in d['kernel_ms'].items()})"; done | tee ${O}_ab.log
