@@ -279,7 +279,11 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     }
     TS_SYNC();
     if (__any(solve)) {
+#ifdef TS_NEWTON_SOLVE_F32      // A/B: the Newton step's elimination in fp32 (fp32 kernels)
+      solve_newton<R, NRM, LPE, R>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+#else
       solve_newton<R, NRM, LPE>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+#endif
       if (solve) {
         alpha = R(1); ls = 0;
         if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
