@@ -310,6 +310,41 @@ template <int LPE, class R> __device__ __forceinline__ R seg_sum(R x) {
   x += dpp_r<0x143, 0xc>(x);   // row_bcast:31    -> rows 2 and 3 add the total of rows 0-1; lane 63 has the sum
   return lane_bcast(x, 63);
 }
+// N independent sums at once, STEP by step over all of them: the N chains interleave, so no DPP instruction waits for the one before it.
+// (Written per value, the scheduler of a register-hungry kernel serialises each chain through one temporary: four dependent DPP adds with
+// their hazard nops per value — k_forward<float, 8, false, 32> after round 4's loop change: 121 extra s_nop, 8 % of the kernel's time.)
+// The scheduling barriers keep the steps apart.
+template <int LPE, int N, class R> __device__ __forceinline__ void seg_sum_many(R (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_r<0xB1, 0xf>(v[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_r<0x4E, 0xf>(v[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_r<0x141, 0xf>(v[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_r<0x140, 0xf>(v[i]);
+  __builtin_amdgcn_sched_barrier(0);
+  if (LPE == 16) return;
+  if (LPE == 32) {
+    R o[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = lane_gather(v[i], (int)threadIdx.x ^ 16);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += o[i];
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_r<0x142, 0xa>(v[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_r<0x143, 0xc>(v[i]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = lane_bcast(v[i], 63);
+}
 // sum over lanes 0..7 of each 8-lane half of a 16-lane row (three DPP steps): for per-pair sums whose points all sit in the first 8 lanes of
 // the slot (the other lanes hold zeros), result in lanes 0..7
 template <class R> __device__ __forceinline__ R half_row_sum(R x) {

@@ -389,11 +389,17 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
   TS_STAMP2(c);
   if (!any_hit) return;
   constexpr bool kHalfRow = NPTC >= 0 && NPTC <= 8 && NRM <= 8;      // all points (and all directions) in the first 8 lanes of the slot
+  if constexpr (kHalfRow) {
 #pragma unroll
-  for (int e = 0; e < 6; ++e) {
-    w0[e] = kHalfRow ? half_row_sum(w0[e]) : seg_sum<LPE>(w0[e]);
+    for (int e = 0; e < 6; ++e) {
+      w0[e] = half_row_sum(w0[e]);
 #pragma unroll
-    for (int j = 0; j < 12; ++j) M[e][j] = kHalfRow ? half_row_sum(M[e][j]) : seg_sum<LPE>(M[e][j]);
+      for (int j = 0; j < 12; ++j) M[e][j] = half_row_sum(M[e][j]);
+    }
+  } else {
+    seg_sum_many<LPE, 6>(w0);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) seg_sum_many<LPE, 12>(M[e]);
   }
   TS_STAMP2(c);
   if (lane == 0) {

@@ -735,6 +735,8 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   }
   if (defer) { a.fposeR = (R*)b->fposeR; a.fposeD = b->fposeD; }
   a.free_run = (defer || !tac_out || b->ntax == 0) && !getenv("TSIM_NO_FREE_RUN");
+  a.lockstep = getenv("TSIM_LOCKSTEP") ? 1 : 0;
+  if (a.lockstep) a.free_run = 0;
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
   if (defer && launch_taxels<R>(b, b->fposeR, b->fposeD, nframes, tac_slot, tac_out, st)) return 1;

@@ -95,10 +95,16 @@ template <class R> struct FwdArgs {
   PushPolicy<R> pol;           // POLICY instantiations only (tsim_push_closed_rollout): the TactilePush policy between the frames
   R* poseR = nullptr; double* poseD = nullptr; int nspt = 0;   // large pads: pose records of the final state for tsim_readout's k_taxels (see k_readout)
   int free_run = 0;            // the slots of a wavefront run their frames / sub-steps independently (k_forward, main loop)
+  int lockstep = 0;            // ... or go through every sub-step together (a slot that has converged re-evaluates its iterate until all have)
   R* fposeR = nullptr; double* fposeD = nullptr;               // [nframes][B][nspt] pose records per frame: the tactile frames are evaluated by k_taxels after the launch
 };
 
 // -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
+#ifdef TS_NO_COLD_HINTS      // A/B
+#define TS_UNLIKELY(x) (x)
+#else
+#define TS_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
 #ifdef TS_WAVES_PER_EU
 #define TS_KLB __launch_bounds__(TS_WAVE, TS_WAVES_PER_EU)
 #else
@@ -292,6 +298,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     }
     // ---- commit the sub-steps that ended with this evaluation: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
     bool commit = fin && !done && !held;
+    if (a.lockstep && !__all(fin || done)) commit = false;      // the slots of a wavefront go through the sub-steps together (see FwdArgs)
     if (!free_run) {                           // the last sub-step of a frame is committed by all slots together
       if (commit && s == a.nsub - 1) { held = true; commit = false; }
       if (__all(held || done)) { commit = held; held = false; }
@@ -318,7 +325,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     TS_SYNC();
     // ---- end of a frame (per slot in a free-running launch, all slots together otherwise): the link poses / velocities in LDS are
     //      those of the accepted state (last evaluation)
-    if (__any(frame_end)) {
+    if (TS_UNLIKELY(__any(frame_end))) {       // once per frame and slot: kept out of the loop's straight-line code
       if (frame_end && lane < nr && valid) {
         const size_t o = ((size_t)f * a.B + env) * nr + lane;
         if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)

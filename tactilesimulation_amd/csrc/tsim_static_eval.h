@@ -63,11 +63,17 @@ __device__ __forceinline__ void ts_fused_pair(const Ctx<R>& c, int lane, R sq, c
       TS_STAMP2(c);
       if (any_hit) {
         constexpr bool kHalfRow = npt <= 8 && NRM <= 8;      // all points (and all directions) in the first 8 lanes of the slot
+        if constexpr (kHalfRow) {
 #pragma unroll
-        for (int e = 0; e < 6; ++e) {
-          w0[e] = kHalfRow ? half_row_sum(w0[e]) : seg_sum<LPE>(w0[e]);
+          for (int e = 0; e < 6; ++e) {
+            w0[e] = half_row_sum(w0[e]);
 #pragma unroll
-          for (int j = 0; j < 12; ++j) M[e][j] = kHalfRow ? half_row_sum(M[e][j]) : seg_sum<LPE>(M[e][j]);
+            for (int j = 0; j < 12; ++j) M[e][j] = half_row_sum(M[e][j]);
+          }
+        } else {
+          seg_sum_many<LPE, 6>(w0);
+#pragma unroll
+          for (int e = 0; e < 6; ++e) seg_sum_many<LPE, 12>(M[e]);
         }
         TS_STAMP2(c);
         // ---- lanes = directions: (dn; dF) = M t, to the world frame, into the links (pair_fold)

@@ -7,15 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
 from tactilesimulation_amd.workloads import push_workload, PUSHER_BLOB
-B, T, S = 4096, int(os.environ.get("STEPS", "20")), 5
-m = load_model(PUSHER_BLOB)
+B, T, S = int(os.environ.get("BATCH", "4096")), int(os.environ.get("STEPS", "20")), 5
+from tactilesimulation_amd import workloads as W
+m = W.synthetic_variant("pusher_13x13") if os.environ.get("MODEL") == "13x13" else load_model(PUSHER_BLOB)
 q0, u, _ = push_workload(B, 100, seed=0)       # the bench's table (episodes of 100 env-steps), its first T frames
 u = u[:, :T]
-sim = BatchSim(m, B, dtype=torch.float32, tape_capacity=T * S)
+REC = os.environ.get("RECORD", "1") == "1"
+sim = BatchSim(m, B, dtype=torch.float32, tape_capacity=T * S if REC else 0)
 ut = torch.tensor(u, device="cuda:0", dtype=torch.float32).transpose(0, 1).contiguous()
 out = {}
 for rep in range(3):
-    sim.reset(torch.tensor(q0, device="cuda:0", dtype=torch.float32), None, backward_flag=True)
+    sim.reset(torch.tensor(q0, device="cuda:0", dtype=torch.float32), None, backward_flag=REC)
     ro = sim.rollout(ut, S)
     torch.cuda.synchronize()
     rounds = ro["status"].cpu().numpy().astype(np.int64)
