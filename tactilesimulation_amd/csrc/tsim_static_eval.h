@@ -97,36 +97,79 @@ __device__ __forceinline__ void ts_fused_pair(const Ctx<R>& c, int lane, R sq, c
   }
 }
 
+// joint-space forces of dof J (phase3_joint_space, with the dof's damping, limit and motor records as constants): adds to the value gj and
+// returns the joint-space part of H[J][J]; every lane computes it (q, qd, u are broadcast reads)
+template <class R, class MS, int J, int M>
+__device__ __forceinline__ void ts_fused_motors(const Ctx<R>& c, R sq, R sv, R& gj, R& hjj) {
+  if constexpr (M < MS::Iv(TSIM_IH_NU)) {
+    constexpr int mo = MS::Iv(TSIM_IH_OFF_MOTOR) + M * TSIM_MI_SIZE, mfo = MS::Iv(TSIM_IH_FOFF_MOTOR) + M * TSIM_MF_SIZE;
+    if constexpr (MS::Iv(mo + TSIM_MI_DOF) == J) {
+      if constexpr (MS::Iv(mo + TSIM_MI_CTRL) == 0) {
+        const R uc = fmin(fmax(c.u[M], R(-1)), R(1));
+        gj -= (R)MS::Fv(mfo + TSIM_MF_LO) + (uc + R(1)) * (R(0.5) * ((R)MS::Fv(mfo + TSIM_MF_HI) - (R)MS::Fv(mfo + TSIM_MF_LO)));
+      } else {
+        gj -= (R)MS::Fv(mfo + TSIM_MF_P) * (c.u[M] - c.q[J]) - (R)MS::Fv(mfo + TSIM_MF_D) * c.qd[J];
+        hjj += (R)MS::Fv(mfo + TSIM_MF_P) * sq + (R)MS::Fv(mfo + TSIM_MF_D) * sv;
+      }
+    }
+    ts_fused_motors<R, MS, J, M + 1>(c, sq, sv, gj, hjj);
+  }
+}
+template <class R, class MS, int J>
+__device__ __forceinline__ R ts_fused_joint_space(const Ctx<R>& c, R sq, R sv, R& gj) {
+  constexpr int dfo = MS::Iv(TSIM_IH_FOFF_DOF) + J * TSIM_DF_SIZE;
+  const R damping = (R)MS::Fv(dfo + TSIM_DF_DAMPING), lk = (R)MS::Fv(dfo + TSIM_DF_LIM_K), lo = (R)MS::Fv(dfo + TSIM_DF_LIM_LO), hi = (R)MS::Fv(dfo + TSIM_DF_LIM_HI);
+  R hjj = R(0);
+  gj += damping * c.qd[J]; hjj += damping * sv;
+  if constexpr (MS::Fv(dfo + TSIM_DF_LIM_K) > 0.0) {
+    if (c.q[J] < lo) { gj -= lk * (lo - c.q[J]); hjj += lk * sq; }
+    else if (c.q[J] > hi) { gj += lk * (c.q[J] - hi); hjj += lk * sq; }
+  }
+  ts_fused_motors<R, MS, J, 0>(c, sq, sv, gj, hjj);
+  return hjj;
+}
+
+// dof JJ of link LINK in the leaf -> root pass: tau_j = W_j . F, its tangent (column k of H, lane k), the joint-space forces
+template <class R, class MS, int LINK, int JJ>
+__device__ __forceinline__ void ts_fused_dof(const Ctx<R>& c, int k, R sq, R sv, R h2, R mv, const S6<R>& Wj, const S6<R>& Wk, const S6<R>& F, const S6<R>& dF) {
+  using T = TsTopo<MS>;
+  constexpr int k0 = T::li(LINK, TSIM_LI_DOF0), ndj = T::li(LINK, TSIM_LI_NDOF), nr = T::NR;
+  if constexpr (JJ < ndj) {
+    constexpr int j = k0 + JJ;
+    const R dtau = dot6(Wj, dF) + mv * dot6(crm(Wk, Wj), F);
+    R gj = dot6(Wj, F);
+    const R hjj = ts_fused_joint_space<R, MS, j>(c, sq, sv, gj);      // damping, limits, motors of this dof
+    if (k < nr) c.H[j * nr + k] = dtau * h2 + (k == j ? hjj : R(0)) * h2;      // columns are stored scaled by 1 / ca (g = r / ca)
+    if (k == 0) c.g[j] = gj * h2;
+  }
+}
+
 // leaf -> root over the lane's accumulators: tau_j = W_j . F_subtree(link(j)), column k of H, the value g (lane 0), a link's subtree
-// wrench into its parent's — links of level LEVEL, then the levels above
+// wrench into its parent's — links of level LEVEL, then the levels above.  The joint-space forces (damping, limits, motors: constants of the
+// dof) go in right here: every lane has the value g_j, lane j adds its diagonal entry
 template <class R, class MS, int LEVEL, int LINK>
-__device__ __forceinline__ void ts_fused_up_links(const Ctx<R>& c, int lane, R sq, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
+__device__ __forceinline__ void ts_fused_up_links(const Ctx<R>& c, int lane, R sq, R sv, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
   using T = TsTopo<MS>;
   if constexpr (LINK <= T::NL) {
     if constexpr (TsLevels<MS>::depth(LINK) == LEVEL) {
-      constexpr int i = LINK, par = T::li(i, TSIM_LI_PARENT), k0 = T::li(i, TSIM_LI_DOF0), ndj = T::li(i, TSIM_LI_NDOF), ancm = T::li(i, TSIM_LI_ANCMASK), nr = T::NR;
+      constexpr int i = LINK, par = T::li(i, TSIM_LI_PARENT), ancm = T::li(i, TSIM_LI_ANCMASK);
       const int k = lane;
       const S6<R> F = Fl[i], dF = dFl[i];
       const S6<R> Wj[3] = {tmp[i].Wj0, tmp[i].Wj1, tmp[i].Wj2};
       const R mv = ((ancm >> k) & 1) ? sq : R(0);          // does dof k move link i (its own joint's dofs included)
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj) {
-        if (jj < ndj) {
-          const R dtau = dot6(Wj[jj], dF) + mv * dot6(crm(Wk, Wj[jj]), F);
-          if (k < nr) c.H[(k0 + jj) * nr + k] = dtau * h2;                  // columns are stored scaled by 1 / ca (g = r / ca)
-          if (k == 0) c.g[k0 + jj] = dot6(Wj[jj], F);
-        }
-      }
+      ts_fused_dof<R, MS, LINK, 0>(c, k, sq, sv, h2, mv, Wj[0], Wk, F, dF);
+      ts_fused_dof<R, MS, LINK, 1>(c, k, sq, sv, h2, mv, Wj[1], Wk, F, dF);
+      ts_fused_dof<R, MS, LINK, 2>(c, k, sq, sv, h2, mv, Wj[2], Wk, F, dF);
       if constexpr (par != 0) { Fl[par] = Fl[par] + F; dFl[par] = dFl[par] + dF; }
     }
-    ts_fused_up_links<R, MS, LEVEL, LINK + 1>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
+    ts_fused_up_links<R, MS, LEVEL, LINK + 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);
   }
 }
 template <class R, class MS, int LEVEL>
-__device__ __forceinline__ void ts_fused_up(const Ctx<R>& c, int lane, R sq, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
+__device__ __forceinline__ void ts_fused_up(const Ctx<R>& c, int lane, R sq, R sv, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
   if constexpr (LEVEL >= 0) {
-    ts_fused_up_links<R, MS, LEVEL, 1>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
-    ts_fused_up<R, MS, LEVEL - 1>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
+    ts_fused_up_links<R, MS, LEVEL, 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);
+    ts_fused_up<R, MS, LEVEL - 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);
   }
 }
 template <class R, class MS, int LINK>
@@ -154,9 +197,7 @@ __device__ __forceinline__ void evaluate_static_fused(const Ctx<R>& c, int lane,
   ts_fused_pair<R, NRM, LPE, MS, 0>(c, lane, sq, st, Wk, Fl, dFl);
   TS_STAMP(c);
   const R h2 = R(1) / c.ca;      // g = r / ca  (BDF1: h^2 r)
-  ts_fused_up<R, MS, TsLevels<MS>::max_depth()>(c, lane, sq, h2, tmp, Wk, Fl, dFl);
+  ts_fused_up<R, MS, TsLevels<MS>::max_depth()>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);      // ... with the joint-space forces of each dof
   TS_SYNC();
   TS_STAMP2(c);
-  phase3_joint_space<R>(c, lane, sq, sv, h2);
-  TS_SYNC();
 }

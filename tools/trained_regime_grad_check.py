@@ -76,6 +76,7 @@ def run(E=80, verbose=True):
         ishard = np.isin(idx, hard)
         out[name] = dict(q_err_max=float(dq.max()), q_err_median=float(np.median(dq)), branch_agree=int(same.sum()), grad_err_median=float(np.median(eg)),
                          grad_err_max_agreeing=float(eg[same].max()) if same.any() else None, grad_err_max_all=float(eg.max()),
+                         grad_err_within_1e4=int((eg < 1e-4).sum()), grad_err_second_largest=float(np.sort(eg)[-2]),
                          grad_err_max_hard_agreeing=float(eg[same & ishard].max()) if (same & ishard).any() else None, hard_agree=int((same & ishard).sum()),
                          dLdu_scale_median=float(np.median(np.abs(O["du"]).max(axis=(0, 2)))), dLdu_scale_max=float(np.abs(O["du"]).max()))
         print(name, json.dumps(out[name]))
