@@ -789,28 +789,31 @@ template <int L> __device__ __forceinline__ double row_bcast(double x) {        
 template <int L> __device__ __forceinline__ float row_bcast(float x) { return __builtin_bit_cast(float, dpp_i<0x150 + L, 0xf>(__builtin_bit_cast(int, x))); }
 __device__ __forceinline__ float fast_rcp_s(float x) { const float r = __builtin_amdgcn_rcpf(x); return fmaf(fmaf(-x, r, 1.0f), r, r); }
 __device__ __forceinline__ double fast_rcp_s(double x) { return fast_rcp(x); }
-template <int COL, int NRM, class S>
+// NC > 0: the system's size as a compile-time constant (static models): columns >= NC do not exist
+template <int COL, int NRM, class S, int NC = 0>
 __device__ __forceinline__ void gj_step_nopivot(S (&a)[NRM], S& rb, S& mypiv, bool& bad, int n, bool row, int lane) {
+  constexpr int NCOL = NC > 0 ? NC : NRM;
   if (COL < n) {                                   // wave-uniform
     S prow[NRM];
 #pragma unroll
-    for (int j = COL; j < NRM; ++j) prow[j] = row_bcast<COL>(a[j]);
+    for (int j = COL; j < NCOL; ++j) prow[j] = row_bcast<COL>(a[j]);
     const S pb = row_bcast<COL>(rb);
     const S piv = prow[COL];
     const bool elim = row && lane != COL;          // identity rows (lanes >= n, other 16-lane rows of a wide slot) take no part
     const S f = elim ? a[COL] * fast_rcp_s(piv) : S(0);
     bad = bad || (elim && (!ts_finite(f) || t_abs(f) >= S(1e6)));      // also catches a zero / non-finite pivot
 #pragma unroll
-    for (int j = COL; j < NRM; ++j) a[j] -= f * prow[j];
+    for (int j = COL; j < NCOL; ++j) a[j] -= f * prow[j];
     rb -= f * pb;
     if (lane == COL) mypiv = piv;
   }
-  if constexpr (COL + 1 < NRM) gj_step_nopivot<COL + 1, NRM, S>(a, rb, mypiv, bad, n, row, lane);
+  if constexpr (COL + 1 < NCOL) gj_step_nopivot<COL + 1, NRM, S, NC>(a, rb, mypiv, bad, n, row, lane);
 }
 // Solves A x = b (or A^T x = b) as solve_lanes does; returns false in the lanes of a slot whose elimination met a bad multiplier (x is then
 // NOT written for that slot: the caller falls back to solve_lanes).
-template <class R, int NRM, int LPE, class S = double>
-__device__ __forceinline__ bool solve_lanes_nopivot(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
+template <class R, int NRM, int LPE, class S = double, int NC = 0>
+__device__ __forceinline__ bool solve_lanes_nopivot(const R* A, const R* b, R* x, int n_, bool transpose, int lane, bool write = true) {
+  const int n = NC > 0 ? NC : n_;
   S a[NRM], rb, mypiv = S(1);
   const bool row = lane < n;
   const int r = min(lane, n - 1);
@@ -822,7 +825,7 @@ __device__ __forceinline__ bool solve_lanes_nopivot(const R* A, const R* b, R* x
   }
   rb = row ? (S)b[r] : S(0);
   bool bad = false;
-  gj_step_nopivot<0, NRM, S>(a, rb, mypiv, bad, n, row, lane);
+  gj_step_nopivot<0, NRM, S, NC>(a, rb, mypiv, bad, n, row, lane);
   const bool slot_bad = seg_max<LPE>(bad ? 1.0f : 0.0f) > 0.0f;
   if (write && row && !slot_bad) x[lane] = (R)(rb * fast_rcp_s(mypiv));
   TS_SYNC();
@@ -831,11 +834,11 @@ __device__ __forceinline__ bool solve_lanes_nopivot(const R* A, const R* b, R* x
 // the solve the kernels call: fp32 kernels try the pivot-free DPP form first (-DTS_SOLVE_PIVOT_ONLY: A/B), fp64 kernels always pivot
 // S: the precision of the elimination.  double for the adjoint solves (their error goes straight into the gradient); the NEWTON steps of the
 // fp32 kernels may take R: the matrix they eliminate is an fp32 rounding already, and the step only has to reduce ||g|| (the residual decides)
-template <class R, int NRM, int LPE, class S = double>
+template <class R, int NRM, int LPE, class S = double, int NC = 0>
 __device__ __forceinline__ void solve_newton(const R* A, const R* b, R* x, int n, bool transpose, int lane, bool write = true) {
 #ifndef TS_SOLVE_PIVOT_ONLY
   if (sizeof(R) == 4) {
-    const bool ok = solve_lanes_nopivot<R, NRM, LPE, S>(A, b, x, n, transpose, lane, write);
+    const bool ok = solve_lanes_nopivot<R, NRM, LPE, S, NC>(A, b, x, n, transpose, lane, write);
     if (__all(ok || !write)) return;
   }
 #endif

@@ -9,6 +9,9 @@
 #include "tsim_eval.h"
 #include "tsim_policy_push.h"
 
+// number of dofs of a statically known model (0: generic kernels, the size is a run-time value)
+template <class MS> constexpr int ts_static_nr() { if constexpr (std::is_void<MS>::value) return 0; else return MS::Iv(TSIM_IH_NR); }
+
 // tape record per (sub-step, env), in reals: q[nr] as DOUBLE (the pose chain is double also in the fp32 kernels),
 // qd[nr], H[nr*nr], u[nu]; padded to an even count so that every record starts 8-byte aligned
 __host__ __device__ inline int ts_qw(int esz) { return 8 / esz; }                      // reals per double
@@ -288,7 +291,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
 #ifdef TS_NEWTON_SOLVE_F32      // A/B: the Newton step's elimination in fp32 (fp32 kernels)
       solve_newton<R, NRM, LPE, R>(c.H, c.rhs, c.dq, nr, false, lane, solve);
 #else
-      solve_newton<R, NRM, LPE>(c.H, c.rhs, c.dq, nr, false, lane, solve);
+      solve_newton<R, NRM, LPE, double, ts_static_nr<MS>()>(c.H, c.rhs, c.dq, nr, false, lane, solve);
 #endif
       if (solve) {
         alpha = R(1); ls = 0;
@@ -641,7 +644,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     TS_STAMP(c);
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.cv * c.lamv[lane];      // d qd1 / d q1 = cv
     TS_SYNC();
-    solve_newton<R, NRM, LPE>(H2, c.rhs, c.z, nr, true, lane);
+    solve_newton<R, NRM, LPE, double, ts_static_nr<MS>()>(H2, c.rhs, c.z, nr, true, lane);
     TS_STAMP(c);
     if constexpr (!kFused) {
       phase2<R, NRM, LPE, MS>(c, lane, R(1));
