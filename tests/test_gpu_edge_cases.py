@@ -152,6 +152,53 @@ def test_on_demand_readout_equals_the_step_outputs(name, dtype):
         assert float(tac.abs().max()) > 0, "the scenario never loaded a taxel: nothing was compared"
 
 
+@pytest.mark.parametrize("name,static", [("pusher", True), ("pusher", False), ("dclaw_position_control", False), ("tactile_insertion", False)])
+def test_scheduling_inside_a_launch_does_not_change_a_bit(name, static, monkeypatch):
+    """How the environments of a wavefront are scheduled inside an episode launch is not part of the result: free-running slots with the
+    tactile frames evaluated by k_taxels after the launch (the default), slots held together at the frame ends with the in-kernel read-out
+    (TSIM_NO_FREE_RUN / TSIM_INKERNEL_READOUT: what closed-loop launches do), and lock-step sub-steps (TSIM_LOCKSTEP: round 3's loop) give
+    the same states, tactile frames, Newton work and episode gradients bit for bit — on a ragged batch (67 environments), masked tactile frames."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.workloads import asset
+    m = load_model(asset(name))
+    B, T = 67, 8
+    if name == "pusher":
+        q0, u, _ = push_workload(B, T, seed=9)
+        u[:, :, 0] = np.abs(u[:, :, 0])                              # towards the box: taxels load within the episode
+    else:
+        from test_gpu_models import _inputs
+        T = 12
+        q0, u = _inputs(name, m, B, T)
+    mask = torch.ones(T, dtype=torch.bool); mask[1] = False; mask[T - 2] = False
+    g = torch.Generator().manual_seed(4)
+    wq, wt = torch.randn(T, B, m.ndof_r, generator=g).cuda(), torch.randn(int(mask.sum()), B, m.ndof_tactile, generator=g).cuda()
+    wv = torch.randn(T, B, m.ndof_var, generator=g).cuda() if m.ndof_var else None
+    def run(env):
+        for k in ("TSIM_NO_FREE_RUN", "TSIM_INKERNEL_READOUT", "TSIM_LOCKSTEP"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        sim = BatchSim(m, B, dtype=torch.float32, tape_capacity=T * S)
+        sim.set_static(static)
+        assert sim.static_model() == int(static)
+        sim.reset(torch.tensor(q0, dtype=torch.float32), None, backward_flag=True)
+        ro = sim.rollout(torch.tensor(u, dtype=torch.float32).transpose(0, 1).contiguous().cuda(), S, want_qd=True, tactile_mask=mask)
+        ev = sim.last_evals().copy()
+        du = sim.backward_episode(T, S, wq, wv, wt, tactile_mask=mask)
+        return ro, ev, du
+    ref = run(())
+    assert float(ref[0]["tactile"].abs().max()) > 0
+    for env in (("TSIM_NO_FREE_RUN",), ("TSIM_INKERNEL_READOUT",), ("TSIM_NO_FREE_RUN", "TSIM_INKERNEL_READOUT"), ("TSIM_LOCKSTEP",), ("TSIM_LOCKSTEP", "TSIM_INKERNEL_READOUT")):
+        got = run(env)
+        for k in ("q", "qd", "tactile", "status") + (("var",) if m.ndof_var else ()):
+            assert torch.equal(got[0][k], ref[0][k]), (env, k)
+        assert (got[1] == ref[1]).all() and torch.equal(got[2], ref[2]), env
+
+
 def test_large_batch_long_episode_indices_are_64_bit(pusher_model):
     """32 768 environments x 100 env-steps (a 4.5 GB tape, 5 GB of tactile output: every per-environment offset beyond 2^32 bytes): eight
     copies of one 4096-environment batch give eight bit-identical blocks, forward and adjoint, and everything converges."""
