@@ -329,6 +329,10 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     // ---- end of a frame (per slot in a free-running launch, all slots together otherwise): the link poses / velocities in LDS are
     //      those of the accepted state (last evaluation)
     if (TS_UNLIKELY(__any(frame_end))) {       // once per frame and slot: kept out of the loop's straight-line code
+#ifndef TS_STATIC_UNFUSED
+      // the fused static evaluation leaves no link records in LDS: write those of the frame's final state now (what the read-out reads)
+      if constexpr (!std::is_void<MS>::value && sizeof(R) == 4) { if (frame_end) ts_static_value_records<R, MS>(c, lane); }
+#endif
       if (frame_end && lane < nr && valid) {
         const size_t o = ((size_t)f * a.B + env) * nr + lane;
         if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
@@ -359,6 +363,9 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       TS_SYNC();
     }
   }
+#ifndef TS_STATIC_UNFUSED
+  if constexpr (!std::is_void<MS>::value && sizeof(R) == 4) { if (a.poseR && a.nframes <= 0) ts_static_value_records<R, MS>(c, lane); }
+#endif
   if (a.poseR) {
     // Large pads are read out on demand (tsim_readout), by a kernel whose lanes are taxels and which needs, per (sensor, primitive)
     // combination, the pose of the sensor link in the primitive's frame and the relative twist there.  The link records in LDS are those
