@@ -619,14 +619,16 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     }
     TS_SYNC();
     TS_STAMP(c);
-    // a statically known model: link sweep, contacts and the leaf -> root pass (c.H = h^2 dr/dq) as one register-resident pass here
-    // (tsim_static_eval.h); what follows reads the link records, the joint screws and the twist tangents it leaves in LDS, and c.H at the end
+    // A statically known model (tsim_static_eval.h): the evaluation at the taped state is one register-resident pass AFTER the adjoint solve
+    // and returns this lane's (H^T z, M z) — no records, no c.H.  Only a sub-step that carries a loss seed needs link records in LDS
+    // (output_vjp reads them): it runs the link sweep alone first.
 #ifdef TS_STATIC_UNFUSED
     constexpr bool kFused = false;
 #else
     constexpr bool kFused = !std::is_void<MS>::value && sizeof(R) == 4;
 #endif
-    if constexpr (kFused) evaluate_static_fused<R, NRM, LPE, MS, true>(c, lane, R(1), R(0), R(0));
+    const bool seeded = (j + 1) % a.seed_stride == 0;
+    if constexpr (kFused) { if (seeded) ts_static_records_for_vjp<R, MS>(c, lane); }
     else if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
 #ifdef TS_STATIC_BRANCH_BLOCKS
     else phase1_static<R, MS, true>(c, lane, R(1), R(0), R(0));
@@ -635,7 +637,6 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
 #endif
     TS_STAMP(c);
     // direct partials of the loss w.r.t. this sub-step's outputs
-    const bool seeded = (j + 1) % a.seed_stride == 0;
     if (seeded) {
       const int fr = j / a.seed_stride;
       const size_t so = a.frames ? (size_t)fr * a.B + env : (size_t)env * (a.n / a.seed_stride) + fr;
@@ -653,17 +654,21 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     TS_SYNC();
     solve_newton<R, NRM, LPE, double, ts_static_nr<MS>()>(H2, c.rhs, c.z, nr, true, lane);
     TS_STAMP(c);
+    R ym, yq = R(0);
     if constexpr (!kFused) {
       phase2<R, NRM, LPE, MS>(c, lane, R(1));
       TS_STAMP(c);
       phase3<R, EXPJ, LPE>(c, lane, R(1), R(0));       // c.H = h^2 dr/dq
-    } else TS_STAMP(c);
-    TS_STAMP(c);
-    const R ym = mass_times_z<LPE>(c, lane);
+      TS_STAMP(c);
+      ym = mass_times_z<LPE>(c, lane);
+      if (lane < nr) for (int i = 0; i < nr; ++i) yq += c.z[i] * c.H[i * nr + lane];
+    } else {
+      TS_STAMP(c);
+      evaluate_static_fused_adjoint<R, NRM, LPE, MS>(c, lane, yq, ym);
+      TS_STAMP(c);
+    }
     TS_STAMP(c);
     if (lane < nr) {
-      R yq = R(0);
-      for (int i = 0; i < nr; ++i) yq += c.z[i] * c.H[i * nr + lane];
       if (!bdf2) {                                    // BDF1: new state from (q0, qd0) only
         c.lamq[lane] = c.lamq[lane] - yq + lq1;       // lq1, lv1: what a later BDF2 step put on this sub-step's (q0, qd0) as ITS (q_1, qd_1)
         c.lamv[lane] = c.h * ym + lv1;

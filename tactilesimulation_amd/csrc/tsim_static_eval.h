@@ -130,8 +130,9 @@ __device__ __forceinline__ R ts_fused_joint_space(const Ctx<R>& c, R sq, R sv, R
 }
 
 // dof JJ of link LINK in the leaf -> root pass: tau_j = W_j . F, its tangent (column k of H, lane k), the joint-space forces
-template <class R, class MS, int LINK, int JJ>
-__device__ __forceinline__ void ts_fused_dof(const Ctx<R>& c, int k, R sq, R sv, R h2, R mv, const S6<R>& Wj, const S6<R>& Wk, const S6<R>& F, const S6<R>& dF) {
+// ADJ: the adjoint kernel's use — nothing is stored; lane k accumulates yq_k = sum_j z_j H[j][k] over its column as it is produced
+template <class R, class MS, int LINK, int JJ, bool ADJ>
+__device__ __forceinline__ void ts_fused_dof(const Ctx<R>& c, int k, R sq, R sv, R h2, R mv, const S6<R>& Wj, const S6<R>& Wk, const S6<R>& F, const S6<R>& dF, const R* zr, R& yq) {
   using T = TsTopo<MS>;
   constexpr int k0 = T::li(LINK, TSIM_LI_DOF0), ndj = T::li(LINK, TSIM_LI_NDOF), nr = T::NR;
   if constexpr (JJ < ndj) {
@@ -139,16 +140,20 @@ __device__ __forceinline__ void ts_fused_dof(const Ctx<R>& c, int k, R sq, R sv,
     const R dtau = dot6(Wj, dF) + mv * dot6(crm(Wk, Wj), F);
     R gj = dot6(Wj, F);
     const R hjj = ts_fused_joint_space<R, MS, j>(c, sq, sv, gj);      // damping, limits, motors of this dof
-    if (k < nr) c.H[j * nr + k] = dtau * h2 + (k == j ? hjj : R(0)) * h2;      // columns are stored scaled by 1 / ca (g = r / ca)
-    if (k == 0) c.g[j] = gj * h2;
+    const R Hjk = dtau * h2 + (k == j ? hjj : R(0)) * h2;      // columns are scaled by 1 / ca (g = r / ca)
+    if constexpr (ADJ) yq += zr[j] * Hjk;
+    else {
+      if (k < nr) c.H[j * nr + k] = Hjk;
+      if (k == 0) c.g[j] = gj * h2;
+    }
   }
 }
 
 // leaf -> root over the lane's accumulators: tau_j = W_j . F_subtree(link(j)), column k of H, the value g (lane 0), a link's subtree
 // wrench into its parent's — links of level LEVEL, then the levels above.  The joint-space forces (damping, limits, motors: constants of the
 // dof) go in right here: every lane has the value g_j, lane j adds its diagonal entry
-template <class R, class MS, int LEVEL, int LINK>
-__device__ __forceinline__ void ts_fused_up_links(const Ctx<R>& c, int lane, R sq, R sv, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
+template <class R, class MS, bool ADJ, int LEVEL, int LINK>
+__device__ __forceinline__ void ts_fused_up_links(const Ctx<R>& c, int lane, R sq, R sv, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl, const R* zr, R& yq) {
   using T = TsTopo<MS>;
   if constexpr (LINK <= T::NL) {
     if constexpr (TsLevels<MS>::depth(LINK) == LEVEL) {
@@ -157,19 +162,19 @@ __device__ __forceinline__ void ts_fused_up_links(const Ctx<R>& c, int lane, R s
       const S6<R> F = Fl[i], dF = dFl[i];
       const S6<R> Wj[3] = {tmp[i].Wj0, tmp[i].Wj1, tmp[i].Wj2};
       const R mv = ((ancm >> k) & 1) ? sq : R(0);          // does dof k move link i (its own joint's dofs included)
-      ts_fused_dof<R, MS, LINK, 0>(c, k, sq, sv, h2, mv, Wj[0], Wk, F, dF);
-      ts_fused_dof<R, MS, LINK, 1>(c, k, sq, sv, h2, mv, Wj[1], Wk, F, dF);
-      ts_fused_dof<R, MS, LINK, 2>(c, k, sq, sv, h2, mv, Wj[2], Wk, F, dF);
+      ts_fused_dof<R, MS, LINK, 0, ADJ>(c, k, sq, sv, h2, mv, Wj[0], Wk, F, dF, zr, yq);
+      ts_fused_dof<R, MS, LINK, 1, ADJ>(c, k, sq, sv, h2, mv, Wj[1], Wk, F, dF, zr, yq);
+      ts_fused_dof<R, MS, LINK, 2, ADJ>(c, k, sq, sv, h2, mv, Wj[2], Wk, F, dF, zr, yq);
       if constexpr (par != 0) { Fl[par] = Fl[par] + F; dFl[par] = dFl[par] + dF; }
     }
-    ts_fused_up_links<R, MS, LEVEL, LINK + 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);
+    ts_fused_up_links<R, MS, ADJ, LEVEL, LINK + 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl, zr, yq);
   }
 }
-template <class R, class MS, int LEVEL>
-__device__ __forceinline__ void ts_fused_up(const Ctx<R>& c, int lane, R sq, R sv, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
+template <class R, class MS, bool ADJ, int LEVEL>
+__device__ __forceinline__ void ts_fused_up(const Ctx<R>& c, int lane, R sq, R sv, R h2, const TsLinkTmp<R>* tmp, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl, const R* zr, R& yq) {
   if constexpr (LEVEL >= 0) {
-    ts_fused_up_links<R, MS, LEVEL, 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);
-    ts_fused_up<R, MS, LEVEL - 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);
+    ts_fused_up_links<R, MS, ADJ, LEVEL, 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl, zr, yq);
+    ts_fused_up<R, MS, ADJ, LEVEL - 1>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl, zr, yq);
   }
 }
 template <class R, class MS, int LINK>
@@ -199,9 +204,93 @@ __device__ __forceinline__ void evaluate_static_fused(const Ctx<R>& c, int lane,
   ts_fused_pair<R, NRM, LPE, MS, 0>(c, lane, sq, st, Wk, Fl, dFl);
   TS_STAMP(c);
   const R h2 = R(1) / c.ca;      // g = r / ca  (BDF1: h^2 r)
-  ts_fused_up<R, MS, TsLevels<MS>::max_depth()>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl);      // ... with the joint-space forces of each dof
+  R yq_unused = R(0);
+  ts_fused_up<R, MS, false, TsLevels<MS>::max_depth()>(c, lane, sq, sv, h2, tmp, Wk, Fl, dFl, nullptr, yq_unused);      // ... with the joint-space forces of each dof
   TS_SYNC();
   TS_STAMP2(c);
+}
+
+// (M z)_j = sum_i J_i^T I_i J_i z in registers (the generic kernels' mass_times_z goes through LDS twice): root -> leaf the motion
+// A_i = sum over the dofs above link i of W_k z_k and the link's f_i = I_i A_i; leaf -> root the subtree sums and tau_j = W_j . f_subtree(link(j))
+template <class R, class MS, int LEVEL, int LINK>
+__device__ __forceinline__ void ts_mz_down_links(const TsLinkTmp<R>* tmp, const R* zr, S6<R>* A, S6<R>* f) {
+  using T = TsTopo<MS>;
+  if constexpr (LINK <= T::NL) {
+    if constexpr (TsLevels<MS>::depth(LINK) == LEVEL) {
+      constexpr int i = LINK, par = T::li(i, TSIM_LI_PARENT), k0 = T::li(i, TSIM_LI_DOF0), ndj = T::li(i, TSIM_LI_NDOF);
+      S6<R> Ai = zero6<R>();
+      if constexpr (par != 0) Ai = A[par];
+      if constexpr (ndj > 0) Ai = Ai + tmp[i].Wj0 * zr[k0];
+      if constexpr (ndj > 1) Ai = Ai + tmp[i].Wj1 * zr[k0 + 1];
+      if constexpr (ndj > 2) Ai = Ai + tmp[i].Wj2 * zr[k0 + 2];
+      A[i] = Ai;
+      f[i] = imul((R)T::lf(i, TSIM_LF_MASS), tmp[i].cw, tmp[i].Ic, Ai);
+    }
+    ts_mz_down_links<R, MS, LEVEL, LINK + 1>(tmp, zr, A, f);
+  }
+}
+template <class R, class MS, int LEVEL>
+__device__ __forceinline__ void ts_mz_down(const TsLinkTmp<R>* tmp, const R* zr, S6<R>* A, S6<R>* f) {
+  if constexpr (LEVEL <= TsLevels<MS>::max_depth()) { ts_mz_down_links<R, MS, LEVEL, 1>(tmp, zr, A, f); ts_mz_down<R, MS, LEVEL + 1>(tmp, zr, A, f); }
+}
+template <class R, class MS, int LEVEL, int LINK>
+__device__ __forceinline__ void ts_mz_up_links(int lane, const TsLinkTmp<R>* tmp, S6<R>* f, R& ym) {
+  using T = TsTopo<MS>;
+  if constexpr (LINK <= T::NL) {
+    if constexpr (TsLevels<MS>::depth(LINK) == LEVEL) {
+      constexpr int i = LINK, par = T::li(i, TSIM_LI_PARENT), k0 = T::li(i, TSIM_LI_DOF0), ndj = T::li(i, TSIM_LI_NDOF);
+      if constexpr (ndj > 0) { const R t_ = dot6(tmp[i].Wj0, f[i]); ym = lane == k0 ? t_ : ym; }
+      if constexpr (ndj > 1) { const R t_ = dot6(tmp[i].Wj1, f[i]); ym = lane == k0 + 1 ? t_ : ym; }
+      if constexpr (ndj > 2) { const R t_ = dot6(tmp[i].Wj2, f[i]); ym = lane == k0 + 2 ? t_ : ym; }
+      if constexpr (par != 0) f[par] = f[par] + f[i];
+    }
+    ts_mz_up_links<R, MS, LEVEL, LINK + 1>(lane, tmp, f, ym);
+  }
+}
+template <class R, class MS, int LEVEL>
+__device__ __forceinline__ void ts_mz_up(int lane, const TsLinkTmp<R>* tmp, S6<R>* f, R& ym) {
+  if constexpr (LEVEL >= 0) { ts_mz_up_links<R, MS, LEVEL, 1>(lane, tmp, f, ym); ts_mz_up<R, MS, LEVEL - 1>(lane, tmp, f, ym); }
+}
+
+// The adjoint kernel's evaluation at a taped state (seeds (1, 0, 0): H = dr/dq / ca) with c.z known: nothing is stored — lane k returns
+//   yq = (H^T z)_k  and  ym = (M z)_k ,  which is all the kernel uses of it.
+template <class R, int NRM, int LPE, class MS>
+__device__ __forceinline__ void evaluate_static_fused_adjoint(const Ctx<R>& c, int lane, R& yq, R& ym) {
+  using T = TsTopo<MS>;
+  TS_SYNC();
+  TsLinkState<R> st[T::NL + 1];
+  TsLinkTmp<R> tmp[T::NL + 1];
+  S6<R> Wk = zero6<R>(), dFl[T::NL + 1], Fl[T::NL + 1];
+  ts_l_level<R, MS, true, false, 0, 0>(c, lane, R(1), R(0), R(0), st, tmp, Wk, dFl);
+  ts_fused_link_wrenches<R, MS, 1>(st, tmp, Fl);
+  TS_STAMP(c);
+  ts_fused_pair<R, NRM, LPE, MS, 0>(c, lane, R(1), st, Wk, Fl, dFl);
+  TS_STAMP(c);
+  R zr[T::NR];
+#pragma unroll
+  for (int j = 0; j < T::NR; ++j) zr[j] = c.z[j];
+  const R h2 = R(1) / c.ca;
+  yq = R(0);
+  ts_fused_up<R, MS, true, TsLevels<MS>::max_depth()>(c, lane, R(1), R(0), h2, tmp, Wk, Fl, dFl, zr, yq);
+  TS_STAMP(c);
+  S6<R> A[T::NL + 1], f[T::NL + 1];
+  ym = R(0);
+  ts_mz_down<R, MS, 0>(tmp, zr, A, f);
+  ts_mz_up<R, MS, TsLevels<MS>::max_depth()>(lane, tmp, f, ym);
+  TS_SYNC();
+}
+
+// the link value records, joint screws and twist tangents (seeds (1, 0, 0)) of the state in c.q / c.qd / c.qa, for output_vjp — the adjoint
+// kernel calls this at the sub-steps that carry a loss seed only
+template <class R, class MS>
+__device__ __forceinline__ void ts_static_records_for_vjp(const Ctx<R>& c, int lane) {
+  using T = TsTopo<MS>;
+  TS_SYNC();
+  TsLinkState<R> st[T::NL + 1];
+  TsLinkTmp<R> tmp[T::NL + 1];
+  S6<R> Wk = zero6<R>(), dFl[T::NL + 1];
+  ts_l_level<R, MS, true, false, 1, 0>(c, lane, R(1), R(0), R(0), st, tmp, Wk, dFl);
+  TS_SYNC();
 }
 
 // the link value records and joint screws of the state in c.q / c.qd / c.qa (the last evaluation's), for the code that reads them from LDS:
