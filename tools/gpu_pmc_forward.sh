@@ -3,12 +3,12 @@ cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
 i=0
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_IFETCH SQ_WAIT_IFETCH SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_fwd_$i -o pmc -- python bench.py --steps 20 --warmup 20 --no-cpu-baseline --timed-only --no-pmc > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_fwd_$i -o pmc -- python bench.py --steps 20 --warmup 20 --no-cpu-baseline --timed-only --no-pmc > /dev/null 2>&1
 done
 python - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_fwd_*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("/tmp/pmc_fwd_*/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
