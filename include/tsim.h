@@ -170,7 +170,8 @@ int tsim_launch_info(const tsim_batch* b, int32_t* out);
 int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes effect with the next launch */
 /* Statically known models.  The library carries, next to the generic kernels, instantiations of the forward / adjoint kernels for models
  * whose compiled blob it was built with (csrc/tsim_static.h; round 4: TactilePush, envs/assets/pusher/pusher.xml): tree, joint types, joint
- * frames and axes are compile-time constants there and the link sweep folds to what the model's structure leaves.  They are used when the
+ * frames and axes, contact pairs, dof records are compile-time constants there and the whole residual evaluation is one register-resident
+ * pass (csrc/tsim_static_eval.h).  They are used when the
  * batch's blob equals the compiled-in one bit for bit (checked at tsim_batch_create / tsim_update_model), the batch is fp32 and has no
  * per-environment tables; results equal the generic kernels' to fp32 rounding (tests/test_gpu_static_model.py).
  * tsim_static_model returns the id of the instantiation the NEXT launch will use (0: generic, 1: TactilePush); tsim_set_static(b, 0)

@@ -674,6 +674,14 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
 }
 
 #include "tsim_static_eval.h"
+// is the evaluation of model MS the fused register-resident pass?  (fp32 instantiations of a static model that asks for it)
+template <class MS, class R> constexpr bool ts_static_fused() {
+#ifdef TS_STATIC_UNFUSED
+  return false;
+#else
+  if constexpr (std::is_void<MS>::value) return false; else return MS::FUSED && sizeof(R) == 4;
+#endif
+}
 
 // full evaluation at the trial increment held in c.dl (with c.q0, c.qd0, c.u): fills c.q, c.qd, c.qa, link state, g, H.
 // The Newton unknown is the increment  dl = q1 - qp  over the force-free predictor qp (BDF1: q0 + h qd0; BDF2:
@@ -692,7 +700,7 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
   TS_SYNC();
   TS_STAMP(c);
 #ifndef TS_STATIC_UNFUSED      // (A/B: the static link sweep followed by the generic phases 2 / 3)
-  if constexpr (!std::is_void<MS>::value && sizeof(R) == 4) {
+  if constexpr (ts_static_fused<MS, R>()) {
     evaluate_static_fused<R, NRM, LPE, MS, false>(c, lane, sq, sv, sa);      // a statically known model: one register-resident pass (tsim_static_eval.h)
     TS_STAMP(c);
     return;

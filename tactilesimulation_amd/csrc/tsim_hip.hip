@@ -856,7 +856,7 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
   return 0;
 }
 int tsim_static_model(const tsim_batch* b) {
-  return (b->static_id == 1 && !b->no_static && b->dtype == TSIM_F32 && !b->dFenv) ? 1 : 0;
+  return (b->static_id != 0 && !b->no_static && b->dtype == TSIM_F32 && !b->dFenv) ? b->static_id : 0;
 }
 int tsim_set_static(tsim_batch* b, int allow) { b->no_static = allow ? 0 : 1; return 0; }
 int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {

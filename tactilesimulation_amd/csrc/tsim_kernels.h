@@ -329,10 +329,8 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     // ---- end of a frame (per slot in a free-running launch, all slots together otherwise): the link poses / velocities in LDS are
     //      those of the accepted state (last evaluation)
     if (TS_UNLIKELY(__any(frame_end))) {       // once per frame and slot: kept out of the loop's straight-line code
-#ifndef TS_STATIC_UNFUSED
       // the fused static evaluation leaves no link records in LDS: write those of the frame's final state now (what the read-out reads)
-      if constexpr (!std::is_void<MS>::value && sizeof(R) == 4) { if (frame_end) ts_static_value_records<R, MS>(c, lane); }
-#endif
+      if constexpr (ts_static_fused<MS, R>()) { if (frame_end) ts_static_value_records<R, MS>(c, lane); }
       if (frame_end && lane < nr && valid) {
         const size_t o = ((size_t)f * a.B + env) * nr + lane;
         if (a.q_out) a.q_out[o] = (R)c.q0D[lane];        // the double position rounded once (== tsim_get_state)
@@ -363,9 +361,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       TS_SYNC();
     }
   }
-#ifndef TS_STATIC_UNFUSED
-  if constexpr (!std::is_void<MS>::value && sizeof(R) == 4) { if (a.poseR && a.nframes <= 0) ts_static_value_records<R, MS>(c, lane); }
-#endif
+  if constexpr (ts_static_fused<MS, R>()) { if (a.poseR && a.nframes <= 0) ts_static_value_records<R, MS>(c, lane); }
   if (a.poseR) {
     // Large pads are read out on demand (tsim_readout), by a kernel whose lanes are taxels and which needs, per (sensor, primitive)
     // combination, the pose of the sensor link in the primitive's frame and the relative twist there.  The link records in LDS are those
@@ -622,11 +618,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     // A statically known model (tsim_static_eval.h): the evaluation at the taped state is one register-resident pass AFTER the adjoint solve
     // and returns this lane's (H^T z, M z) — no records, no c.H.  Only a sub-step that carries a loss seed needs link records in LDS
     // (output_vjp reads them): it runs the link sweep alone first.
-#ifdef TS_STATIC_UNFUSED
-    constexpr bool kFused = false;
-#else
-    constexpr bool kFused = !std::is_void<MS>::value && sizeof(R) == 4;
-#endif
+    constexpr bool kFused = ts_static_fused<MS, R>();
     const bool seeded = (j + 1) % a.seed_stride == 0;
     if constexpr (kFused) { if (seeded) ts_static_records_for_vjp<R, MS>(c, lane); }
     else if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
