@@ -443,6 +443,61 @@ __device__ __forceinline__ R mass_times_z(const Ctx<R>& c, int lane) {
   return tau;
 }
 
+// The taxel loop of the tactile adjoint: lanes = taxels t0 .. t0 + nt of one sensor against one primitive whose staged pose is P; every lane
+// accumulates in g the gradient of  w . out  w.r.t. the pair's relative displacement (dth, drho) and relative twist (dw, dv), primitive frame.
+// Returns whether any lane of the wavefront had a loaded, seeded taxel.  PRIMC >= 0: the primitive type as a constant (static models), with
+// an fp32 "certainly outside" test in front of the double-precision position.  shape / sf: the primitive's shape and the sensor's penalty record.
+template <int LPE, class R, int PRIMC = -1>
+__device__ __forceinline__ bool vjp_taxels(const Ctx<R>& c, int lane, int t0, int nt, int prim, const R* shape, const R* sf, const PairPose<R>& P, const R* wtac, R (&g)[12]) {
+  const M3<R> RPA = P.RPA;
+  const V3<R> pPA = P.pPA, wrel = P.wrel, vrel = P.vrel;
+#pragma unroll
+  for (int e = 0; e < 12; ++e) g[e] = R(0);
+  bool any_live = false;
+  // the seed and the position of a chunk's taxels are fetched one chunk ahead: a lone wavefront cannot hide the two dependent
+  // global-memory latencies per chunk (seed -> live? -> position) otherwise
+  R nw0 = R(0), nw1 = R(0), nw2 = R(0), nx0 = R(0), nx1 = R(0), nx2 = R(0);
+  if (lane < nt) {
+    const int t = t0 + lane; const R* tp = c.Fg + c.foff_tax + t;
+    nw0 = wtac[3 * t]; nw1 = wtac[3 * t + 1]; nw2 = wtac[3 * t + 2]; nx0 = tp[0]; nx1 = tp[c.ntax]; nx2 = tp[2 * c.ntax];
+  }
+  for (int base = 0; base < nt; base += LPE) {
+    const bool valid = base + lane < nt;
+    const int t = t0 + (valid ? base + lane : 0);
+    const R* tp = c.Fg + c.foff_tax + t;
+    const R w0 = valid ? nw0 : R(0), w1 = valid ? nw1 : R(0), w2 = valid ? nw2 : R(0);
+    const R x0 = nx0, x1 = nx1, x2 = nx2;
+    if (base + LPE + lane < nt) {
+      const int tn = t0 + base + LPE + lane; const R* tq = c.Fg + c.foff_tax + tn;
+      nw0 = wtac[3 * tn]; nw1 = wtac[3 * tn + 1]; nw2 = wtac[3 * tn + 2]; nx0 = tq[0]; nx1 = tq[c.ntax]; nx2 = tq[2 * c.ntax];
+    }
+    bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
+    if (PRIMC >= 0 && sizeof(R) == 4 && live) live = prim_distance<R>(prim, shape, mulMv(RPA, mk3<R>(x0, x1, x2)) + pPA) < R(TS_FAR_MARGIN);
+    V3<R> xP, F; M3<R> Jx, Jv;
+    if (live) {
+      const V3<double> xPd = mulMv(P.RPAd, mk3<double>((double)x0, (double)x1, (double)x2)) + P.pPAd;
+      xP = cvt3<R>(xPd);
+      live = contact_law<R, true>(prim, shape, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
+    }
+    if (!__any(live)) continue;
+    any_live = true;
+    if (live) {
+      // weight in the sensor-link frame, then in the primitive frame:  s = wP . F
+      const V3<R> wl = mk3<R>(w0 * tp[3 * c.ntax] + w1 * tp[6 * c.ntax] + w2 * tp[9 * c.ntax],
+                              w0 * tp[4 * c.ntax] + w1 * tp[7 * c.ntax] + w2 * tp[10 * c.ntax],
+                              w0 * tp[5 * c.ntax] + w1 * tp[8 * c.ntax] + w2 * tp[11 * c.ntax]);
+      const V3<R> wP = mulMv(RPA, wl);
+      const V3<R> gv = mulMtv(Jv, wP);
+      const V3<R> gx = mulMtv(Jx, wP) + cross3(gv, wrel);       // d s / d(point displacement)
+      const V3<R> ath = cross3(xP, gx) + cross3(wP, F);         // d s / d(relative rotation)
+      const V3<R> bw = cross3(xP, gv);                           // d s / d(relative angular velocity)
+      g[0] += ath.x; g[1] += ath.y; g[2] += ath.z; g[3] += gx.x; g[4] += gx.y; g[5] += gx.z;
+      g[6] += bw.x; g[7] += bw.y; g[8] += bw.z; g[9] += gv.x; g[10] += gv.y; g[11] += gv.z;
+    }
+  }
+  return any_live;
+}
+
 // lam_q += (dvar/dq)^T w_var + (dtac/dq)^T w_tac ; lam_v += (dtac/dqd)^T w_tac, at the state whose link values and
 // q-tangents (seeds (1,0,0)) are in LDS.  Tactile: reverse mode at the taxel level — each lane forms the gradient of
 // w . out w.r.t. the pair's relative displacement and relative twist (12 numbers, primitive frame); one reduction
@@ -476,55 +531,13 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
       pair_stage_value(c, pk, 0, lane == 0);
       TS_SYNC();
       const R* S = c.PP;
-      const M3<R> RPA = ldm(S + PP_RPA);
-      const V3<R> pPA = ldv(S + PP_PPA), wrel = ldv(S + PP_WREL), vrel = ldv(S + PP_VREL);
+      PairPose<R> P;
+      P.RPAd = ldm(c.PPd); P.pPAd = ldv(c.PPd + 9);
+      P.RPA = ldm(S + PP_RPA); P.pPA = ldv(S + PP_PPA); P.wrel = ldv(S + PP_WREL); P.vrel = ldv(S + PP_VREL);
       R g[12];
-#pragma unroll
-      for (int e = 0; e < 12; ++e) g[e] = R(0);
-      bool any_live = false;
-      // the seed and the position of a chunk's taxels are fetched one chunk ahead: a lone wavefront cannot hide the two dependent
-      // global-memory latencies per chunk (seed -> live? -> position) otherwise
-      R nw0 = R(0), nw1 = R(0), nw2 = R(0), nx0 = R(0), nx1 = R(0), nx2 = R(0);
-      if (lane < nt) {
-        const int t = t0 + lane; const R* tp = c.Fg + c.foff_tax + t;
-        nw0 = wtac[3 * t]; nw1 = wtac[3 * t + 1]; nw2 = wtac[3 * t + 2]; nx0 = tp[0]; nx1 = tp[c.ntax]; nx2 = tp[2 * c.ntax];
-      }
-      for (int base = 0; base < nt; base += LPE) {
-        const bool valid = base + lane < nt;
-        const int t = t0 + (valid ? base + lane : 0);
-        const R* tp = c.Fg + c.foff_tax + t;
-        const R w0 = valid ? nw0 : R(0), w1 = valid ? nw1 : R(0), w2 = valid ? nw2 : R(0);
-        const R x0 = nx0, x1 = nx1, x2 = nx2;
-        if (base + LPE + lane < nt) {
-          const int tn = t0 + base + LPE + lane; const R* tq = c.Fg + c.foff_tax + tn;
-          nw0 = wtac[3 * tn]; nw1 = wtac[3 * tn + 1]; nw2 = wtac[3 * tn + 2]; nx0 = tq[0]; nx1 = tq[c.ntax]; nx2 = tq[2 * c.ntax];
-        }
-        bool live = valid && (w0 != R(0) || w1 != R(0) || w2 != R(0));
-        V3<R> xP, F; M3<R> Jx, Jv;
-        if (live) {
-          const V3<double> xPd = mulMv(ldm(c.PPd), mk3<double>((double)x0, (double)x1, (double)x2)) + ldv(c.PPd + 9);
-          xP = cvt3<R>(xPd);
-          live = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, sf, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
-        }
-        if (!__any(live)) continue;
-        any_live = true;
-        if (live) {
-          // weight in the sensor-link frame, then in the primitive frame:  s = wP . F
-          const V3<R> wl = mk3<R>(w0 * tp[3 * c.ntax] + w1 * tp[6 * c.ntax] + w2 * tp[9 * c.ntax],
-                                  w0 * tp[4 * c.ntax] + w1 * tp[7 * c.ntax] + w2 * tp[10 * c.ntax],
-                                  w0 * tp[5 * c.ntax] + w1 * tp[8 * c.ntax] + w2 * tp[11 * c.ntax]);
-          const V3<R> wP = mulMv(RPA, wl);
-          const V3<R> gv = mulMtv(Jv, wP);
-          const V3<R> gx = mulMtv(Jx, wP) + cross3(gv, wrel);       // d s / d(point displacement)
-          const V3<R> ath = cross3(xP, gx) + cross3(wP, F);         // d s / d(relative rotation)
-          const V3<R> bw = cross3(xP, gv);                           // d s / d(relative angular velocity)
-          g[0] += ath.x; g[1] += ath.y; g[2] += ath.z; g[3] += gx.x; g[4] += gx.y; g[5] += gx.z;
-          g[6] += bw.x; g[7] += bw.y; g[8] += bw.z; g[9] += gv.x; g[10] += gv.y; g[11] += gv.z;
-        }
-      }
+      const bool any_live = vjp_taxels<LPE, R>(c, lane, t0, nt, prim, pf + TSIM_PF_SHAPE, sf, P, wtac, g);
       if (!any_live) continue;
-#pragma unroll
-      for (int e = 0; e < 12; ++e) g[e] = seg_sum<LPE>(g[e]);
+      seg_sum_many<LPE, 12>(g);
       // lanes = directions
       pair_stage_tangent(c, pk, 0, lane, R(1), 0);
       if (lane < nr) {
@@ -620,7 +633,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     // (output_vjp reads them): it runs the link sweep alone first.
     constexpr bool kFused = ts_static_fused<MS, R>();
     const bool seeded = (j + 1) % a.seed_stride == 0;
-    if constexpr (kFused) { if (seeded) ts_static_records_for_vjp<R, MS>(c, lane); }
+    if constexpr (kFused) { }      // (a seeded sub-step runs its own link sweep inside ts_static_output_vjp)
     else if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
 #ifdef TS_STATIC_BRANCH_BLOCKS
     else phase1_static<R, MS, true>(c, lane, R(1), R(0), R(0));
@@ -639,7 +652,8 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
       TS_SYNC();
       const R* wtac_ = (a.df_dtac && ntac3 && tslot >= 0) ? a.df_dtac + sot * ntac3 : nullptr;
       if (POLICY) wtac_ = (pol_have && a.pol.mode == TSIM_PUSH_OBS_TACTILE) ? a.pol.dobs_tac + ((size_t)(fr + 1) * a.B + env) * PP_NTAC : nullptr;   // tactile part (frame fr + 1's observation)
-      output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, wtac_);
+      if constexpr (kFused) ts_static_output_vjp<R, LPE, MS>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, wtac_);
+      else output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, wtac_);
     }
     TS_STAMP(c);
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.cv * c.lamv[lane];      // d qd1 / d q1 = cv
@@ -708,6 +722,77 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   }
 }
 
+
+// ---- output_vjp for a statically known model with the fused evaluation (tsim_static_eval.h): the link sweep's states stay in registers, so
+// the pose of each (sensor, primitive) combination, this lane's 12-vector of it and the end-effector Jacobians need no record in LDS;
+// primitive type, shape and the sensor's penalty record are constants.  Adds to lam_q / lam_v exactly what output_vjp adds.
+template <class R, int LPE, class MS, int SN, int J>
+__device__ __forceinline__ void ts_vjp_sprim(const Ctx<R>& c, int lane, const TsLinkState<R>* st, const S6<R>& Wk, const R* wtac, R& dlq, R& dlv) {
+  using T = TsTopo<MS>;
+  constexpr int so = MS::Iv(TSIM_IH_OFF_SENSOR) + SN * TSIM_SI_SIZE, nsp = MS::Iv(so + TSIM_SI_NSPRIM);
+  if constexpr (J < nsp) {
+    constexpr int pk = MS::Iv(MS::Iv(TSIM_IH_OFF_SPRIM) + MS::Iv(so + TSIM_SI_SPRIM0) + J);
+    constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + pk * TSIM_PI_SIZE, prim = MS::Iv(o + TSIM_PI_PRIM), la = MS::Iv(o + TSIM_PI_LINKA), lb = MS::Iv(o + TSIM_PI_LINKB);
+    constexpr int t0 = MS::Iv(so + TSIM_SI_TAX0), nt = MS::Iv(so + TSIM_SI_NTAX);
+    R pf[TSIM_PF_SIZE], sf[TSIM_SF_SIZE];
+#pragma unroll
+    for (int e = 0; e < TSIM_SF_SIZE; ++e) sf[e] = (R)MS::Fv(MS::Iv(TSIM_IH_FOFF_SENSOR) + SN * TSIM_SF_SIZE + e);
+    M3<R> RP; V3<R> pP; PairPose<R> P; S6<R> Vrel, dVA, dVB;
+    ts_fused_pair_pose<R, MS, pk>(st, pf, RP, pP, P, Vrel, dVA, dVB);
+    R g[12];
+    const bool any_live = vjp_taxels<LPE, R, prim>(c, lane, t0, nt, prim, pf + TSIM_PF_SHAPE, sf, P, wtac, g);
+    if (any_live) {
+      seg_sum_many<LPE, 12>(g);
+      // lanes = directions: this lane's 12-vector of the pair (pair_stage_tangent, vmode 0) and its twist column alone (vmode 1)
+      const int k = lane;
+      constexpr int ancA = la != 0 ? T::li(la == 0 ? 1 : la, TSIM_LI_ANCMASK) : 0, ancB = lb != 0 ? T::li(lb == 0 ? 1 : lb, TSIM_LI_ANCMASK) : 0;
+      const R inA = ((ancA >> k) & 1) ? R(1) : R(0), inB = ((ancB >> k) & 1) ? R(1) : R(0);
+      const S6<R> dxiP = to_frame(RP, pP, Wk * (inA - inB));
+      const S6<R> dxiB = to_frame(RP, pP, Wk * inB);
+      const S6<R> dVrel = to_frame(RP, pP, dVA - dVB) - crm(dxiB, Vrel);
+      dlq += g[0] * dxiP.a.x + g[1] * dxiP.a.y + g[2] * dxiP.a.z + g[3] * dxiP.l.x + g[4] * dxiP.l.y + g[5] * dxiP.l.z
+           + g[6] * dVrel.a.x + g[7] * dVrel.a.y + g[8] * dVrel.a.z + g[9] * dVrel.l.x + g[10] * dVrel.l.y + g[11] * dVrel.l.z;
+      dlv += g[6] * dxiP.a.x + g[7] * dxiP.a.y + g[8] * dxiP.a.z + g[9] * dxiP.l.x + g[10] * dxiP.l.y + g[11] * dxiP.l.z;      // d(relative twist) / d qd_k = the same frame change of W_k
+    }
+    ts_vjp_sprim<R, LPE, MS, SN, J + 1>(c, lane, st, Wk, wtac, dlq, dlv);
+  }
+}
+template <class R, int LPE, class MS, int SN>
+__device__ __forceinline__ void ts_vjp_sensors(const Ctx<R>& c, int lane, const TsLinkState<R>* st, const S6<R>& Wk, const R* wtac, R& dlq, R& dlv) {
+  if constexpr (SN < MS::Iv(TSIM_IH_NSENSOR)) {
+    ts_vjp_sprim<R, LPE, MS, SN, 0>(c, lane, st, Wk, wtac, dlq, dlv);
+    ts_vjp_sensors<R, LPE, MS, SN + 1>(c, lane, st, Wk, wtac, dlq, dlv);
+  }
+}
+template <class R, class MS, int E>
+__device__ __forceinline__ void ts_vjp_vars(int lane, const TsLinkTmp<R>* tmp, const S6<R>& Wk, const R* wvar, R& dlq) {
+  using T = TsTopo<MS>;
+  if constexpr (E < MS::Iv(TSIM_IH_NVAR)) {
+    constexpr int l = MS::Iv(MS::Iv(TSIM_IH_OFF_VAR) + E * TSIM_VI_SIZE + TSIM_VI_LINK), fo = MS::Iv(TSIM_IH_FOFF_VAR) + E * TSIM_VF_SIZE;
+    if constexpr (l != 0) {
+      constexpr int anc = T::li(l == 0 ? 1 : l, TSIM_LI_ANCMASK);
+      const R mv = ((anc >> lane) & 1) ? R(1) : R(0);
+      const V3<R> x = mulMv(tmp[l].XR, mk3<R>((R)MS::Fv(fo), (R)MS::Fv(fo + 1), (R)MS::Fv(fo + 2))) + tmp[l].Xp;
+      const V3<R> Jv_ = cross3(Wk.a, x) + Wk.l;
+      dlq += mv * (wvar[3 * E] * Jv_.x + wvar[3 * E + 1] * Jv_.y + wvar[3 * E + 2] * Jv_.z);
+    }
+    ts_vjp_vars<R, MS, E + 1>(lane, tmp, Wk, wvar, dlq);
+  }
+}
+template <class R, int LPE, class MS>
+__device__ __forceinline__ void ts_static_output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac) {
+  using T = TsTopo<MS>;
+  TS_SYNC();
+  TsLinkState<R> st[T::NL + 1];
+  TsLinkTmp<R> tmp[T::NL + 1];
+  S6<R> Wk = zero6<R>(), dFl[T::NL + 1];
+  ts_l_level<R, MS, true, false, 0, 0>(c, lane, R(1), R(0), R(0), st, tmp, Wk, dFl);      // values + this lane's twist tangents (seeds (1, 0, 0)), nothing stored
+  R dlq = R(0), dlv = R(0);
+  if (wvar) ts_vjp_vars<R, MS, 0>(lane, tmp, Wk, wvar, dlq);
+  if (wtac) ts_vjp_sensors<R, LPE, MS, 0>(c, lane, st, Wk, wtac, dlq, dlv);
+  if (lane < T::NR) { c.lamq[lane] += dlq; c.lamv[lane] += dlv; }
+  TS_SYNC();
+}
 
 // ================================================================================================ debug evaluation
 template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; int stage_cpt; };

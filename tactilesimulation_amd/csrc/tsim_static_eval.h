@@ -18,39 +18,48 @@
 // An evaluation round of four environments (fine stamps, profiles/r04_static_model.md): 37.7 k -> see there.
 #pragma once
 
+// pose of link A of pair PK in the pair's primitive frame (pair_stage_value) from the link states in registers; link 0 is the world.  Also
+// returns the pair's float record as constants (rounded to R first: the device blob holds R), the primitive frame in the world (RP, pP), the
+// relative twist there and this lane's twist tangents of the two links
+template <class R, class MS, int PK>
+__device__ __forceinline__ void ts_fused_pair_pose(const TsLinkState<R>* st, R (&pf)[TSIM_PF_SIZE], M3<R>& RP, V3<R>& pP, PairPose<R>& P, S6<R>& Vrel, S6<R>& dVA, S6<R>& dVB) {
+  constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + PK * TSIM_PI_SIZE, fo = MS::Iv(TSIM_IH_FOFF_PAIR) + PK * TSIM_PF_SIZE;
+  constexpr int la = MS::Iv(o + TSIM_PI_LINKA), lb = MS::Iv(o + TSIM_PI_LINKB);
+#pragma unroll
+  for (int e = 0; e < TSIM_PF_SIZE; ++e) pf[e] = (R)MS::Fv(fo + e);
+  M3<double> Rprim; V3<double> pprim;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) Rprim.m[e] = (double)pf[TSIM_PF_R + e];
+  pprim = mk3<double>((double)pf[TSIM_PF_P], (double)pf[TSIM_PF_P + 1], (double)pf[TSIM_PF_P + 2]);
+  M3<double> RPd; V3<double> pPd;
+  if constexpr (lb == 0) { RPd = Rprim; pPd = pprim; }
+  else { RPd = mulMM(st[lb].Rd, Rprim); pPd = mulMv(st[lb].Rd, pprim) + st[lb].pd; }
+  if constexpr (la == 0) { P.RPAd = mulMtM(RPd, M3<double>{{1, 0, 0, 0, 1, 0, 0, 0, 1}}); P.pPAd = mulMtv(RPd, zero3<double>() - pPd); }
+  else { P.RPAd = mulMtM(RPd, st[la].Rd); P.pPAd = mulMtv(RPd, st[la].pd - pPd); }
+  RP = cvtm<R>(RPd);
+  pP = cvt3<R>(pPd);
+  S6<R> VA = zero6<R>(), VB = zero6<R>();
+  dVA = zero6<R>(); dVB = zero6<R>();
+  if constexpr (la != 0) { VA = st[la].V; dVA = st[la].dV; }
+  if constexpr (lb != 0) { VB = st[lb].V; dVB = st[lb].dV; }
+  Vrel = to_frame(RP, pP, VA - VB);
+  P.RPA = cvtm<R>(P.RPAd); P.pPA = cvt3<R>(P.pPAd); P.wrel = Vrel.a; P.vrel = Vrel.l;
+}
+
 // pair PK of the static model: pose, this lane's 12-vector, the point loop, the fold into the lane's per-link wrench accumulators
 template <class R, int NRM, int LPE, class MS, int PK>
 __device__ __forceinline__ void ts_fused_pair(const Ctx<R>& c, int lane, R sq, const TsLinkState<R>* st, const S6<R>& Wk, S6<R>* Fl, S6<R>* dFl) {
   using T = TsTopo<MS>;
   constexpr int NP = MS::Iv(TSIM_IH_NPAIR);
   if constexpr (PK < NP) {
-    constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + PK * TSIM_PI_SIZE, fo = MS::Iv(TSIM_IH_FOFF_PAIR) + PK * TSIM_PF_SIZE;
+    constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + PK * TSIM_PI_SIZE;
     constexpr int flags = MS::Iv(o + TSIM_PI_FLAGS), prim = MS::Iv(o + TSIM_PI_PRIM), npt = MS::Iv(o + TSIM_PI_NPT), pt0 = MS::Iv(o + TSIM_PI_PT0);
     constexpr int la = MS::Iv(o + TSIM_PI_LINKA), lb = MS::Iv(o + TSIM_PI_LINKB);
     if constexpr ((flags & 1) != 0) {
       const int k = lane;
-      // ---- the pair's float record as constants (rounded to R first: the device blob holds R)
       R pf[TSIM_PF_SIZE];
-#pragma unroll
-      for (int e = 0; e < TSIM_PF_SIZE; ++e) pf[e] = (R)MS::Fv(fo + e);
-      M3<double> Rprim; V3<double> pprim;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) Rprim.m[e] = (double)pf[TSIM_PF_R + e];
-      pprim = mk3<double>((double)pf[TSIM_PF_P], (double)pf[TSIM_PF_P + 1], (double)pf[TSIM_PF_P + 2]);
-      // ---- pose of A in the primitive's frame (pair_stage_value), from the link states in registers; link 0 is the world
-      M3<double> RPd; V3<double> pPd;
-      if constexpr (lb == 0) { RPd = Rprim; pPd = pprim; }
-      else { RPd = mulMM(st[lb].Rd, Rprim); pPd = mulMv(st[lb].Rd, pprim) + st[lb].pd; }
-      PairPose<R> P;
-      if constexpr (la == 0) { P.RPAd = mulMtM(RPd, M3<double>{{1, 0, 0, 0, 1, 0, 0, 0, 1}}); P.pPAd = mulMtv(RPd, zero3<double>() - pPd); }
-      else { P.RPAd = mulMtM(RPd, st[la].Rd); P.pPAd = mulMtv(RPd, st[la].pd - pPd); }
-      const M3<R> RP = cvtm<R>(RPd);
-      const V3<R> pP = cvt3<R>(pPd);
-      S6<R> VA = zero6<R>(), VB = zero6<R>(), dVA = zero6<R>(), dVB = zero6<R>();
-      if constexpr (la != 0) { VA = st[la].V; dVA = st[la].dV; }
-      if constexpr (lb != 0) { VB = st[lb].V; dVB = st[lb].dV; }
-      const S6<R> Vrel = to_frame(RP, pP, VA - VB);
-      P.RPA = cvtm<R>(P.RPAd); P.pPA = cvt3<R>(P.pPAd); P.wrel = Vrel.a; P.vrel = Vrel.l;
+      M3<R> RP; V3<R> pP; PairPose<R> P; S6<R> Vrel, dVA, dVB;
+      ts_fused_pair_pose<R, MS, PK>(st, pf, RP, pP, P, Vrel, dVA, dVB);
       // ---- this lane's direction (pair_stage_tangent, vmode 0): relative displacement and d(relative twist) in the primitive's frame
       constexpr int ancA = la != 0 ? T::li(la == 0 ? 1 : la, TSIM_LI_ANCMASK) : 0, ancB = lb != 0 ? T::li(lb == 0 ? 1 : lb, TSIM_LI_ANCMASK) : 0;
       const R inA = ((ancA >> k) & 1) ? R(1) : R(0), inB = ((ancB >> k) & 1) ? R(1) : R(0);
