@@ -13,9 +13,9 @@
 //   * the point loop (pair_points_matrix, the same code as the generic kernels') reduces to the 6 x 12 matrix in every lane; lane k
 //     applies it to ITS 12-vector, brings the wrench and its tangent to the world frame and adds them to its per-link accumulators;
 //   * the leaf -> root pass is a compile-time loop over the levels on those accumulators; the parents are constants.
-// What still goes to LDS is what something ELSE reads: the link value records (read-out, the adjoint kernel's output_vjp and
-// mass_times_z), the joint screws WP, the twist tangents DT_VW (output_vjp), and the result: g and H.
-// An evaluation round of four environments (fine stamps, profiles/r04_static_model.md): 37.7 k -> see there.
+// What still goes to LDS is the result — g and H in the forward kernel (the solve and the tape read them), nothing in the adjoint kernel
+// (it takes H^T z and M z back in registers) — and, once per frame, the link value records the read-out reads (ts_static_value_records).
+// An evaluation round of four environments (fine stamps, profiles/r04_static_model.md): 37.7 k -> 17.1 k cycles.
 #pragma once
 
 // pose of link A of pair PK in the pair's primitive frame (pair_stage_value) from the link states in registers; link 0 is the world.  Also
@@ -195,9 +195,10 @@ __device__ __forceinline__ void ts_fused_link_wrenches(const TsLinkState<R>* st,
 }
 
 // phases 1 - 3 of one evaluation (what evaluate() runs between setting q / qd / qa and returning g, H).  RECORDS: the link value records
-// (with the COM / inertia entries), the joint screws and the twist tangents are left in LDS — what the adjoint kernel reads after the
-// evaluation (output_vjp, mass_times_z).  The forward kernel asks for none: its read-out needs the value records of a frame's FINAL state
-// only, and writes them then (ts_static_value_records) — 105 LDS store instructions less in every evaluation round.
+// (with the COM / inertia entries), the joint screws and the twist tangents are left in LDS as well, for code that reads them there (A/B
+// only: the forward kernel's read-out needs the value records of a frame's FINAL state only and writes them then, ts_static_value_records —
+// 105 LDS store instructions less in every evaluation round; the adjoint kernel has its own pass, evaluate_static_fused_adjoint, and
+// ts_static_output_vjp for the seeded sub-steps: no records at all).
 template <class R, int NRM, int LPE, class MS, bool RECORDS>
 __device__ __forceinline__ void evaluate_static_fused(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
   using T = TsTopo<MS>;
@@ -286,19 +287,6 @@ __device__ __forceinline__ void evaluate_static_fused_adjoint(const Ctx<R>& c, i
   ym = R(0);
   ts_mz_down<R, MS, 0>(tmp, zr, A, f);
   ts_mz_up<R, MS, TsLevels<MS>::max_depth()>(lane, tmp, f, ym);
-  TS_SYNC();
-}
-
-// the link value records, joint screws and twist tangents (seeds (1, 0, 0)) of the state in c.q / c.qd / c.qa, for output_vjp — the adjoint
-// kernel calls this at the sub-steps that carry a loss seed only
-template <class R, class MS>
-__device__ __forceinline__ void ts_static_records_for_vjp(const Ctx<R>& c, int lane) {
-  using T = TsTopo<MS>;
-  TS_SYNC();
-  TsLinkState<R> st[T::NL + 1];
-  TsLinkTmp<R> tmp[T::NL + 1];
-  S6<R> Wk = zero6<R>(), dFl[T::NL + 1];
-  ts_l_level<R, MS, true, false, 1, 0>(c, lane, R(1), R(0), R(0), st, tmp, Wk, dFl);
   TS_SYNC();
 }
 
