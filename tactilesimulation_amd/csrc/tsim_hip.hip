@@ -519,9 +519,19 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
 // Does the batch's model equal a compiled-in static model (int blob and float records, bit for bit)?  Then its launches may use the
 // instantiation that has the model's structure folded in (tsim_static.h); any edit of a record (tsim_update_model) drops back to the
 // generic kernels, and so do per-environment tables.
+// Is the batch's model the compiled-in one in everything the static kernels take from it?  All int records and all float records in front of
+// the per-point arrays, bit for bit — EXCEPT the taxel layout (number of taxels, a sensor's taxel range and image shape): the static code reads
+// none of it (the read-out kernels and the tactile adjoint take taxels from the batch's own blob), so a TactilePush pad re-gridded to
+// 13 x 13 taxels (BASELINE configs[1]) runs on the same instantiation as the XML's 13 x 10.
 template <class MS> static bool blob_equals_static(const tsim_batch* b) {
   if ((int)b->I.size() != MS::NI || b->I[TSIM_IH_FOFF_CPT] != MS::NFREC) return false;
-  for (int i = 0; i < MS::NI; ++i) if (b->I[i] != MS::Iv(i)) return false;
+  auto taxel_layout = [&](int i) {
+    if (i == TSIM_IH_NTAXEL || i == TSIM_IH_NF || i == TSIM_IH_NDOF_TACTILE) return true;
+    const int os = MS::Iv(TSIM_IH_OFF_SENSOR), ns = MS::Iv(TSIM_IH_NSENSOR);
+    if (i >= os && i < os + ns * TSIM_SI_SIZE) { const int f = (i - os) % TSIM_SI_SIZE; return f == TSIM_SI_TAX0 || f == TSIM_SI_NTAX || f == TSIM_SI_ROWS || f == TSIM_SI_COLS; }
+    return false;
+  };
+  for (int i = 0; i < MS::NI; ++i) if (b->I[i] != MS::Iv(i) && !taxel_layout(i)) return false;
   for (int i = 0; i < MS::NFREC; ++i) if (std::memcmp(&b->F[i], (const double[]){MS::Fv(i)}, sizeof(double)) != 0) return false;
   return true;
 }

@@ -733,7 +733,7 @@ __device__ __forceinline__ void ts_vjp_sprim(const Ctx<R>& c, int lane, const Ts
   if constexpr (J < nsp) {
     constexpr int pk = MS::Iv(MS::Iv(TSIM_IH_OFF_SPRIM) + MS::Iv(so + TSIM_SI_SPRIM0) + J);
     constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + pk * TSIM_PI_SIZE, prim = MS::Iv(o + TSIM_PI_PRIM), la = MS::Iv(o + TSIM_PI_LINKA), lb = MS::Iv(o + TSIM_PI_LINKB);
-    constexpr int t0 = MS::Iv(so + TSIM_SI_TAX0), nt = MS::Iv(so + TSIM_SI_NTAX);
+    const int t0 = ts_u(c.I[c.off_sensor + SN * TSIM_SI_SIZE + TSIM_SI_TAX0]), nt = ts_u(c.I[c.off_sensor + SN * TSIM_SI_SIZE + TSIM_SI_NTAX]);      // the taxel layout is the batch's own (blob_equals_static)
     R pf[TSIM_PF_SIZE], sf[TSIM_SF_SIZE];
 #pragma unroll
     for (int e = 0; e < TSIM_SF_SIZE; ++e) sf[e] = (R)MS::Fv(MS::Iv(TSIM_IH_FOFF_SENSOR) + SN * TSIM_SF_SIZE + e);

@@ -96,6 +96,32 @@ def test_one_static_evaluation_against_the_generic_and_the_fp64_one(pusher_model
         g_static_median=float(np.median(ega)), g_generic_median=float(np.median(egb)), g_static_max=float(ega.max()), g_generic_max=float(egb.max()))
 
 
+def test_the_taxel_layout_is_not_part_of_the_static_model():
+    """BASELINE configs[1] words the TactilePush pad as 13 x 13 taxels (the XML has 13 x 10: workloads.synthetic_variant).  Taxels take no part
+    in the dynamics and the static kernels read none of the layout, so that model runs on the same instantiation — and agrees with the generic
+    kernels like the XML's own model does (forward, tactile frames of the re-gridded pad, episode gradient with tactile seeds)."""
+    from tactilesimulation_amd.workloads import synthetic_variant
+    m = synthetic_variant("pusher_13x13")
+    assert m.ndof_tactile == 3 * 169
+    B, T, S = 1024, 8, 5
+    q0, u, _ = push_workload(B, T, seed=6)
+    u[:, :, 0] = np.abs(u[:, :, 0])
+    g = torch.Generator().manual_seed(5)
+    wq, wv, wt = (torch.randn(T, B, n, generator=g).to(DEV) for n in (7, 6, 507))
+    a = BatchSim(m, B, dtype=torch.float32, tape_capacity=T * S)
+    b = BatchSim(m, B, dtype=torch.float32, tape_capacity=T * S)
+    b.set_static(False)
+    assert a.static_model() == 1 and b.static_model() == 0
+    ra, rb = _run(a, q0, u, T, S, wq, wv, wt), _run(b, q0, u, T, S, wq, wv, wt)
+    rel = lambda x, y: float((x - y).abs().max()) / max(float(y.abs().max()), 1e-30)
+    assert int(ra[0]["status"].abs().max()) == 0 and float(ra[0]["tactile"].abs().max()) > 0 and tuple(ra[0]["tactile"].shape) == (T, B, 507)
+    # (tactile forces are penalty stiffness x a penetration depth of ~1e-4 m: a position difference of 1e-6 between the two fp32 roundings shows
+    # as 1e-4 ... 2e-4 of the frame's largest force on a pad that is pressed on the box the whole episode)
+    assert float((ra[0]["q"] - rb[0]["q"]).abs().max()) < 5e-6 and rel(ra[0]["tactile"], rb[0]["tactile"]) < 5e-4
+    e = ((ra[2] - rb[2]).abs().amax((0, 2)) / rb[2].abs().amax((0, 2)).clamp_min(1e-30)).cpu().numpy()
+    assert np.median(e) < 1e-5 and (e < 1e-4).mean() > 0.99, (float(np.median(e)), float((e < 1e-4).mean()))
+
+
 def test_static_kernels_switch_off_for_other_blobs_shapes_and_tables(pusher_model):
     B = 4096
     sim = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=0)
