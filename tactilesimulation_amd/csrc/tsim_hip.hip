@@ -734,7 +734,10 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   if (emit) { a.poseR = (R*)b->poseR; a.poseD = b->poseD; }
   // The tactile frames of the launch: by k_taxels afterwards, from the pose records the launch leaves per frame — which is what lets the
   // slots of a wavefront run their frames independently (k_forward, main loop).  TSIM_INKERNEL_READOUT=1 / TSIM_NO_FREE_RUN=1: A/B.
-  bool defer = tac_out && taxels_supported(b) && !getenv("TSIM_INKERNEL_READOUT");
+  // (not when the per-frame pose records would take more than 1 GiB — 180-frame grasp episodes with 22 (sensor, primitive) combinations —: those
+  // launches keep the in-kernel read-out)
+  const size_t fpose_bytes = (size_t)nframes * b->B * (size_t)std::max(b->nspt, 1) * (TP_R_SIZE * b->esz + TP_D_SIZE * sizeof(double));
+  bool defer = tac_out && taxels_supported(b) && fpose_bytes <= ((size_t)1 << 30) && !getenv("TSIM_INKERNEL_READOUT");
   if (defer && b->fpose_frames < nframes) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) defer = false;      // no allocation inside a capture: the in-kernel read-out
