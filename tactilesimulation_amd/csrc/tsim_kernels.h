@@ -402,6 +402,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
 
 
 // ================================================================================================ backward kernel
+template <class R, int LPE, class MS> __device__ __forceinline__ void ts_static_output_vjp(const Ctx<R>& c, int lane, const R* wvar, const R* wtac);      // below
 template <class R> struct BwdArgs {
   const int* I; const R* F; const R* Fenv; int fstride;
   int B, n, t_end;
