@@ -1,3 +1,12 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_static_model.py tests/test_gpu_configs.py tests/test_gpu_edge_cases.py -m gpu -q 2>&1 | tail -3
-python tools/sub_record_ab.py push_fwd 2>/dev/null | grep '^{' | cut -c1-200
+for tag in base o2; do
+  if [ "$tag" = base ]; then unset TSIM_HIP_LIB; else export TSIM_HIP_LIB=$PWD/tactilesimulation_amd/csrc/ab/libtsim_$tag.so; fi
+  python tools/sub_record_ab.py dclaw insertion 2>/dev/null | grep '^{' | sed "s/^/$tag /" | cut -c1-110
+  python - <<'PY'
+import sys, torch
+sys.path.insert(0, '.')
+import bench
+r = bench.sub_record("push", "f64", torch.device("cuda:0"), steps=20, warm=5)
+print("f64", round(r["value"]), round(r["ms_per_step"], 4))
+PY
+done
