@@ -56,7 +56,9 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-ve
 # -O2 for the static unit: its kernels are small (42 KB at -Os, 59 KB at -O2: both inside the 64 KB instruction cache) and -O2's scheduling
 # is worth 4 % there (k_forward 3.30 -> 3.17 ms, k_backward 0.91 -> 0.87 ms per 20-step launch); the generic unit keeps -Os (its NRM = 16
 # kernels are 63 KB already; at -O2: D'Claw -5 %, TactileInsertion -2 %, fp64 -2 %).
-HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),
+# -amdgpu-sched-strategy=iterative-ilp for the same unit: its straight-line code is bound by dependent-instruction latency of a lone
+# wavefront; the ILP-first list scheduler is worth another 2 - 3 % (k_forward 3.20 -> 3.14 ms, k_backward 0.865 -> 0.835 ms; max-ilp: 1 %).
+HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
              ("tsim_static_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"])]      # (closed-loop instantiations: 76 KB at -O2, stay at -Os)
 
 
