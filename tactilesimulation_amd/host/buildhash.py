@@ -48,7 +48,11 @@ HIP_SO = os.path.join(CSRC, "libtsim_hip.so")
 #   13 % fewer static instructions measured 1 - 2 % faster on every bench leg (profiles/r03_pmc_wait_decomposition.md)
 # -fno-slp-vectorize: packing scalar fp32 math into v_pk_* pairs costs more v_mov than it saves FMAs here and pushes the kernels over
 #   256 registers (measured: +9 %, profiles/r01_launch_shape_ab.txt)
-HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-function-calls=false"]
+# -amdgpu-sched-strategy=iterative-ilp: the kernels are long straight-line code executed by ONE wavefront per SIMD, i.e. bound by the latency of
+#   dependent instructions; the ILP-first list scheduler instead of the occupancy-first default (occupancy is one wavefront either way) measured
+#   +3 ... +6 % on every leg (TactileInsertion 2.22 -> 2.30 M, fp64 3.02 -> 3.16 M, closed loop 17.0 -> 18.1 M, static k_backward 0.865 -> 0.835 ms)
+HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-function-calls=false",
+             "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 # Translation units of the library and the extra flags of each.  -ffinite-math-only -fno-signed-zeros (x * 0 -> 0 and x + 0 -> x may be folded:
 # exact for every finite x, only the sign of a zero can differ) go ONLY to the kernels instantiated for a statically known model
 # (csrc/tsim_static.h): there they turn the generic link sweep into the handful of operations the model's structure leaves; the generic
@@ -56,9 +60,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-ve
 # -O2 for the static unit: its kernels are small (42 KB at -Os, 59 KB at -O2: both inside the 64 KB instruction cache) and -O2's scheduling
 # is worth 4 % there (k_forward 3.30 -> 3.17 ms, k_backward 0.91 -> 0.87 ms per 20-step launch); the generic unit keeps -Os (its NRM = 16
 # kernels are 63 KB already; at -O2: D'Claw -5 %, TactileInsertion -2 %, fp64 -2 %).
-# -amdgpu-sched-strategy=iterative-ilp for the same unit: its straight-line code is bound by dependent-instruction latency of a lone
-# wavefront; the ILP-first list scheduler is worth another 2 - 3 % (k_forward 3.20 -> 3.14 ms, k_backward 0.865 -> 0.835 ms; max-ilp: 1 %).
-HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
+HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),
              ("tsim_static_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"])]      # (closed-loop instantiations: 76 KB at -O2, stay at -Os)
 
 
