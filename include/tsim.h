@@ -178,6 +178,25 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes
  * keeps a batch on the generic kernels (also: environment variable TSIM_NO_STATIC at creation), tsim_set_static(b, 1) allows them again. */
 int tsim_static_model(const tsim_batch* b);
 int tsim_set_static(tsim_batch* b, int allow);
+/* Name of the kernel instantiation the NEXT forward / adjoint launch of this batch uses, for measurement records (bench.py
+ * `kernel_instantiation`): "generic", "static:<model>" (every float of the model a compile-time constant) or "param:<model>" (round 5: the
+ * model's STRUCTURE — tree, joint types, contact pairs, which joint frames are identities and which axes unit vectors — is compiled in, its
+ * parameters are read from the batch's float records, shared or per environment: the instantiation survives tsim_update_model and
+ * tsim_set_env_tables as long as the structure does).  Returns a pointer into static storage. */
+const char* tsim_kernel_variant(const tsim_batch* b);
+/* Host-side switches of a batch (take effect with the next launch).  No reference counterpart.
+ *   TSIM_OPT_PAIR_CULL  (default 1; environment variable TSIM_NO_PAIR_CULL=1 at creation: 0)  a contact pair whose points' bounding sphere is
+ *                       out of reach of its primitive in every environment of a wavefront is skipped by the residual evaluation, and the
+ *                       generic fp32 kernels test a point's fp32 distance before its double-precision one.  Exact: what is skipped would
+ *                       have contributed zeros (tests/test_gpu_exact_options.py asserts equal outputs with the option off). */
+/*   TSIM_OPT_VALUE_TRIALS (default 2; environment variable TSIM_VALUE_TRIALS=n at creation; 0: off)  a line-search trial only needs ||g||: after
+ *                       this many rejected trials of a Newton iteration the further ones evaluate the residual WITHOUT its tangents (about half
+ *                       the work) whenever no environment of the wavefront needs a Newton matrix from that round; a trial that is taken is
+ *                       re-evaluated in full first.  Exact: iterates, convergence flags and the taped matrices are those of the loop without
+ *                       the option (tests/test_gpu_exact_options.py); tsim_last_evals counts trial points either way. */
+enum { TSIM_OPT_PAIR_CULL = 1, TSIM_OPT_VALUE_TRIALS = 2 };
+int tsim_set_option(tsim_batch* b, int option, int value);
+int tsim_get_option(const tsim_batch* b, int option);
 
 /* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */
 int tsim_last_evals(tsim_batch* b, int32_t* host_out);

@@ -403,6 +403,7 @@ template <class R> struct Ctx {
   double *LPd;                            // per link: R (9) + p (3)
   double *PPd;                            // per staged pair: R_PA (9) + p_PA (3)
   const int* LI;                          // sweep schedule + per-link int records in LDS (ts_sched layout below)
+  int cull;               // phase 2 skips contact pairs whose bounding sphere is clear of the primitive (tsim_set_option TSIM_OPT_PAIR_CULL)
   long long* stamps;      // optional per-env array of shader-clock stamps (debug kernel only), else null
   mutable int nstamp;
 };
@@ -464,10 +465,11 @@ __host__ __device__ inline int ts_lds_reals(int nl, int nr, int nu, int nfrec, i
 // max(branch size) steps instead of nl.
 //   S[0] = number of ints, S[1] = steps, S[2 + l] = branch of lane l (l < 16; -1: lane has no dof),
 //   S[18 + b] = leader lane of branch b, S[34] = number of branches, S[35] = offset of the taxel staging table (ts_tax_table),
+//   S[36] = offset of the contact pairs' bounding spheres (ts_pair_bound),
 //   S[TS_SCHED_ENT + step * 16 + l] = link visited by lane l at that step | leader << 8 (0: none; the leader lane of a
 //   branch stores the link's value record), then per link 8 ints: parent, joint type, dof0, ndof, ancestor mask, branch.
 // The leaf->root projection (phase 3) uses the same lists backwards, one lane per (direction, branch).
-enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_TAXTAB = 35, TS_SCHED_ENT = 36, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
+enum { TS_SCHED_BRANCH = 2, TS_SCHED_LEADER = 18, TS_SCHED_NB = 34, TS_SCHED_TAXTAB = 35, TS_SCHED_PBOUND = 36, TS_SCHED_ENT = 37, TS_LR_PARENT = 0, TS_LR_JTYPE, TS_LR_DOF0, TS_LR_NDOF, TS_LR_ANCMASK, TS_LR_BRANCH, TS_LR_SIZE = 8 };
 __device__ __forceinline__ int ts_sched_rec(const int* S) { return TS_SCHED_ENT + S[1] * 16; }
 // ... followed by a copy of the contact-pair int records (TSIM_PI_*), for the lanes = pairs staging of phase 2
 template <class C> __device__ __forceinline__ const int* ts_pair_rec(const C& c, int pk) {
@@ -483,6 +485,12 @@ template <class C> __device__ __forceinline__ const int* ts_motor_rec(const C& c
 // ... and, last, the taxel staging table of k_taxels (tsim_readout): per sensor 3 ints (end of its taxel range, first (sensor,
 // primitive) record, number of records), then per record 2 ints (primitive type, contact pair)
 __device__ __forceinline__ const int* ts_tax_table(const int* S) { return S + S[TS_SCHED_TAXTAB]; }
+// ... and per contact pair 4 floats: the bounding sphere of the pair's contact points in the frame of link A (centre, radius; radius < 0: no
+// bound — the moving contact point of a sphere on a plane).  Built by the host from the contact-point arrays (build_sched); phase 2 skips a pair
+// whose sphere is farther from the primitive than its radius in every environment of the wavefront (pair_stage_value, phase2).
+template <class C> __device__ __forceinline__ const float* ts_pair_bound(const C& c, int pk) {
+  return reinterpret_cast<const float*>(c.LI + c.LI[TS_SCHED_PBOUND]) + 4 * pk;
+}
 
 // A wavefront is about to read global memory it (or a wavefront of its CU) stored to earlier in the launch: wait until the stores
 // have reached L2 (s_waitcnt vmcnt(0): one CU, one XCD, one L2), then drop the vector L1's lines (buffer_inv sc1) — the L1 keeps a
@@ -535,7 +543,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     c.CPTl = (__attribute__((address_space(3))) const R*)(c.cpt_lds ? cpt_l : mf);
     F = mf;
   }
-  c.stamps = nullptr; c.nstamp = 0;
+  c.stamps = nullptr; c.nstamp = 0; c.cull = 0;
   c.nl = I[TSIM_IH_NL]; c.nr = I[TSIM_IH_NR]; c.nu = I[TSIM_IH_NU]; c.nvar = I[TSIM_IH_NVAR];
   c.npair = I[TSIM_IH_NPAIR]; c.ncpt = I[TSIM_IH_NCPT]; c.nsensor = I[TSIM_IH_NSENSOR]; c.ntax = I[TSIM_IH_NTAXEL];
   c.nd = c.nr;
@@ -626,7 +634,7 @@ __device__ __forceinline__ R prim_distance(int prim, const R* shape, V3<R> x) {
 }
 
 template <class R, bool JAC>
-__device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv, V3<double> xh, int* branch = nullptr) {
+__device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* kp, V3<R> x, V3<R> v, V3<R>& F, M3<R>& Jx, M3<R>& Jv, V3<double> xh, int* branch = nullptr, bool jac = true) {
   const R kn = kp[0], kt = kp[1], mu = kp[2], kd = kp[3];
   R d; V3<R> n;
   R ncurv = R(0);          // N = dn/dx = ncurv * (Pm - n n^T), Pm = diag(1, 1, pz)
@@ -662,7 +670,7 @@ __device__ __forceinline__ bool contact_law(int prim, const R* shape, const R* k
   const R sg = fn >= R(0) ? R(1) : R(-1);
   if (!stick) s = mu * sg * fn / vtn;
   F = n * fn - vt * s;
-  if (JAC) {
+  if (JAC && jac) {      // jac: a wave-uniform run-time switch on top (value-only evaluations of line-search trials, evaluate())
     // N w = ncurv (Pm w - n (n.w))
     const V3<R> Nv = (mk3<R>(v.x, v.y, pz * v.z) - n * dd) * ncurv;
     const V3<R> dfx = n * a + Nv * (kd * d);       // d fn / dx

@@ -156,7 +156,7 @@ static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, i
 #define TS_LAUNCH_POLICY(KERNEL, R, b, st, a) do {                                                                                   \
     const LaunchShape L = launch_shape(b);                                                                                           \
     if constexpr (sizeof(R) == 4) {      /* the statically specialised TactilePush instantiation (tsim_static_pusher.hip) */           \
-      if (b->static_id == 1 && L.lpe == 16 && !b->dFenv && !b->no_static) { ts_static_pusher_launch_policy(a, L.grid, L.lds, st); break; }   \
+      if (kernel_mode(b) == TS_KM_STATIC && L.lpe == 16) { ts_static_pusher_launch_policy(a, L.grid, L.lds, st); break; }               \
     }                                                                                                                                 \
     if (L.lpe == 64) hipLaunchKernelGGL((KERNEL<R, 8, false, 64, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                  \
     else if (L.lpe == 32) hipLaunchKernelGGL((KERNEL<R, 8, false, 32, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);             \
@@ -172,7 +172,7 @@ static int push_closed_rollout_t(tsim_batch* b, const tsim_push_policy* pol, con
   a.tape = (R*)b->tape; a.u = nullptr;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
-  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm;
+  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials;
   a.pol = make_push_policy<R>(pol);
   a.pol.goal = (const R*)goal; a.pol.dist = (const R*)dist; a.pol.tac0 = (const R*)tac0;
   a.pol.u_out = (R*)u_out; a.pol.gl_out = (R*)gl_out; a.pol.h1_out = (R*)h1_out; a.pol.h2_out = (R*)h2_out;
@@ -206,7 +206,7 @@ static int push_closed_backward_t(tsim_batch* b, const tsim_push_policy* pol, co
   memset(&a, 0, sizeof(a));
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = nullptr; a.fstride = b->nfrec; a.B = b->B; a.n = nframes * nsub; a.t_end = b->t_cur; a.seed_stride = nsub; a.frames = 1; a.tac_slot = nullptr;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = nullptr;
-  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = nullptr;
+  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = nullptr; a.cull = b->pair_cull;
   a.pol = make_push_policy<R>(pol);
   a.pol.goal = (const R*)goal; a.pol.du_direct = (const R*)du_direct;
   a.pol.u_out = (R*)u_out; a.pol.h1_out = (R*)h1_out; a.pol.h2_out = (R*)h2_out;

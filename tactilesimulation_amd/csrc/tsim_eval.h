@@ -20,9 +20,9 @@
 // (the branch's leader lane stores them), its own tangent, and carries the parent's state in registers when the parent
 // is the link it processed in the previous step (chains), so the common case has no LDS round trip.
 template <class R, bool TANGENT, bool EXPJ>
-__device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+__device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R sa, bool tang = true) {
   const int k = lane, nd = c.nd;
-  const bool act = TANGENT && lane < c.nr;
+  const bool act = TANGENT && tang && lane < c.nr;      // tang (wave-uniform): false = values only, see evaluate()
   const int* S = c.LI;
   const int nsteps = ts_u(S[1]), rec0 = TS_SCHED_ENT + nsteps * 16;
   const int l16 = lane & 15;
@@ -222,8 +222,12 @@ __device__ __forceinline__ void phase1(const Ctx<R>& c, int lane, R sq, R sv, R 
 // ================================================================================================ staged pairs
 // value record of pair pk in slot: pose of A in the primitive frame, relative twist (A w.r.t. B) in that frame.
 // pk may differ between lanes (lanes = pairs in phase 2); `store`: this lane writes the record.
+// Returns whether some contact point of the pair MAY touch the primitive: false only if the bounding sphere of the pair's points (link-A
+// frame, ts_pair_bound) is farther from the primitive than its radius + TS_FAR_MARGIN — prim_distance is a lower bound of the Euclidean
+// distance outside every primitive, and the margin is far above the rounding of an R-precision pose product, so no point contact_law would
+// accept is ever behind a `false`.
 template <class R>
-__device__ __forceinline__ void pair_stage_value(const Ctx<R>& c, int pk, int slot, bool store) {
+__device__ __forceinline__ bool pair_stage_value(const Ctx<R>& c, int pk, int slot, bool store) {
   const int* pi = ts_pair_rec(c, pk);
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
   const int la = pi[TSIM_PI_LINKA], lb = pi[TSIM_PI_LINKB];
@@ -244,6 +248,10 @@ __device__ __forceinline__ void pair_stage_value(const Ctx<R>& c, int pk, int sl
     stm(S + PP_RPA, cvtm<R>(RPAd)); stv(S + PP_PPA, cvt3<R>(pPAd)); st6(S + PP_WREL, Vrel); stm(S + PP_RP, RP); stv(S + PP_PP, pP);
     st6(S + PP_WN, zero6<R>());
   }
+  const float* bd = ts_pair_bound(c, pk);
+  if (!(bd[3] >= 0.0f)) return true;
+  const V3<R> xc = mulMv(cvtm<R>(RPAd), mk3<R>((R)bd[0], (R)bd[1], (R)bd[2])) + cvt3<R>(pPAd);
+  return prim_distance<R>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, xc) < (R)bd[3] + R(TS_FAR_MARGIN);
 }
 // per-direction record of (pair pk, direction k): relative displacement and d(relative twist), both in the primitive
 // frame.  pk and k may differ between lanes (lanes = (pair, direction) in phase 2).
@@ -293,7 +301,7 @@ template <class R> struct PairPose { M3<double> RPAd; V3<double> pPAd; M3<R> RPA
 // Returns whether any lane of the WAVEFRONT had a penetrating point (wave-uniform).  pf: the pair's float record (shape at TSIM_PF_SHAPE,
 // penalty parameters from TSIM_PF_KN) — LDS for the generic kernels, an array of compile-time constants for a static model.
 template <class R, int LPE, int PRIMC, int FLAGSC>
-__device__ __forceinline__ bool pair_points_matrix(const Ctx<R>& c, int pt0, int npt, int prim, bool sphere_plane, const R* pf, const PairPose<R>& P, int lane, R (&w0)[6], R (&M)[6][12]) {
+__device__ __forceinline__ bool pair_points_matrix(const Ctx<R>& c, int pt0, int npt, int prim, bool sphere_plane, const R* pf, const PairPose<R>& P, int lane, R (&w0)[6], R (&M)[6][12], bool tang = true) {
   const M3<double> RPAd = P.RPAd; const V3<double> pPAd = P.pPAd;
   const M3<R> RPA = P.RPA; const V3<R> pPA = P.pPA, wrel = P.wrel, vrel = P.vrel;
 #pragma unroll
@@ -310,16 +318,17 @@ __device__ __forceinline__ bool pair_points_matrix(const Ctx<R>& c, int pt0, int
     M3<R> Jx, Jv;
     if (pidx < npt) {
       const V3<R> cp = ld_cpt(c, pt0 + pidx);                // SoA: consecutive lanes -> consecutive addresses
-      // "certainly outside" in the kernel's own precision first (static models: TS_FAR_MARGIN is far above the rounding of an R-precision
-      // pose product, so the set of points contact_law accepts is unchanged): the far cap of a pad never gets to the double-precision part
+      // "certainly outside" in the kernel's own precision first (TS_FAR_MARGIN is far above the rounding of an R-precision pose product, so the
+      // set of points contact_law accepts is unchanged): the far cap of a pad never gets to the double-precision part.  Static models always;
+      // the generic fp32 kernels with the batch's pair-cull option (round 5: the primitive type is then a wave-uniform run-time value)
       bool near_ = true;
-      if (PRIMC >= 0 && sizeof(R) == 4 && !sphere_plane) near_ = prim_distance<R>(prim, pf + TSIM_PF_SHAPE, mulMv(RPA, cp) + pPA) < R(TS_FAR_MARGIN);
+      if ((PRIMC >= 0 || c.cull) && sizeof(R) == 4 && !sphere_plane) near_ = prim_distance<R>(prim, pf + TSIM_PF_SHAPE, mulMv(RPA, cp) + pPA) < R(TS_FAR_MARGIN);
       if (near_) {
         V3<double> xPd = mulMv(RPAd, cvt3<double>(cp)) + pPAd;
         cP = cvt3<R>(xPd);
         if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
         xP = cvt3<R>(xPd);
-        hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
+        hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd, nullptr, tang);
       }
     }
     if (!__any(hit)) continue;
@@ -327,6 +336,8 @@ __device__ __forceinline__ bool pair_points_matrix(const Ctx<R>& c, int pt0, int
     if (hit) {
       const V3<R> n0 = cross3(xP, F);
       w0[0] += n0.x; w0[1] += n0.y; w0[2] += n0.z; w0[3] += F.x; w0[4] += F.y; w0[5] += F.z;
+    }
+    if (hit && tang) {
       // columns of dF:  d/d(drho) = K = Jx + Jv [wrel]x ;  d/d(dth) = -K [c]x ;  d/d(dw) = -Jv [x]x ;  d/d(dv) = Jv
       // (row r of A [w]x is (A_r x w)^T)
       V3<R> Kr[3], Ath[3], Aw[3], Jvr[3];
@@ -372,7 +383,7 @@ __device__ __forceinline__ bool pair_points_matrix(const Ctx<R>& c, int pt0, int
 }
 
 template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
-__device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane) {
+__device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
@@ -385,28 +396,32 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
   P.wrel = ldv(S + PP_WREL); P.vrel = ldv(S + PP_VREL);
   P.RPA = ldm(S + PP_RPA); P.pPA = ldv(S + PP_PPA);      // R-precision copy of the staged pose (the far test of static models)
   R w0[6], M[6][12];               // value wrench (n; F) and d(n; F) / d(dth, drho, dw, dv)
-  const bool any_hit = pair_points_matrix<R, LPE, PRIMC, FLAGSC>(c, pt0, npt, prim, sphere_plane, pf, P, lane, w0, M);
+  const bool any_hit = pair_points_matrix<R, LPE, PRIMC, FLAGSC>(c, pt0, npt, prim, sphere_plane, pf, P, lane, w0, M, tang);
   TS_STAMP2(c);
   if (!any_hit) return;
   constexpr bool kHalfRow = NPTC >= 0 && NPTC <= 8 && NRM <= 8;      // all points (and all directions) in the first 8 lanes of the slot
   if constexpr (kHalfRow) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      w0[e] = half_row_sum(w0[e]);
+    for (int e = 0; e < 6; ++e) w0[e] = half_row_sum(w0[e]);
+    if (tang) {
 #pragma unroll
-      for (int j = 0; j < 12; ++j) M[e][j] = half_row_sum(M[e][j]);
+      for (int e = 0; e < 6; ++e)
+#pragma unroll
+        for (int j = 0; j < 12; ++j) M[e][j] = half_row_sum(M[e][j]);
     }
   } else {
     seg_sum_many<LPE, 6>(w0);
+    if (tang) {
 #pragma unroll
-    for (int e = 0; e < 6; ++e) seg_sum_many<LPE, 12>(M[e]);
+      for (int e = 0; e < 6; ++e) seg_sum_many<LPE, 12>(M[e]);
+    }
   }
   TS_STAMP2(c);
   if (lane == 0) {
 #pragma unroll
     for (int e = 0; e < 6; ++e) S[PP_WN + e] = w0[e];
   }
-  if (lane < nd) {                 // lanes = directions: (dn; dF) = M t, t = this direction's staged 12-vector
+  if (tang && lane < nd) {                 // lanes = directions: (dn; dF) = M t, t = this direction's staged 12-vector
     R* T = c.PT + (slot * nd + lane) * PT_SIZE;
     R t[12];
 #pragma unroll
@@ -425,7 +440,7 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
 // accumulators.  Kept for fp64, where the 78 accumulators of the matrix form cost 156 registers and the kernel loses more
 // to spills than it gains (measured: 3.07 M vs 2.84 M env-steps/s at two environments per wavefront).
 template <class R, int NRM, int LPE>
-__device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int pk, int slot, int lane) {
+__device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
@@ -454,7 +469,7 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
       cP = cvt3<R>(xPd);
       if (sphere_plane) xPd.z -= (double)pf[TSIM_PF_SHAPE]; // lowest point of the sphere (plane normal = +z of P)
       xP = cvt3<R>(xPd);
-      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd);
+      hit = contact_law<R, true>(prim, pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, xP, vrel + cross3(wrel, xP), F, Jx, Jv, xPd, nullptr, tang);
     }
     if (!__any(hit)) continue;
     any_hit = true;
@@ -462,6 +477,7 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
       const V3<R> n0 = cross3(xP, F);
       acc[0][0] += n0.x; acc[0][1] += n0.y; acc[0][2] += n0.z; acc[0][3] += F.x; acc[0][4] += F.y; acc[0][5] += F.z;
     }
+    if (!tang) continue;
 #pragma unroll
     for (int d = 0; d < NRM; ++d) {
       if (d < nd && ((anc >> d) & 1)) {
@@ -488,6 +504,7 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
       for (int e = 0; e < 6; ++e) S[PP_WN + e] = s[e];
     }
   }
+  if (!tang) return;
 #pragma unroll
   for (int d = 0; d < NRM; ++d) {
     if (d < nd && ((anc >> d) & 1)) {
@@ -504,24 +521,24 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
 }
 
 template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
-__device__ __forceinline__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane) {
-  if (sizeof(R) == 4) pair_contacts_matrix<R, NRM, LPE, PRIMC, FLAGSC, NPTC>(c, pk, slot, lane);
-  else pair_contacts_per_direction<R, NRM, LPE>(c, pk, slot, lane);
+__device__ __forceinline__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
+  if (sizeof(R) == 4) pair_contacts_matrix<R, NRM, LPE, PRIMC, FLAGSC, NPTC>(c, pk, slot, lane, tang);
+  else pair_contacts_per_direction<R, NRM, LPE>(c, pk, slot, lane, tang);
 }
 // the contact loops of a group of pairs with each pair's primitive type / flags taken from the static model (template recursion over the pairs)
 template <class R, int NRM, int LPE, class MS, int PK>
-__device__ __forceinline__ void pair_contacts_static(const Ctx<R>& c, int p0, int pe, int lane) {
+__device__ __forceinline__ void pair_contacts_static(const Ctx<R>& c, int p0, int pe, unsigned act, int lane, bool tang = true) {
   constexpr int NP = MS::Iv(TSIM_IH_NPAIR);
   if constexpr (PK < NP) {
     constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + PK * TSIM_PI_SIZE, flags = MS::Iv(o + TSIM_PI_FLAGS), prim = MS::Iv(o + TSIM_PI_PRIM), npt = MS::Iv(o + TSIM_PI_NPT);
-    if constexpr ((flags & 1) != 0) { if (PK >= p0 && PK < pe) pair_contacts<R, NRM, LPE, prim, flags, npt>(c, PK, PK - p0, lane); }
-    pair_contacts_static<R, NRM, LPE, MS, PK + 1>(c, p0, pe, lane);
+    if constexpr ((flags & 1) != 0) { if (PK >= p0 && PK < pe && ((act >> (PK - p0)) & 1u)) pair_contacts<R, NRM, LPE, prim, flags, npt>(c, PK, PK - p0, lane, tang); }
+    pair_contacts_static<R, NRM, LPE, MS, PK + 1>(c, p0, pe, act, lane, tang);
   }
 }
 
 // lanes = directions: bring the staged pair's wrench (value + tangent k) to the world frame and fold it into the links
 template <class R>
-__device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq) {
+__device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int lane, R sq, bool tang = true) {
   const int k = lane, nd = c.nd;
   if (k >= c.nr) return;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
@@ -531,12 +548,14 @@ __device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int
   const M3<R> RP = ldm(S + PP_RP);
   const V3<R> pP = ldv(S + PP_PP);
   const S6<R> Ww = wrench_to_world(RP, pP, ld6(S + PP_WN));
-  const R inB = ((ts_u(anc_of(c.I, c.off_link, lb)) >> k) & 1) ? R(1) : R(0);
-  const S6<R> dWw = wrench_to_world(RP, pP, ld6(T + PT_WN)) + crf(ld6(c.WP + k * 6) * (sq * inB), Ww);
-  if (la > 0) {         // link 0 (world-fixed general bodies) takes no wrench
-    acc6(c.DT + (la * nd + k) * DT_SIZE + DT_FN, dWw, R(-1));
+  if (tang) {
+    const R inB = ((ts_u(anc_of(c.I, c.off_link, lb)) >> k) & 1) ? R(1) : R(0);
+    const S6<R> dWw = wrench_to_world(RP, pP, ld6(T + PT_WN)) + crf(ld6(c.WP + k * 6) * (sq * inB), Ww);
+    if (la > 0) {         // link 0 (world-fixed general bodies) takes no wrench
+      acc6(c.DT + (la * nd + k) * DT_SIZE + DT_FN, dWw, R(-1));
+    }
+    if (lb > 0) acc6(c.DT + (lb * nd + k) * DT_SIZE + DT_FN, dWw, R(1));
   }
-  if (lb > 0) acc6(c.DT + (lb * nd + k) * DT_SIZE + DT_FN, dWw, R(1));
   if (k == 0) {
     if (la > 0) acc6(c.LP + la * LK_SIZE + LK_FN, Ww, R(-1));
     if (lb > 0) acc6(c.LP + lb * LK_SIZE + LK_FN, Ww, R(1));
@@ -544,15 +563,24 @@ __device__ __forceinline__ void pair_fold(const Ctx<R>& c, int pk, int slot, int
 }
 
 template <class R, int NRM, int LPE, class MS = void>
-__device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
+__device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq, bool tang = true) {
   for (int p0 = 0; p0 < c.npair; p0 += TS_PAIR_GROUP) {
     const int pe = min(p0 + TS_PAIR_GROUP, c.npair), np = pe - p0;
-    // lanes = pairs of the group: value records
-    if (lane < np && (ts_pair_rec(c, p0 + lane)[TSIM_PI_FLAGS] & 1)) pair_stage_value(c, p0 + lane, lane, true);
+    // lanes = pairs of the group: value records, and whether the pair can be in contact at all (its points' bounding sphere against the
+    // primitive).  A pair that cannot, in ANY environment of the wavefront, is skipped from here on — its staged wrench and wrench tangents
+    // would be exact zeros, and what the fold adds for it is x + 0 (round 5: TactileInsertion's hole walls and the ground are out of reach for
+    // most of an attempt, D'Claw's fingertips touch the cap 15 % of the time; c.cull == 0 keeps every pair live)
+    bool near_ = false;
+    if (lane < np && (ts_pair_rec(c, p0 + lane)[TSIM_PI_FLAGS] & 1)) near_ = pair_stage_value(c, p0 + lane, lane, true) || !c.cull;
+    const unsigned long long nb = __ballot(near_);
+    unsigned act = 0;                          // bit j: pair p0 + j is live in some slot of the wavefront (wave-uniform)
+#pragma unroll
+    for (int s_ = 0; s_ < TS_WAVE / LPE; ++s_) act |= (unsigned)(nb >> (s_ * LPE)) & ((1u << TS_PAIR_GROUP) - 1u);
     TS_SYNC();
     TS_STAMP(c);
+    if (act == 0) { TS_STAMP(c); TS_STAMP(c); continue; }
     // lanes = (pair, direction): per-direction records
-    {
+    if (tang) {
       const int ntask = np * c.nr;
       // wave-uniform trip count with the idle lanes masked inside: the lane-strided form (t = lane; t < ntask; t += LPE)
       // of this loop produced wrong adjoints in the 32-lane shape only (toolchain issue with the divergent loop, not
@@ -561,7 +589,7 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
         const int t = t0 + lane;
         if (t < ntask) {
           const int p = t / c.nr, k = t - p * c.nr;
-          if (ts_pair_rec(c, p0 + p)[TSIM_PI_FLAGS] & 1) pair_stage_tangent(c, p0 + p, p, k, sq, 0);
+          if ((ts_pair_rec(c, p0 + p)[TSIM_PI_FLAGS] & 1) && ((act >> p) & 1u)) pair_stage_tangent(c, p0 + p, p, k, sq, 0);
         }
       }
     }
@@ -569,12 +597,12 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
     TS_STAMP(c);
     if constexpr (std::is_void<MS>::value) {
       for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
-        if (ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane);
-    } else pair_contacts_static<R, NRM, LPE, MS, 0>(c, p0, pe, lane);
+        if ((ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) && ((act >> (pk - p0)) & 1u)) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane, tang);
+    } else pair_contacts_static<R, NRM, LPE, MS, 0>(c, p0, pe, act, lane, tang);
     TS_SYNC();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = directions; serial over pairs: two pairs may touch the same link
-      if (ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) pair_fold(c, pk, pk - p0, lane, sq);
+      if ((ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) && ((act >> (pk - p0)) & 1u)) pair_fold(c, pk, pk - p0, lane, sq, tang);
     TS_SYNC();
   }
 }
@@ -582,7 +610,7 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq) {
 // joint-space forces: damping, limits, motor (lanes = dofs; the motor of a dof comes from the schedule in LDS), and the
 // 1 / ca scaling of g and H (each lane scales its own column)
 template <class R>
-__device__ __forceinline__ void phase3_joint_space(const Ctx<R>& c, int lane, R sq, R sv, R h2) {
+__device__ __forceinline__ void phase3_joint_space(const Ctx<R>& c, int lane, R sq, R sv, R h2, bool tang = true) {
   const int nr = c.nr;
   const bool act = lane < nr;
   if (act) {
@@ -609,7 +637,8 @@ __device__ __forceinline__ void phase3_joint_space(const Ctx<R>& c, int lane, R 
       }
       if (dm != -2) break;             // the usual case: exactly one motor on this dof
     }
-    c.g[j] = gj * h2; c.H[j * nr + j] += hjj * h2;
+    c.g[j] = gj * h2;
+    if (tang) c.H[j * nr + j] += hjj * h2;
   }
 }
 
@@ -618,7 +647,7 @@ __device__ __forceinline__ void phase3_joint_space(const Ctx<R>& c, int lane, R 
 // parent; then the joint-space forces.  Result: g (value, LDS) and H[j][k] = d g_j / d dir_k (lane k owns
 // column k).  Both are scaled by h^2.
 template <class R, bool EXPJ, int LPE>
-__device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
+__device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv, bool tang = true) {
   const int nd = c.nd, nr = c.nr;
   const bool act = lane < nr;
   const R h2 = R(1) / c.ca;      // g = r / ca  (BDF1: h^2 r)
@@ -630,7 +659,7 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   const int nsteps = ts_u(S[1]), rec0 = TS_SCHED_ENT + nsteps * 16, ntask = ts_u(S[TS_SCHED_NB]) * nr;
   for (int t0 = 0; t0 < ntask; t0 += LPE) {
     const int t = t0 + lane;
-    const bool has = t < ntask;
+    const bool has = t < ntask && (tang || t % nr == 0);      // values only: direction 0's lanes carry g, the others have nothing to do
     const int b = has ? t / nr : 0, k = has ? t - b * nr : 0;
     const int col = S[TS_SCHED_LEADER + b];
     const S6<R> Wk = ld6(c.WP + k * 6);
@@ -643,25 +672,28 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
       const int* li = S + rec0 + (i - 1) * TS_LR_SIZE;
       const int par = li[TS_LR_PARENT], k0 = li[TS_LR_DOF0], ndj = li[TS_LR_NDOF];
       S6<R> F = ld6(c.LP + i * LK_SIZE + LK_FN);
-      S6<R> dF = ld6(c.DT + (i * nd + k) * DT_SIZE + DT_FN);
+      S6<R> dF = zero6<R>();
+      if (tang) dF = ld6(c.DT + (i * nd + k) * DT_SIZE + DT_FN);
       if (carry_to == i) { F = F + cF; dF = dF + cdF; }
       const bool moves = (li[TS_LR_ANCMASK] >> k) & 1;
       for (int j = k0; j < k0 + ndj; ++j) {
         const S6<R> Wj = ld6(c.WP + j * 6);
-        R dtau = dot6(Wj, dF);
-        if (moves) {
-          const bool same_exp = EXPJ && li[TS_LR_JTYPE] == TSIM_J_SPHERICAL_EXP && k >= k0 && k < k0 + ndj;
-          const S6<R> dW = same_exp ? ld6(c.expw + ((j - k0) * 3 + (k - k0)) * 6) : crm(Wk, Wj);
-          dtau += sq * dot6(dW, F);
+        if (tang) {
+          R dtau = dot6(Wj, dF);
+          if (moves) {
+            const bool same_exp = EXPJ && li[TS_LR_JTYPE] == TSIM_J_SPHERICAL_EXP && k >= k0 && k < k0 + ndj;
+            const S6<R> dW = same_exp ? ld6(c.expw + ((j - k0) * 3 + (k - k0)) * 6) : crm(Wk, Wj);
+            dtau += sq * dot6(dW, F);
+          }
+          c.H[j * nr + k] = dtau * h2;                  // columns are stored scaled by 1 / ca (g = r / ca)
         }
-        c.H[j * nr + k] = dtau * h2;                  // columns are stored scaled by 1 / ca (g = r / ca)
         if (k == 0) c.g[j] = dot6(Wj, F);
       }
       if (par > 0) {
         const int nxt = st > 0 ? (S[TS_SCHED_ENT + (st - 1) * 16 + col] & 0xff) : 0;
         if (par == nxt) { cF = F; cdF = dF; carry_to = par; }
         else {
-          acc6(c.DT + (par * nd + k) * DT_SIZE + DT_FN, dF, R(1));
+          if (tang) acc6(c.DT + (par * nd + k) * DT_SIZE + DT_FN, dF, R(1));
           if (k == 0) acc6(c.LP + par * LK_SIZE + LK_FN, F, R(1));
         }
       }
@@ -669,18 +701,14 @@ __device__ __forceinline__ void phase3(const Ctx<R>& c, int lane, R sq, R sv) {
   }
   TS_SYNC();
   TS_STAMP2(c);
-  phase3_joint_space<R>(c, lane, sq, sv, h2);
+  phase3_joint_space<R>(c, lane, sq, sv, h2, tang);
   TS_SYNC();
 }
 
 #include "tsim_static_eval.h"
 // is the evaluation of model MS the fused register-resident pass?  (fp32 instantiations of a static model that asks for it)
 template <class MS, class R> constexpr bool ts_static_fused() {
-#ifdef TS_STATIC_UNFUSED
-  return false;
-#else
   if constexpr (std::is_void<MS>::value) return false; else return MS::FUSED && sizeof(R) == 4;
-#endif
 }
 
 // full evaluation at the trial increment held in c.dl (with c.q0, c.qd0, c.u): fills c.q, c.qd, c.qa, link state, g, H.
@@ -688,8 +716,11 @@ template <class MS, class R> constexpr bool ts_static_fused() {
 // 4/3 q0 - 1/3 q_1 + 8/9 h qd0 - 2/9 h qd_1), not q1 itself: qd1 = qdp + cv dl, qdd1 = ca dl keep full relative
 // precision in fp32 (no q1 - q0 cancellation).  forward seeds: (1, cv, ca) -> H = dg/dq1 ;  adjoint seeds (1, 0, 0)
 // -> H = (1/ca) dr/dq  (BDF1: h^2 dr/dq).
+// tang (wave-uniform, default true): false = the VALUES only — q, qd, qa, the link state and g; no tangent, no H (c.H keeps what it held).  Every
+// number it does compute is computed exactly as the full evaluation computes it.  k_forward asks for it when no environment of the wavefront
+// needs a Newton matrix from this round: line-search trials deep in a backtracking (only ||g|| decides them), finished slots.
 template <class R, int NRM, bool EXPJ, int LPE, class MS = void>
-__device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa) {
+__device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, R sa, bool tang = true) {
   if (lane < c.nr) {
     const R d = c.dl[lane];
     c.qd[lane] = c.qdp[lane] + c.cv * d;
@@ -699,23 +730,17 @@ __device__ __forceinline__ void evaluate(const Ctx<R>& c, int lane, R sq, R sv, 
   }
   TS_SYNC();
   TS_STAMP(c);
-#ifndef TS_STATIC_UNFUSED      // (A/B: the static link sweep followed by the generic phases 2 / 3)
   if constexpr (ts_static_fused<MS, R>()) {
-    evaluate_static_fused<R, NRM, LPE, MS, false>(c, lane, sq, sv, sa);      // a statically known model: one register-resident pass (tsim_static_eval.h)
+    evaluate_static_fused<R, NRM, LPE, MS, false>(c, lane, sq, sv, sa, tang);      // a statically known model: one register-resident pass (tsim_static_eval.h)
     TS_STAMP(c);
     return;
   }
-#endif
-  if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, sq, sv, sa);
-#ifdef TS_STATIC_BRANCH_BLOCKS
-  else phase1_static<R, MS, true, false>(c, lane, sq, sv, sa);       // A/B: the block-per-branch form
-#else
-  else phase1_static_levels<R, MS, true, false>(c, lane, sq, sv, sa);      // a statically known model: tsim_static.h (forward: no COM / inertia records)
-#endif
+  if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, sq, sv, sa, tang);
+  else phase1_static_levels<R, MS, true, false>(c, lane, sq, sv, sa);      // a statically known model whose evaluation is not fused (tsim_static.h; forward: no COM / inertia records)
   TS_STAMP(c);
-  phase2<R, NRM, LPE, MS>(c, lane, sq);
+  phase2<R, NRM, LPE, MS>(c, lane, sq, tang);
   TS_STAMP(c);
-  phase3<R, EXPJ, LPE>(c, lane, sq, sv);
+  phase3<R, EXPJ, LPE>(c, lane, sq, sv, tang);
   TS_STAMP(c);
 }
 

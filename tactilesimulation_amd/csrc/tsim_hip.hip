@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -432,7 +433,14 @@ struct tsim_batch {
   int nsched;                    // ints of the sweep schedule appended to dI
   int stage_cpt;                 // the contact-point arrays are staged in LDS with the shared tables
   int n_simd;                    // SIMDs of the device (CUs x 4)
-  int static_id = 0, no_static = 0;   // the blob equals a compiled-in static model bit for bit (1: TsStaticPusher); TSIM_NO_STATIC=1 / tsim_set_static(0) keeps the generic kernels
+  int value_trials = 2;          // line-search trials after this many rejected ones evaluate the residual only (0: off; tsim_set_option TSIM_OPT_VALUE_TRIALS; TSIM_VALUE_TRIALS=n at creation)
+  int pair_cull = 1;             // phase 2 skips contact pairs out of reach of their primitive (tsim_set_option TSIM_OPT_PAIR_CULL; TSIM_NO_PAIR_CULL=1 at creation: off)
+  // Compiled-in models (csrc/tsim_static.h).  static_id: the model whose STRUCTURE the batch's blob has (ints + the structural floats: 1 TactilePush);
+  // static_exact: every float record equals the compiled asset's bit for bit as well (the fully static instantiation); env_struct_ok: the
+  // per-environment tables keep the structural floats (checked on the device by tsim_set_env_tables).  TSIM_NO_STATIC=1 at creation /
+  // tsim_set_static(0) keep the generic kernels.
+  int static_id = 0, static_exact = 0, env_struct_ok = 0, no_static = 0;
+  unsigned char* dKmask = nullptr; int* dFlag = nullptr;      // structural-float mask of static_id on the device, one-int result of the table check
   void* fposeR = nullptr; double* fposeD = nullptr; int fpose_frames = 0;   // pose records per frame [fpose_frames][B][nspt] of episode launches with a deferred read-out
   int pose_valid = 0;            // the pose records are those of the current state (left by the last forward launch)
   int pose_off = 0;              // a launch of this batch was captured in a HIP graph: replays change the state behind the host's back, no reuse
@@ -452,7 +460,7 @@ static void pose_invalidate(tsim_batch* b, hipStream_t st) {
 
 
 // sweep schedule of the link tree (layout: ts_sched in tsim_device.h)
-static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
+static std::vector<int32_t> build_sched(const std::vector<int32_t>& I, const std::vector<double>& F) {
   const int nl = I[TSIM_IH_NL], nr = I[TSIM_IH_NR], ol = I[TSIM_IH_OFF_LINK];
   std::vector<int> parent(nl + 1, 0), branch(nl + 1, -1), dof_link(nr, 0);
   std::vector<std::vector<int>> links;                       // links of each root branch, parents before children
@@ -506,6 +514,26 @@ static std::vector<int32_t> build_sched(const std::vector<int32_t>& I) {
     }
     S[0] = (int32_t)S.size();
   }
+  {   // bounding sphere of each contact pair's points, link-A frame (ts_pair_bound): centre of the points' box, radius rounded UP
+    S[TS_SCHED_PBOUND] = (int32_t)S.size();
+    const int ncpt = I[TSIM_IH_NCPT], fc = I[TSIM_IH_FOFF_CPT];
+    for (int pk = 0; pk < npair; ++pk) {
+      const int32_t* pi = &I[op + pk * TSIM_PI_SIZE];
+      const int p0_ = pi[TSIM_PI_PT0], n_ = pi[TSIM_PI_NPT];
+      float bd[4] = {0.f, 0.f, 0.f, -1.f};
+      if (n_ > 0 && !(pi[TSIM_PI_FLAGS] & 2)) {
+        double lo[3], hi[3], cc[3];
+        for (int a_ = 0; a_ < 3; ++a_) { lo[a_] = 1e300; hi[a_] = -1e300; }
+        for (int i = 0; i < n_; ++i) for (int a_ = 0; a_ < 3; ++a_) { const double v = F[fc + a_ * ncpt + p0_ + i]; lo[a_] = std::min(lo[a_], v); hi[a_] = std::max(hi[a_], v); }
+        for (int a_ = 0; a_ < 3; ++a_) { bd[a_] = (float)(0.5 * (lo[a_] + hi[a_])); cc[a_] = (double)bd[a_]; }      // the centre the device will use
+        double r2 = 0.0;
+        for (int i = 0; i < n_; ++i) { double d2 = 0.0; for (int a_ = 0; a_ < 3; ++a_) { const double d = F[fc + a_ * ncpt + p0_ + i] - cc[a_]; d2 += d * d; } r2 = std::max(r2, d2); }
+        bd[3] = (float)(std::sqrt(r2) * (1.0 + 1e-6) + 1e-7);
+      }
+      for (int e = 0; e < 4; ++e) { int32_t w; std::memcpy(&w, &bd[e], 4); S.push_back(w); }
+    }
+    S[0] = (int32_t)S.size();
+  }
   const int dm0 = rec0 + nl * TS_LR_SIZE + npair * TSIM_PI_SIZE;                                 // dof -> motor, motor int records
   for (int j = 0; j < 16; ++j) S[dm0 + j] = -1;
   for (int m = 0; m < nu; ++m) {
@@ -535,15 +563,35 @@ template <class MS> static bool blob_equals_static(const tsim_batch* b) {
   for (int i = 0; i < MS::NFREC; ++i) if (std::memcmp(&b->F[i], (const double[]){MS::Fv(i)}, sizeof(double)) != 0) return false;
   return true;
 }
+// ... or in its STRUCTURE only: all ints (but the taxel layout) and the structural floats of the compiled asset (TsParam::Fk: exact 0, 1, -1)
+template <class MS> static bool blob_has_structure(const tsim_batch* b) {
+  if ((int)b->I.size() != MS::NI || b->I[TSIM_IH_FOFF_CPT] != MS::NFREC) return false;
+  auto taxel_layout = [&](int i) {
+    if (i == TSIM_IH_NTAXEL || i == TSIM_IH_NF || i == TSIM_IH_NDOF_TACTILE) return true;
+    const int os = MS::Iv(TSIM_IH_OFF_SENSOR), ns = MS::Iv(TSIM_IH_NSENSOR);
+    if (i >= os && i < os + ns * TSIM_SI_SIZE) { const int f = (i - os) % TSIM_SI_SIZE; return f == TSIM_SI_TAX0 || f == TSIM_SI_NTAX || f == TSIM_SI_ROWS || f == TSIM_SI_COLS; }
+    return false;
+  };
+  for (int i = 0; i < MS::NI; ++i) if (b->I[i] != MS::Iv(i) && !taxel_layout(i)) return false;
+  for (int i = 0; i < MS::NFREC; ++i) if (MS::Fk(i) && !(b->F[i] == MS::Fv(i))) return false;
+  return true;
+}
 static void detect_static_model(tsim_batch* b) {
-  b->static_id = blob_equals_static<TsStaticPusher>(b) ? 1 : 0;
-  b->no_static = getenv("TSIM_NO_STATIC") != nullptr;
+  b->static_id = blob_has_structure<TsParam<TsStaticPusher>>(b) ? 1 : 0;
+  b->static_exact = b->static_id == 1 && blob_equals_static<TsStaticPusher>(b);
+}
+// which instantiation the next launch of the simulation kernels uses: 0 generic, 1 fully static, 2 structure-static (parameters at run time)
+enum { TS_KM_GENERIC = 0, TS_KM_STATIC = 1, TS_KM_PARAM = 2 };
+static int kernel_mode(const tsim_batch* b) {
+  if (b->static_id == 0 || b->no_static || b->dtype != TSIM_F32) return TS_KM_GENERIC;
+  if (b->dFenv) return b->env_struct_ok ? TS_KM_PARAM : TS_KM_GENERIC;
+  return b->static_exact ? TS_KM_STATIC : TS_KM_PARAM;
 }
 static int upload_model(tsim_batch* b, hipStream_t st) {
   detect_static_model(b);
   HIPCHK(hipMemcpyAsync(b->dI, b->I.data(), b->I.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
   {
-    std::vector<int32_t> S = build_sched(b->I);              // appended to the device copy at I[TSIM_IH_NI]
+    std::vector<int32_t> S = build_sched(b->I, b->F);              // appended to the device copy at I[TSIM_IH_NI]
     if ((int)S.size() != b->nsched) return fail("sweep schedule size changed");
     b->tt_off = b->I[TSIM_IH_NI] + S[TS_SCHED_TAXTAB];
     HIPCHK(hipMemcpyAsync(b->dI + b->I.size(), S.data(), S.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -575,6 +623,14 @@ static int zero_async(void* p, size_t bytes, hipStream_t st) {
   return 0;
 }
 
+// do the per-environment tables [B][nfrec] keep the structural floats of the compiled-in model (mask km: 1 = structural; ref: the batch's
+// shared records, which do)?  flag != 0: some environment does not
+__global__ void k_check_structure(const float* tables, const float* ref, const unsigned char* km, int nfrec, size_t n, int* flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = (int)(i % (size_t)nfrec);
+  if (km[f] && !(tables[i] == ref[f])) atomicOr(flag, 1);
+}
 // scatter [B][nr] q / qd into tape record 0
 template <class R> __global__ void k_set_state(R* tape, const R* q, const R* qd, int B, int nr, int rec) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -625,7 +681,7 @@ static LaunchShape launch_shape(const tsim_batch* b) {
     const int cand[3] = {64, 32, 16};
     // (the fused static kernels: 1 : 1.13 : 1.24 — their rounds get cheaper with more lanes per environment, so a batch that fills the SIMDs
     // with one environment per wavefront takes that shape: TactilePush 13 x 13 at B = 1024, forward only: 9.0 / 8.0 / 7.3 M env-steps/s)
-    const bool fused_static = b->static_id != 0 && !b->no_static && !b->dFenv && b->dtype == TSIM_F32;
+    const bool fused_static = kernel_mode(b) != TS_KM_GENERIC;
     const double lat_generic[3] = {1.0, 0.93, 1.02}, lat_static[3] = {1.0, 1.13, 1.24};
     const double* lat = fused_static ? lat_static : lat_generic;
     for (int i = 0; i < 3; ++i) {
@@ -660,6 +716,10 @@ void ts_static_pusher_launch(const BwdArgs<float>& a, int lpe, unsigned grid, si
 void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);      // ... with the policy between the frames
 void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
+// ... and of the structure-static ones (tsim_param_pusher.hip): the same kernels with the model's parameters read from the float records
+void ts_param_pusher_launch(const FwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
+void ts_param_pusher_launch(const BwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
+void ts_param_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
 // compiled out otherwise: it costs registers in every evaluation); LPE as above
 #define TS_LAUNCH_L(KERNEL, R, NRM, L, st, a) do {                                                                       \
@@ -670,10 +730,9 @@ void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_
 #define TS_LAUNCH(KERNEL, R, b, st, a) do {                                                                              \
     const LaunchShape L = launch_shape(b);                                                                               \
     if constexpr (sizeof(R) == 4) {      /* a statically known model (tsim_static.h): instantiated in its own translation unit */ \
-      if (b->static_id == 1 && !b->dFenv && !b->no_static) {                                                              \
-        ts_static_pusher_launch(a, L.lpe, L.grid, L.lds, st);                                                             \
-        break;                                                                                                            \
-      }                                                                                                                   \
+      const int km_ = kernel_mode(b);                                                                                     \
+      if (km_ == TS_KM_STATIC) { ts_static_pusher_launch(a, L.lpe, L.grid, L.lds, st); break; }                           \
+      if (km_ == TS_KM_PARAM) { ts_param_pusher_launch(a, L.lpe, L.grid, L.lds, st); break; }                             \
     }                                                                                                                     \
     if (b->has_exp) hipLaunchKernelGGL((KERNEL<R, 16, true, 64>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);            \
     else if (b->nr <= 8) TS_LAUNCH_L(KERNEL, R, 8, L, st, a);                                                            \
@@ -728,7 +787,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->B >= 256 && nframes == 1 && b->order_valid) ? b->order : (b->B >= 256 && nframes > 1 && b->order_ep_n == nframes * nsub && !getenv("TSIM_NO_EPISODE_LPT")) ? b->order_ep : nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
-  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm;
+  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials;
   const bool emit = pose_emit(b, st);
   a.nspt = b->nspt;
   if (emit) { a.poseR = (R*)b->poseR; a.poseD = b->poseD; }
@@ -778,7 +837,7 @@ static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, co
   BwdArgs<R> a;
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames; a.tac_slot = tac_slot;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
-  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = b->bwd_stamps;
+  a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = b->bwd_stamps; a.cull = b->pair_cull;
   TS_LAUNCH(k_backward, R, b, st, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -816,7 +875,10 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->t_cur = 0; b->record = 0; b->has_exp = n_exp > 0;
   b->dFenv = nullptr; b->nfrec = I[TSIM_IH_FOFF_CPT];
   b->lpe_forced = 0;
-  { const std::vector<int32_t> S_ = build_sched(b->I); b->nsched = (int)S_.size(); b->tt_off = b->I[TSIM_IH_NI] + S_[TS_SCHED_TAXTAB]; }
+  { const std::vector<int32_t> S_ = build_sched(b->I, b->F); b->nsched = (int)S_.size(); b->tt_off = b->I[TSIM_IH_NI] + S_[TS_SCHED_TAXTAB]; }
+  b->pair_cull = getenv("TSIM_NO_PAIR_CULL") ? 0 : 1;
+  b->no_static = getenv("TSIM_NO_STATIC") != nullptr;
+  if (const char* e = getenv("TSIM_VALUE_TRIALS")) b->value_trials = std::max(0, atoi(e));
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
   b->cross_kinks = dtype == TSIM_F32 ? 1 : 0;
   {
@@ -825,6 +887,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
     b->n_simd = 4 * cus;
   }
   b->stage_cpt = 0;
+  detect_static_model(b);      // before the staging decision: the launch shape depends on which kernels run
   if (lds_bytes_for(b, 1) > 64 * 1024) { delete b; return fail("model needs more than 64 KiB of LDS per environment"); }
   decide_stage_cpt(b);
   b->dI = nullptr; b->dF = nullptr; b->tape = nullptr; b->lamq = nullptr; b->lamv = nullptr; b->evals = nullptr; b->order = nullptr; b->order_valid = 0; b->prev = nullptr; b->has_prev = 0; b->poseR = nullptr; b->poseD = nullptr; b->nspt = b->I[TSIM_IH_NSPRIM];
@@ -848,7 +911,7 @@ void tsim_batch_destroy(tsim_batch* b) {
   DeviceGuard guard_(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
   for (void* p : b->pool) (void)hipFree(p);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD); (void)hipFree(b->fposeR); (void)hipFree(b->fposeD);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD); (void)hipFree(b->fposeR); (void)hipFree(b->fposeD); (void)hipFree(b->dKmask); (void)hipFree(b->dFlag);
   delete b;
 }
 
@@ -872,10 +935,29 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
   decide_stage_cpt(b);      // depends on the shape; the flag travels with every launch as a kernel argument: nothing on the device to update
   return 0;
 }
-int tsim_static_model(const tsim_batch* b) {
-  return (b->static_id != 0 && !b->no_static && b->dtype == TSIM_F32 && !b->dFenv) ? b->static_id : 0;
+int tsim_static_model(const tsim_batch* b) { return kernel_mode(b) != TS_KM_GENERIC ? b->static_id : 0; }
+const char* tsim_kernel_variant(const tsim_batch* b) {
+  const int km = kernel_mode(b);
+  if (km == TS_KM_STATIC) return "static:pusher";
+  if (km == TS_KM_PARAM) return "param:pusher";
+  return "generic";
 }
-int tsim_set_static(tsim_batch* b, int allow) { b->no_static = allow ? 0 : 1; return 0; }
+int tsim_set_static(tsim_batch* b, int allow) {
+  b->no_static = allow ? 0 : 1;
+  b->order_valid = 0; b->order_ep_n = 0;
+  decide_stage_cpt(b);      // the launch shape depends on which kernels run
+  return 0;
+}
+int tsim_set_option(tsim_batch* b, int option, int value) {
+  if (option == TSIM_OPT_PAIR_CULL) { b->pair_cull = value != 0; return 0; }
+  if (option == TSIM_OPT_VALUE_TRIALS) { if (value < 0) return fail("set_option: TSIM_OPT_VALUE_TRIALS >= 0"); b->value_trials = value; return 0; }
+  return fail("set_option: unknown option " + std::to_string(option));
+}
+int tsim_get_option(const tsim_batch* b, int option) {
+  if (option == TSIM_OPT_PAIR_CULL) return b->pair_cull;
+  if (option == TSIM_OPT_VALUE_TRIALS) return b->value_trials;
+  return -1;
+}
 int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {
   if (eval_budget < 0) return fail("set_solver_options: negative evaluation budget");
   b->cross_kinks = cross_kinks != 0;
@@ -899,17 +981,46 @@ int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* st
   TS_DEVICE(b);
   pose_invalidate(b, (hipStream_t)stream);
   b->I.assign(I, I + I[TSIM_IH_NI]); b->F.assign(F, F + I[TSIM_IH_NF]);
-  if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; decide_stage_cpt(b); }     // per-environment tables refer to the old model
-  return upload_model(b, (hipStream_t)stream);
+  if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; b->env_struct_ok = 0; }     // per-environment tables refer to the old model
+  if (int rc = upload_model(b, (hipStream_t)stream)) return rc;
+  b->order_valid = 0; b->order_ep_n = 0;
+  decide_stage_cpt(b);      // the edit may have moved the batch between the compiled-in and the generic kernels: another launch shape
+  return 0;
 }
 
 int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream) {
   TS_DEVICE(b);
   pose_invalidate(b, (hipStream_t)stream);
-  if (!tables) { if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; decide_stage_cpt(b); } return 0; }
+  if (!tables) { if (b->dFenv) { HIPCHK(hipFree(b->dFenv)); b->dFenv = nullptr; b->env_struct_ok = 0; decide_stage_cpt(b); } return 0; }
   size_t bytes = (size_t)b->B * b->nfrec * b->esz;
-  if (!b->dFenv) { HIPCHK(hipMalloc(&b->dFenv, bytes)); decide_stage_cpt(b); }      // the block's LDS layout changes with per-environment tables
+  const bool fresh = !b->dFenv;
+  if (fresh) HIPCHK(hipMalloc(&b->dFenv, bytes));
   HIPCHK(hipMemcpyAsync(b->dFenv, tables, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  // A batch whose model has a compiled-in structure stays on that instantiation if every environment's table keeps the structural floats
+  // (the exact 0 / 1 / -1 entries the instantiation has folded away): checked here, on the device, once per call — one small kernel and a
+  // 4-byte read-back (this call synchronises then; inside a stream capture the check is skipped and the batch takes the generic kernels).
+  const int ok_before = b->env_struct_ok;
+  b->env_struct_ok = 0;
+  if (b->static_id != 0 && b->dtype == TSIM_F32) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+      if (!b->dKmask) {
+        std::vector<unsigned char> km(b->nfrec);
+        for (int i = 0; i < b->nfrec; ++i) km[i] = TsParam<TsStaticPusher>::Fk(i) ? 1 : 0;
+        HIPCHK(hipMalloc((void**)&b->dKmask, km.size())); HIPCHK(hipMalloc((void**)&b->dFlag, sizeof(int)));
+        HIPCHK(hipMemcpy(b->dKmask, km.data(), km.size(), hipMemcpyHostToDevice));
+      }
+      int flag = 0;
+      HIPCHK(hipMemsetAsync(b->dFlag, 0, sizeof(int), (hipStream_t)stream));
+      const size_t n = (size_t)b->B * b->nfrec;
+      hipLaunchKernelGGL(k_check_structure, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)b->dFenv, (const float*)b->dF, b->dKmask, b->nfrec, n, b->dFlag);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&flag, b->dFlag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+      HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+      b->env_struct_ok = flag == 0;
+    }
+  }
+  if (fresh || ok_before != b->env_struct_ok) { b->order_valid = 0; b->order_ep_n = 0; decide_stage_cpt(b); }      // the block's LDS layout / the kernels change
   return 0;
 }
 int tsim_table_size(const tsim_batch* b) { return b->nfrec; }
@@ -1118,13 +1229,14 @@ int tsim_debug_eval(tsim_batch* b, const void* q1, const void* q0, const void* q
   const dim3 grid((b->B + ns - 1) / ns), blk(TS_WAVE);
   const size_t lds = lds_bytes_for(b, ns);
   if (b->dtype == TSIM_F32) {
-    DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles, b->stage_cpt};
-    if (lpe == 16 && b->static_id == 1 && !b->dFenv && !b->no_static) ts_static_pusher_launch_debug(a, grid.x, lds, (hipStream_t)stream);      // the static sweep's g and H
+    DbgArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, (const float*)q1, (const float*)q0, (const float*)qd0, (const float*)u, (float*)g_out, (float*)H_out, cycles, b->stage_cpt, b->pair_cull};
+    if (lpe == 16 && kernel_mode(b) == TS_KM_STATIC) ts_static_pusher_launch_debug(a, grid.x, lds, (hipStream_t)stream);      // the static sweep's g and H
+    else if (lpe == 16 && kernel_mode(b) == TS_KM_PARAM) ts_param_pusher_launch_debug(a, grid.x, lds, (hipStream_t)stream);
     else if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<float, 16>), grid, blk, lds, (hipStream_t)stream, a);
     else if (lpe == 32) hipLaunchKernelGGL((k_debug_eval<float, 32>), grid, blk, lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_debug_eval<float, 64>), grid, blk, lds, (hipStream_t)stream, a);
   } else {
-    DbgArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles, b->stage_cpt};
+    DbgArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, (const double*)q1, (const double*)q0, (const double*)qd0, (const double*)u, (double*)g_out, (double*)H_out, cycles, b->stage_cpt, b->pair_cull};
     if (lpe == 16) hipLaunchKernelGGL((k_debug_eval<double, 16>), grid, blk, lds, (hipStream_t)stream, a);
     else if (lpe == 32) hipLaunchKernelGGL((k_debug_eval<double, 32>), grid, blk, lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_debug_eval<double, 64>), grid, blk, lds, (hipStream_t)stream, a);

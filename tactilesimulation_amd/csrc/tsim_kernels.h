@@ -100,6 +100,8 @@ template <class R> struct FwdArgs {
   int free_run = 0;            // the slots of a wavefront run their frames / sub-steps independently (k_forward, main loop)
   int lockstep = 0;            // ... or go through every sub-step together (a slot that has converged re-evaluates its iterate until all have)
   R* fposeR = nullptr; double* fposeD = nullptr;               // [nframes][B][nspt] pose records per frame: the tactile frames are evaluated by k_taxels after the launch
+  int cull = 0;                // phase 2 skips contact pairs out of reach of their primitive (Ctx::cull)
+  int vo_ls = 0;               // > 0: line-search trials after vo_ls rejected ones evaluate the residual only (k_forward, main loop; tsim_set_option TSIM_OPT_VALUE_TRIALS)
 };
 
 // -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
@@ -126,6 +128,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   const bool valid = eidx < a.B;                                        // a batch that is no multiple of NS: idle slot
   const int env = a.order ? a.order[min(eidx, a.B - 1)] : min(eidx, a.B - 1);
   Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  c.cull = a.cull;
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   init_world(c, lane, LPE);
   {
@@ -180,6 +183,14 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   R gn = R(0), alpha = R(1), sv = R(0), sa = R(0);
   int iter = 0, ls = -1, sub_evals = 0, crossings = 0;       // ls < 0: the evaluation just done is not a line-search trial
   bool conv = false, fin = false, forced = false;
+  // Line-search trials need ||g|| only.  A slot that is deep in a backtracking (>= a.vo_ls rejected trials in this iteration) marks its next
+  // evaluation `vo`; a round in which no live slot of the wavefront needs a Newton matrix evaluates the VALUES only (evaluate(..., tang = false):
+  // no tangents, no contact Jacobians, no 72 of the 78 reductions per pair — about half a round).  A values-only trial that would be TAKEN
+  // (accepted, or the last of max_ls) is evaluated once more, with tangents, before anything is decided: g comes out bit-identical, so the
+  // decision repeats itself and H is the full evaluation's.  Iterates, convergence and the taped matrices are exactly those of the loop
+  // without the option; `evals` counts trial points (the repeats are not counted).  Where it pays: the environments a launch waits for
+  // are the ones in long line searches (a D'Claw fingertip jammed against the cap: 100 iterations x 12 trials; profiles/r05_value_trials.md).
+  bool vo = false;
 #ifdef TS_ROUND_STATS   // A/B builds only (tools/round_stats.py): rounds of this wavefront and its shader clocks, left in status / gnorm
   int rounds_ = 0; const long long rs_t0_ = clock64();
 #endif
@@ -231,7 +242,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       }
       sv = c.cv; sa = c.ca;
       if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
-      gn = R(0); alpha = R(1); iter = 0; ls = -1; sub_evals = 0; crossings = 0; conv = false; fin = false; forced = false;
+      gn = R(0); alpha = R(1); iter = 0; ls = -1; sub_evals = 0; crossings = 0; conv = false; fin = false; forced = false; vo = false;
       ss = false;
     }
     TS_SYNC();
@@ -258,21 +269,30 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     //    TactileInsertion grasp (||g|| ~ 1e-3, steps of 0.02 - 0.5) that reached roots 0.15 rad away from the literal one.
     //  * eval_budget (default 0 = none): an upper bound on the evaluations of one sub-step for throughput-minded roll-out collection;
     //    a sub-step cut short is flagged non-converged in status.
-    evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, R(1), sv, sa);
+    const bool tang = a.vo_ls <= 0 || __any(!fin && !done && !held && !vo);      // does any live slot need H from this round?
+    evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, R(1), sv, sa, tang);
     const R gnew = block_norm2<LPE>(c.g, nr, lane);
     bool solve = false;
     if (!fin && !done) {
-      ++evals; ++sub_evals;
-      bool take = false;                     // the point just evaluated becomes the iterate
+      // what the evaluation just done means for this slot: 0 the full step across a kink comes next, 1 the step is halved, 2 the point is taken
+      int action = 2;                        // the first evaluation of the sub-step, an accepted trial, or the step across a kink
       if (ls >= 0 && !forced && (!ts_finite(gnew) || gnew >= gn)) {              // a rejected trial (a non-finite one is rejected too)
-        if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) {
-          ++crossings; forced = true;        // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
+        if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) action = 0;
+        else if (ls < c.max_ls) action = 1;
+      }                                      // (else: the literal loop takes the last trial anyway)
+      bool take = false;                     // the point just evaluated becomes the iterate
+      if (action == 2 && !tang) vo = false;  // to be taken, but evaluated without tangents: the same point again, in full (nothing else changes)
+      else {
+        ++evals; ++sub_evals;
+        if (action == 0) {
+          ++crossings; forced = true; vo = false;      // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
           if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-        } else if (ls < c.max_ls) {          // halve the step
+        } else if (action == 1) {            // halve the step
           alpha *= R(0.5); ++ls;
+          vo = a.vo_ls > 0 && ls >= a.vo_ls;
           if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
-        } else take = true;                  // the literal loop: the last trial is taken anyway
-      } else take = true;                    // the first evaluation of the sub-step, an accepted trial, or the step across a kink
+        } else { take = true; vo = false; }
+      }
       if (take) {
         forced = false;
         if (ls >= 0) ++iter;
@@ -288,11 +308,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     }
     TS_SYNC();
     if (__any(solve)) {
-#ifdef TS_NEWTON_SOLVE_F32      // A/B: the Newton step's elimination in fp32 (fp32 kernels)
-      solve_newton<R, NRM, LPE, R>(c.H, c.rhs, c.dq, nr, false, lane, solve);
-#else
-      solve_newton<R, NRM, LPE, double, ts_static_nr<MS>()>(c.H, c.rhs, c.dq, nr, false, lane, solve);
-#endif
+      solve_newton<R, NRM, LPE, double, ts_static_nr<MS>()>(c.H, c.rhs, c.dq, nr, false, lane, solve);      // (elimination in fp32: -0.7 %, not taken; profiles/r04_static_model.md)
       if (solve) {
         alpha = R(1); ls = 0;
         if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
@@ -416,6 +432,7 @@ template <class R> struct BwdArgs {
   int stage_cpt;
   long long* cyc;         // diagnostics: shader-clock stamps of the first sub-steps of wavefront 0 (tsim_debug_stamps), or null
   PushPolicy<R> pol;      // POLICY instantiations only (tsim_push_closed_backward)
+  int cull = 0;
 };
 
 // (M z)_j for lane j, M = sum_i J_i^T I_i J_i:  lanes = links form f_i = I_i (sum_{k above i} W_k z_k) in the (idle) pair-staging
@@ -570,6 +587,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   const bool valid = (int)blockIdx.x * NS + slot < a.B;
   const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
   Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  c.cull = a.cull;
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
   R* H2 = c.H2;    // taped Newton matrix of the sub-step
@@ -636,11 +654,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
     const bool seeded = (j + 1) % a.seed_stride == 0;
     if constexpr (kFused) { }      // (a seeded sub-step runs its own link sweep inside ts_static_output_vjp)
     else if constexpr (std::is_void<MS>::value) phase1<R, true, EXPJ>(c, lane, R(1), R(0), R(0));
-#ifdef TS_STATIC_BRANCH_BLOCKS
-    else phase1_static<R, MS, true>(c, lane, R(1), R(0), R(0));
-#else
     else phase1_static_levels<R, MS, true>(c, lane, R(1), R(0), R(0));
-#endif
     TS_STAMP(c);
     // direct partials of the loss w.r.t. this sub-step's outputs
     if (seeded) {
@@ -737,9 +751,9 @@ __device__ __forceinline__ void ts_vjp_sprim(const Ctx<R>& c, int lane, const Ts
     const int t0 = ts_u(c.I[c.off_sensor + SN * TSIM_SI_SIZE + TSIM_SI_TAX0]), nt = ts_u(c.I[c.off_sensor + SN * TSIM_SI_SIZE + TSIM_SI_NTAX]);      // the taxel layout is the batch's own (blob_equals_static)
     R pf[TSIM_PF_SIZE], sf[TSIM_SF_SIZE];
 #pragma unroll
-    for (int e = 0; e < TSIM_SF_SIZE; ++e) sf[e] = (R)MS::Fv(MS::Iv(TSIM_IH_FOFF_SENSOR) + SN * TSIM_SF_SIZE + e);
+    for (int e = 0; e < TSIM_SF_SIZE; ++e) sf[e] = ts_F<R, MS>(c, MS::Iv(TSIM_IH_FOFF_SENSOR) + SN * TSIM_SF_SIZE + e);
     M3<R> RP; V3<R> pP; PairPose<R> P; S6<R> Vrel, dVA, dVB;
-    ts_fused_pair_pose<R, MS, pk>(st, pf, RP, pP, P, Vrel, dVA, dVB);
+    ts_fused_pair_pose<R, MS, pk>(c, st, pf, RP, pP, P, Vrel, dVA, dVB);
     R g[12];
     const bool any_live = vjp_taxels<LPE, R, prim>(c, lane, t0, nt, prim, pf + TSIM_PF_SHAPE, sf, P, wtac, g);
     if (any_live) {
@@ -766,18 +780,18 @@ __device__ __forceinline__ void ts_vjp_sensors(const Ctx<R>& c, int lane, const 
   }
 }
 template <class R, class MS, int E>
-__device__ __forceinline__ void ts_vjp_vars(int lane, const TsLinkTmp<R>* tmp, const S6<R>& Wk, const R* wvar, R& dlq) {
+__device__ __forceinline__ void ts_vjp_vars(const Ctx<R>& c, int lane, const TsLinkTmp<R>* tmp, const S6<R>& Wk, const R* wvar, R& dlq) {
   using T = TsTopo<MS>;
   if constexpr (E < MS::Iv(TSIM_IH_NVAR)) {
     constexpr int l = MS::Iv(MS::Iv(TSIM_IH_OFF_VAR) + E * TSIM_VI_SIZE + TSIM_VI_LINK), fo = MS::Iv(TSIM_IH_FOFF_VAR) + E * TSIM_VF_SIZE;
     if constexpr (l != 0) {
       constexpr int anc = T::li(l == 0 ? 1 : l, TSIM_LI_ANCMASK);
       const R mv = ((anc >> lane) & 1) ? R(1) : R(0);
-      const V3<R> x = mulMv(tmp[l].XR, mk3<R>((R)MS::Fv(fo), (R)MS::Fv(fo + 1), (R)MS::Fv(fo + 2))) + tmp[l].Xp;
+      const V3<R> x = mulMv(tmp[l].XR, mk3<R>(ts_F<R, MS>(c, fo), ts_F<R, MS>(c, fo + 1), ts_F<R, MS>(c, fo + 2))) + tmp[l].Xp;
       const V3<R> Jv_ = cross3(Wk.a, x) + Wk.l;
       dlq += mv * (wvar[3 * E] * Jv_.x + wvar[3 * E + 1] * Jv_.y + wvar[3 * E + 2] * Jv_.z);
     }
-    ts_vjp_vars<R, MS, E + 1>(lane, tmp, Wk, wvar, dlq);
+    ts_vjp_vars<R, MS, E + 1>(c, lane, tmp, Wk, wvar, dlq);
   }
 }
 template <class R, int LPE, class MS>
@@ -789,14 +803,14 @@ __device__ __forceinline__ void ts_static_output_vjp(const Ctx<R>& c, int lane, 
   S6<R> Wk = zero6<R>(), dFl[T::NL + 1];
   ts_l_level<R, MS, true, false, 0, 0>(c, lane, R(1), R(0), R(0), st, tmp, Wk, dFl);      // values + this lane's twist tangents (seeds (1, 0, 0)), nothing stored
   R dlq = R(0), dlv = R(0);
-  if (wvar) ts_vjp_vars<R, MS, 0>(lane, tmp, Wk, wvar, dlq);
+  if (wvar) ts_vjp_vars<R, MS, 0>(c, lane, tmp, Wk, wvar, dlq);
   if (wtac) ts_vjp_sensors<R, LPE, MS, 0>(c, lane, st, Wk, wtac, dlq, dlv);
   if (lane < T::NR) { c.lamq[lane] += dlq; c.lamv[lane] += dlv; }
   TS_SYNC();
 }
 
 // ================================================================================================ debug evaluation
-template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; int stage_cpt; };
+template <class R> struct DbgArgs { const int* I; const R* F; const R* Fenv; int fstride; int B; const R *q1, *q0, *qd0, *u; R *g, *H; long long* cyc; int stage_cpt; int cull; };
 
 template <class R, int LPE, class MS = void>
 __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
@@ -807,6 +821,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   const bool valid = (int)blockIdx.x * NS + slot < a.B;
   const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
   Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  c.cull = a.cull;
   const int nr = c.nr, nu = c.nu;
   init_world(c, lane, LPE);
   if (lane < nr) {

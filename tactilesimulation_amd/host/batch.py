@@ -274,6 +274,19 @@ class BatchSim:
     def set_static(self, allow):
         capi.check(capi.lib().tsim_set_static(self._h, int(bool(allow))))
 
+    def kernel_variant(self):
+        """Name of the kernel instantiation the next launch uses: "generic", "static:<model>", "param:<model>" (include/tsim.h)."""
+        return capi.lib().tsim_kernel_variant(self._h).decode()
+
+    OPT_PAIR_CULL, OPT_VALUE_TRIALS = 1, 2
+
+    def set_option(self, option, value):
+        """include/tsim.h tsim_set_option (TSIM_OPT_*)."""
+        capi.check(capi.lib().tsim_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option):
+        return capi.lib().tsim_get_option(self._h, int(option))
+
     def launch_info(self):
         out = (C.c_int32 * 4)()
         capi.lib().tsim_launch_info(self._h, out)

@@ -61,6 +61,7 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-ve
 # is worth 4 % there (k_forward 3.30 -> 3.17 ms, k_backward 0.91 -> 0.87 ms per 20-step launch); the generic unit keeps -Os (its NRM = 16
 # kernels are 63 KB already; at -O2: D'Claw -5 %, TactileInsertion -2 %, fp64 -2 %).
 HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),
+             ("tsim_param_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),      # the same kernels, parameters at run time (tsim_static.h ts_F)
              ("tsim_static_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"])]      # (closed-loop instantiations: 76 KB at -O2, stay at -Os)
 
 

@@ -124,21 +124,31 @@ def test_the_taxel_layout_is_not_part_of_the_static_model():
 
 
 def test_static_kernels_switch_off_for_other_blobs_shapes_and_tables(pusher_model):
+    """The FULLY static instantiation needs the compiled-in blob bit for bit; a batch that keeps the model's structure moves to the
+    structure-static one (round 5, tests/test_gpu_param_model.py), everything else to the generic kernels — and kernel_variant() says which."""
     B = 4096
     sim = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=0)
-    assert sim.static_model() == 1
+    assert sim.static_model() == 1 and sim.kernel_variant() == "static:pusher"
     sim.set_lanes_per_env(32)
-    assert sim.static_model() == 1                                       # every launch shape has its static instantiation
+    assert sim.kernel_variant() == "static:pusher"                      # every launch shape has its static instantiation
     sim.set_lanes_per_env(0)
     sim.set_env_tables(sim.base_tables())
-    assert sim.static_model() == 0                                       # per-environment tables
+    assert sim.static_model() == 1 and sim.kernel_variant() == "param:pusher"      # per-environment tables: parameters at run time
     sim.set_env_tables(None)
-    assert sim.static_model() == 1
+    assert sim.kernel_variant() == "static:pusher"
     m = copy.copy(pusher_model); m.F = pusher_model.F.copy()
-    m.F[m.I[BL.TSIM_IH_FOFF_PAIR] + BL.TSIM_PF_KN] *= 1.5                # one float record edited: no longer the compiled-in model
+    m.F[m.I[BL.TSIM_IH_FOFF_PAIR] + BL.TSIM_PF_KN] *= 1.5                # one float record edited: no longer the compiled-in model, still its structure
     sim.update_model(m)
-    assert sim.static_model() == 0
+    assert sim.kernel_variant() == "param:pusher"
+    m2 = copy.copy(pusher_model); m2.F = pusher_model.F.copy()
+    m2.F[m2.I[BL.TSIM_IH_FOFF_LINK] + BL.TSIM_LF_R + 1] = 0.01            # a joint frame that is no identity any more: another structure
+    sim.update_model(m2)
+    assert sim.static_model() == 0 and sim.kernel_variant() == "generic"
     sim.update_model(pusher_model)
-    assert sim.static_model() == 1
+    assert sim.static_model() == 1 and sim.kernel_variant() == "static:pusher"
+    sim.set_static(False)
+    assert sim.static_model() == 0 and sim.kernel_variant() == "generic"
+    sim.update_model(pusher_model)
+    assert sim.kernel_variant() == "generic"                            # tsim_set_static(0) survives a model update
     assert BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0).static_model() == 0
     assert BatchSim(pusher_model, 64, dtype=torch.float32, tape_capacity=0).static_model() == 1      # small batch: one environment per wavefront, static too

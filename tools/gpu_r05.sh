@@ -1,0 +1,30 @@
+# The round-5 GPU sessions, one function per session (run on the GPU box through gpurun from the repo root): bash tools/gpu_r05.sh <session>
+set -x
+cd ${GRAFT_REPO_ROOT:-.}; mkdir -p gpurun_out; export TMPDIR=/tmp
+S=$1; O=gpurun_out/r05${S}
+case $S in
+a)  # pair cull + structure-static kernels: parity, then the legs they were built for
+  timeout 900 python -m pytest tests/test_gpu_exact_options.py tests/test_gpu_param_model.py tests/test_gpu_static_model.py tests/test_gpu_edge_cases.py -x -q -m gpu 2>&1 | tail -15 > ${O}_tests.log
+  timeout 600 python -m pytest tests/test_gpu_models.py -x -q -m gpu -k "dclaw or insertion or ball_push or slider" 2>&1 | tail -8 >> ${O}_tests.log
+  timeout 600 python tools/sub_record_ab.py dclaw insertion push_fwd > ${O}_legs_cull.jsonl 2> ${O}_legs_cull.err
+  TSIM_NO_PAIR_CULL=1 timeout 600 python tools/sub_record_ab.py dclaw insertion push_fwd > ${O}_legs_nocull.jsonl 2> ${O}_legs_nocull.err
+  timeout 300 python tools/param_tables_probe.py > ${O}_param_tables.json 2> ${O}_param_tables.err
+  ;;
+b)  # where an evaluation's cycles go on the generic kernels (D'Claw, TactileInsertion), the structure-static kernels on the bench's own inputs
+  timeout 600 python -m pytest tests/test_gpu_param_model.py -x -q -m gpu 2>&1 | tail -5 > ${O}_tests.log
+  for w in dclaw insertion; do for l in 32 16; do timeout 300 python tools/eval_stamps.py $w $l 20 >> ${O}_stamps.jsonl 2>> ${O}_stamps.err; done; done
+  timeout 300 python tools/eval_stamps.py insertion 32 40 >> ${O}_stamps.jsonl 2>> ${O}_stamps.err
+  timeout 300 python tools/param_tables_probe.py > ${O}_param_tables.json 2> ${O}_param_tables.err
+  ;;
+c)  # value-only line-search trials: exactness, then the straggler-bound legs with the option off / on
+  timeout 900 python -m pytest tests/test_gpu_exact_options.py tests/test_gpu_param_model.py tests/test_gpu_static_model.py tests/test_gpu_edge_cases.py -x -q -m gpu 2>&1 | tail -15 > ${O}_tests.log
+  timeout 600 python -m pytest tests/test_gpu_models.py tests/test_gpu_literal.py -x -q -m gpu 2>&1 | tail -8 >> ${O}_tests.log
+  for v in 0 1 2 3; do TSIM_VALUE_TRIALS=$v timeout 600 python tools/sub_record_ab.py dclaw insertion push_fwd >> ${O}_legs.jsonl 2>> ${O}_legs.err; done
+  for v in 0 2; do TSIM_VALUE_TRIALS=$v timeout 300 python tools/param_tables_probe.py >> ${O}_param_tables.jsonl 2>> ${O}_param_tables.err; done
+  ;;
+d)  # the shortcuts A/B in one process (launch-by-launch times): D'Claw, TactileInsertion, TactilePush forward-only and the headline's forward launch
+  timeout 600 python -m pytest tests/test_gpu_exact_options.py -x -q -m gpu 2>&1 | tail -15 > ${O}_tests.log
+  for w in dclaw insertion push_fwd push; do timeout 600 python tools/option_ab.py $w >> ${O}_option_ab.jsonl 2>> ${O}_option_ab.err; done
+  timeout 600 python tools/option_ab.py dclaw 8192 3 >> ${O}_option_ab.jsonl 2>> ${O}_option_ab.err
+  ;;
+esac
