@@ -194,12 +194,21 @@ const char* tsim_kernel_variant(const tsim_batch* b);
  *                       the work) whenever no environment of the wavefront needs a Newton matrix from that round; a trial that is taken is
  *                       re-evaluated in full first.  Exact: iterates, convergence flags and the taped matrices are those of the loop without
  *                       the option (tests/test_gpu_exact_options.py); tsim_last_evals counts trial points either way. */
-enum { TSIM_OPT_PAIR_CULL = 1, TSIM_OPT_VALUE_TRIALS = 2 };
+/*   TSIM_OPT_TRIAL_HELPERS (default 1; environment variable TSIM_NO_TRIAL_HELPERS=1 at creation: 0)  a launch lasts as long as its slowest
+ *                       environment's chain of evaluations, and those chains are long line searches.  The slots of a wavefront whose own
+ *                       environments are finished evaluate the NEXT trial points (dlbase + 2^-t dq: known in advance) of a slot that is still
+ *                       in a line search; the owner judges the results in the order and with the decision code of the sequential loop.
+ *                       Exact: iterates, convergence flags, taped matrices and tsim_last_evals are those of the loop without helpers
+ *                       (tests/test_gpu_exact_options.py); a line search of n trials takes ceil(n / (1 + helpers)) rounds. */
+enum { TSIM_OPT_PAIR_CULL = 1, TSIM_OPT_VALUE_TRIALS = 2, TSIM_OPT_TRIAL_HELPERS = 3 };
 int tsim_set_option(tsim_batch* b, int option, int value);
 int tsim_get_option(const tsim_batch* b, int option);
 
 /* residual evaluations each environment spent in the most recent tsim_step (HOST int32[B]); synchronises. */
 int tsim_last_evals(tsim_batch* b, int32_t* host_out);
+/* ... and how many of those trial points were evaluated by a helper slot (TSIM_OPT_TRIAL_HELPERS) instead of in a round of the environment's own
+ * (HOST int32[B]); synchronises.  No reference counterpart (diagnostics: tests assert that the helper path ran, profiles report its share). */
+int tsim_last_helper_trials(tsim_batch* b, int32_t* host_out);
 
 /* The Newton iteration of a sub-step is the loop the model's <solver_option tol max_iter max_ls> states (envs/assets/pusher/pusher.xml:4)
  * and nothing else: up to max_iter iterations, each halving its step until ||g|| decreases, at most max_ls times, taking the last trial

@@ -421,6 +421,7 @@ struct tsim_batch {
   void *lamq, *lamv;             // carried adjoint [2][B][nr]: of the state the next adjoint sub-step starts from, and (BDF2) what later
                                  // sub-steps already contributed to the state one step further back
   int* evals;                    // residual evaluations of the last forward launch, per env
+  int* helped = nullptr;         // ... and how many of its line-search trials a helper slot evaluated (k_forward; tsim_last_helper_trials)
   float* gnorm = nullptr;        // largest ||g|| a sub-step of the last forward launch ended with, per env
   int cross_kinks = 0, eval_budget = 0;     // tsim_set_solver_options
   int* order; int order_valid;   // block -> env map for the next forward launch (LPT scheduling)
@@ -434,6 +435,7 @@ struct tsim_batch {
   int stage_cpt;                 // the contact-point arrays are staged in LDS with the shared tables
   int n_simd;                    // SIMDs of the device (CUs x 4)
   int value_trials = 2;          // line-search trials after this many rejected ones evaluate the residual only (0: off; tsim_set_option TSIM_OPT_VALUE_TRIALS; TSIM_VALUE_TRIALS=n at creation)
+  int trial_helpers = 1;        // finished slots of a wavefront evaluate the next line-search trials of a slot that is still in one (tsim_set_option TSIM_OPT_TRIAL_HELPERS; TSIM_NO_TRIAL_HELPERS=1 at creation: off)
   int pair_cull = 1;             // phase 2 skips contact pairs out of reach of their primitive (tsim_set_option TSIM_OPT_PAIR_CULL; TSIM_NO_PAIR_CULL=1 at creation: off)
   // Compiled-in models (csrc/tsim_static.h).  static_id: the model whose STRUCTURE the batch's blob has (ints + the structural floats: 1 TactilePush);
   // static_exact: every float record equals the compiled asset's bit for bit as well (the fully static instantiation); env_struct_ok: the
@@ -449,6 +451,7 @@ struct tsim_batch {
   size_t esz;
   std::vector<CacheEntry> cache;   // saved tapes, newest last
   std::vector<void*> pool;          // spare tape buffers
+  std::vector<void*> retired;       // per-frame pose records replaced by larger ones while a captured graph may still name them (launch_forward)
   long long* bwd_stamps = nullptr;  // diagnostics (tsim_debug_stamps)
 };
 // The state changed other than by a forward launch (or is about to, in a captured graph): tsim_readout recomputes the kinematics.
@@ -787,7 +790,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->B >= 256 && nframes == 1 && b->order_valid) ? b->order : (b->B >= 256 && nframes > 1 && b->order_ep_n == nframes * nsub && !getenv("TSIM_NO_EPISODE_LPT")) ? b->order_ep : nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
-  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials;
+  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials; a.helpers = b->trial_helpers; a.helped = b->helped;
   const bool emit = pose_emit(b, st);
   a.nspt = b->nspt;
   if (emit) { a.poseR = (R*)b->poseR; a.poseD = b->poseD; }
@@ -802,7 +805,11 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) defer = false;      // no allocation inside a capture: the in-kernel read-out
     else {
       HIPCHK(hipStreamSynchronize(st));          // an earlier launch may still be writing the old records
-      (void)hipFree(b->fposeR); (void)hipFree(b->fposeD); b->fposeR = nullptr; b->fposeD = nullptr; b->fpose_frames = 0;
+      // A HIP graph captured from this batch (pose_off) holds the OLD buffers' addresses in its kernel arguments — a replay after this
+      // point would write freed memory: such buffers are retired (freed with the batch), not freed
+      if (b->pose_off) { if (b->fposeR) b->retired.push_back(b->fposeR); if (b->fposeD) b->retired.push_back(b->fposeD); }
+      else { (void)hipFree(b->fposeR); (void)hipFree(b->fposeD); }
+      b->fposeR = nullptr; b->fposeD = nullptr; b->fpose_frames = 0;
       if (hipMalloc(&b->fposeR, (size_t)nframes * b->B * b->nspt * TP_R_SIZE * b->esz) != hipSuccess ||
           hipMalloc((void**)&b->fposeD, (size_t)nframes * b->B * b->nspt * TP_D_SIZE * sizeof(double)) != hipSuccess) {
         (void)hipGetLastError(); (void)hipFree(b->fposeR); b->fposeR = nullptr; b->fposeD = nullptr; defer = false;
@@ -878,6 +885,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   { const std::vector<int32_t> S_ = build_sched(b->I, b->F); b->nsched = (int)S_.size(); b->tt_off = b->I[TSIM_IH_NI] + S_[TS_SCHED_TAXTAB]; }
   b->pair_cull = getenv("TSIM_NO_PAIR_CULL") ? 0 : 1;
   b->no_static = getenv("TSIM_NO_STATIC") != nullptr;
+  b->trial_helpers = getenv("TSIM_NO_TRIAL_HELPERS") ? 0 : 1;
   if (const char* e = getenv("TSIM_VALUE_TRIALS")) b->value_trials = std::max(0, atoi(e));
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
   b->cross_kinks = dtype == TSIM_F32 ? 1 : 0;
@@ -894,7 +902,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   size_t tape_bytes = (size_t)(tape_capacity + 1) * B * b->rec * b->esz;
   if (hipMalloc(&b->dI, (b->I.size() + b->nsched) * sizeof(int32_t)) != hipSuccess || hipMalloc(&b->dF, b->F.size() * b->esz) != hipSuccess ||
       hipMalloc(&b->tape, tape_bytes) != hipSuccess || hipMalloc(&b->lamq, (size_t)2 * B * nr * b->esz) != hipSuccess ||
-      hipMalloc(&b->lamv, (size_t)2 * B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->gnorm, (size_t)B * sizeof(float)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->order_ep, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
+      hipMalloc(&b->lamv, (size_t)2 * B * nr * b->esz) != hipSuccess || hipMalloc(&b->evals, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->helped, (size_t)B * sizeof(int)) != hipSuccess || hipMemset(b->helped, 0, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->gnorm, (size_t)B * sizeof(float)) != hipSuccess || hipMalloc(&b->order, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc((void**)&b->order_ep, (size_t)B * sizeof(int)) != hipSuccess || hipMalloc(&b->prev, (size_t)B * 2 * nr * sizeof(double)) != hipSuccess ||
       (b->nspt > 0 && (hipMalloc(&b->poseR, (size_t)B * b->nspt * TP_R_SIZE * b->esz) != hipSuccess || hipMalloc((void**)&b->poseD, (size_t)B * b->nspt * TP_D_SIZE * sizeof(double)) != hipSuccess))) {
     tsim_batch_destroy(b);
     return fail("hipMalloc failed (tape bytes = " + std::to_string(tape_bytes) + ")");
@@ -911,7 +919,8 @@ void tsim_batch_destroy(tsim_batch* b) {
   DeviceGuard guard_(b->device);
   for (auto& e : b->cache) (void)hipFree(e.buf);
   for (void* p : b->pool) (void)hipFree(p);
-  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD); (void)hipFree(b->fposeR); (void)hipFree(b->fposeD); (void)hipFree(b->dKmask); (void)hipFree(b->dFlag);
+  for (void* p : b->retired) (void)hipFree(p);
+  (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->helped); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD); (void)hipFree(b->fposeR); (void)hipFree(b->fposeD); (void)hipFree(b->dKmask); (void)hipFree(b->dFlag);
   delete b;
 }
 
@@ -951,11 +960,13 @@ int tsim_set_static(tsim_batch* b, int allow) {
 int tsim_set_option(tsim_batch* b, int option, int value) {
   if (option == TSIM_OPT_PAIR_CULL) { b->pair_cull = value != 0; return 0; }
   if (option == TSIM_OPT_VALUE_TRIALS) { if (value < 0) return fail("set_option: TSIM_OPT_VALUE_TRIALS >= 0"); b->value_trials = value; return 0; }
+  if (option == TSIM_OPT_TRIAL_HELPERS) { b->trial_helpers = value != 0; return 0; }
   return fail("set_option: unknown option " + std::to_string(option));
 }
 int tsim_get_option(const tsim_batch* b, int option) {
   if (option == TSIM_OPT_PAIR_CULL) return b->pair_cull;
   if (option == TSIM_OPT_VALUE_TRIALS) return b->value_trials;
+  if (option == TSIM_OPT_TRIAL_HELPERS) return b->trial_helpers;
   return -1;
 }
 int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {
@@ -967,6 +978,11 @@ int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {
 int tsim_last_gnorm(tsim_batch* b, float* host_out) {
   TS_DEVICE(b);
   if (hipMemcpy(host_out, b->gnorm, (size_t)b->B * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_gnorm: copy failed");
+  return 0;
+}
+int tsim_last_helper_trials(tsim_batch* b, int32_t* host_out) {
+  TS_DEVICE(b);
+  if (hipMemcpy(host_out, b->helped, (size_t)b->B * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("last_helper_trials: copy failed");
   return 0;
 }
 int tsim_last_evals(tsim_batch* b, int32_t* host_out) {

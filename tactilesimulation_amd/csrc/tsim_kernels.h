@@ -81,6 +81,10 @@ __device__ __forceinline__ void readout(const Ctx<R>& c, int lane, int env, bool
 }
 
 // ================================================================================================ forward kernel
+// trial point of a backtracking line search, base + alpha dq, as ONE fused multiply-add wherever it is formed: the slot that owns the line search and
+// a helper slot (k_forward) must arrive at the same bits
+__device__ __forceinline__ float ts_trial_point(float base, float alpha, float dq) { return __builtin_fmaf(alpha, dq, base); }
+__device__ __forceinline__ double ts_trial_point(double base, double alpha, double dq) { return __builtin_fma(alpha, dq, base); }
 enum { TP_R_SIZE = 18, TP_D_SIZE = 12 };      // pose record of a (sensor, primitive) combination: R part, double part (k_readout)
 template <class R> struct FwdArgs {
   const int* I; const R* F; const R* Fenv; int fstride;
@@ -102,6 +106,8 @@ template <class R> struct FwdArgs {
   R* fposeR = nullptr; double* fposeD = nullptr;               // [nframes][B][nspt] pose records per frame: the tactile frames are evaluated by k_taxels after the launch
   int cull = 0;                // phase 2 skips contact pairs out of reach of their primitive (Ctx::cull)
   int vo_ls = 0;               // > 0: line-search trials after vo_ls rejected ones evaluate the residual only (k_forward, main loop; tsim_set_option TSIM_OPT_VALUE_TRIALS)
+  int* helped = nullptr;        // [B] line-search trials of the launch that a helper slot evaluated for this environment (tsim_last_helper_trials)
+  int helpers = 0;             // slots that have finished their environment evaluate the NEXT line-search trials of a slot that is still in one (k_forward, main loop; TSIM_OPT_TRIAL_HELPERS)
 };
 
 // -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
@@ -180,7 +186,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   bool held = false;                         // !free_run: the last sub-step of the frame is finished, waiting for the other slots
   R unext = R(0);                            // the next frame's action, fetched one frame ahead (a lone wavefront cannot hide the load)
   if (!POLICY && !done && lane < nu) unext = a.u[(size_t)env * nu + lane];
-  R gn = R(0), alpha = R(1), sv = R(0), sa = R(0);
+  R gn = R(0), alpha = R(1);
   int iter = 0, ls = -1, sub_evals = 0, crossings = 0;       // ls < 0: the evaluation just done is not a line-search trial
   bool conv = false, fin = false, forced = false;
   // Line-search trials need ||g|| only.  A slot that is deep in a backtracking (>= a.vo_ls rejected trials in this iteration) marks its next
@@ -191,6 +197,21 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   // without the option; `evals` counts trial points (the repeats are not counted).  Where it pays: the environments a launch waits for
   // are the ones in long line searches (a D'Claw fingertip jammed against the cap: 100 iterations x 12 trials; profiles/r05_value_trials.md).
   bool vo = false;
+  // Helper slots (round 5).  What a launch waits for is its slowest environment's CHAIN of evaluations, and those chains are long line
+  // searches (D'Claw: a fingertip jammed against the cap, 100 iterations x 12 trials; TactileInsertion: one sub-step of 60 - 300 trials) —
+  // while the other slots of that wavefront have long finished their own environments and re-evaluate a final iterate for nothing.  The trial
+  // points of a backtracking are known in advance: dlbase + 2^-t dq, t = 0, 1, 2 ...  So a slot that is `done` evaluates trial t + j of a slot
+  // that is about to evaluate its trial t (same predictor, control, increment base and direction, read from that slot's LDS; the owner's
+  // parameter table with per-environment tables), and the owner then judges the results IN ORDER with the decision code of the sequential
+  // loop: a rejected own trial is followed at once by the helper's result for the next one, and so on.  A helper's point that is to be taken
+  // is adopted (its g and H copied from the helper's LDS) when the round computed tangents and a Newton step follows; otherwise the owner
+  // evaluates that point again itself, in full, exactly as the value-only trials do.  The evaluation is a function of its inputs only
+  // (reductions inside a slot are symmetric), so iterates, convergence flags, taped matrices and `evals` (trial points judged) are those of
+  // the loop without helpers, bit for bit (tests/test_gpu_exact_options.py); a line search of n trials takes ceil(n / (1 + helpers)) rounds.
+  // Not in launches that leave their final link records for tsim_readout (a helper's records are not its environment's).
+#define helpers_on (NS > 1 && !POLICY && a.helpers != 0 && !a.lockstep && a.poseR == nullptr)      /* (re-read from the kernel arguments where it is asked: no register held for it) */
+  if (helpers_on && !valid) { done = true; fs = false; ss = false; }      // an idle slot of the last wavefront helps from the start
+  int helped = 0;
 #ifdef TS_ROUND_STATS   // A/B builds only (tools/round_stats.py): rounds of this wavefront and its shader clocks, left in status / gnorm
   int rounds_ = 0; const long long rs_t0_ = clock64();
 #endif
@@ -240,7 +261,6 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
         c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
         if (lane < nr) { c.qpD[lane] = c.q0D[lane] + (double)c.h * (double)c.qd0[lane]; c.qp[lane] = (R)c.qpD[lane]; c.qdp[lane] = c.qd0[lane]; }
       }
-      sv = c.cv; sa = c.ca;
       if (lane < nr) c.dl[lane] = R(0);          // initial guess: the predictor
       gn = R(0); alpha = R(1); iter = 0; ls = -1; sub_evals = 0; crossings = 0; conv = false; fin = false; forced = false; vo = false;
       ss = false;
@@ -270,33 +290,118 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     //  * eval_budget (default 0 = none): an upper bound on the evaluations of one sub-step for throughput-minded roll-out collection;
     //    a sub-step cut short is flagged non-converged in status.
     const bool tang = a.vo_ls <= 0 || __any(!fin && !done && !held && !vo);      // does any live slot need H from this round?
-    evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, R(1), sv, sa, tang);
+    // ---- helper slots: who evaluates whose next trials this round (wave-uniform masks over the slots; see above).  Nothing of this is live
+    //      across the evaluation (the kernels hold one wavefront per SIMD on their register count): the helpers are set up here, the owners
+    //      find theirs again afterwards, from the same masks
+    auto slot_masks = [&](bool need, unsigned& cm, unsigned& nm) {
+      const unsigned long long cb = __ballot(done), nb = __ballot(need);
+      cm = 0; nm = 0;
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) { cm |= (unsigned)((cb >> (s_ * LPE)) & 1ull) << s_; nm |= (unsigned)((nb >> (s_ * LPE)) & 1ull) << s_; }
+    };
+    auto nth = [](unsigned mask, int n) { int r = 0;
+#pragma unroll
+      for (int s_ = 0; s_ < NS; ++s_) { if ((mask >> s_) & 1u) { if (n == 0) r = s_; --n; } } return r; };
+    // (nothing to set up — and nothing spent on it — while every slot still has its own environment)
+    if (TS_UNLIKELY(helpers_on && __any(done))) {               // (cold code: laid out behind the loop's straight-line path)
+      const bool need = !done && !fin && !held && ls >= 0 && !forced;      // in a line search: this round evaluates trial ls, the next would be ls + 1
+      unsigned cm, nm; slot_masks(need, cm, nm);
+      if (cm != 0 && nm != 0) {                   // wave-uniform
+        const int m = __popc(nm);
+        int owner = slot, off = 0;
+        if (done) { const int j = __popc(cm & ((1u << slot) - 1u)); owner = nth(nm, j % m); off = 1 + j / m; }      // helper j serves owner j mod m with its trial + 1 + j / m
+        // the owner's loop state (identical in all lanes of its slot) travels through the LDS crossbar; every lane takes part
+        const int src = owner * LPE + lane;
+        const int ols = lane_gather(ls, src);
+        const R oalpha = lane_gather(alpha, src), ocv = lane_gather(c.cv, src), oca = lane_gather(c.ca, src);
+        if (done && ols + off <= c.max_ls) {
+          const int d = (owner - slot) * ts_lds_env_reals(c.nl, nr, nu, (int)sizeof(R));   // this slot's LDS arrays -> the owner's
+          const R ah = oalpha * (off == 1 ? R(0.5) : off == 2 ? R(0.25) : R(0.125));
+          if (lane < nr) {
+            c.qp[lane] = c.qp[lane + d]; c.qdp[lane] = c.qdp[lane + d];
+            c.qpD[lane] = (c.qpD + d * (int)sizeof(R) / 8)[lane];
+            c.dl[lane] = ts_trial_point(dlbase[lane + d], ah, c.dq[lane + d]);
+          }
+          if (lane < nu) c.u[lane] = c.u[lane + d];
+          c.cv = ocv; c.ca = oca;                 // (a finished slot has no use for its own any more)
+          if (a.Fenv) c.F = lds + owner * (a.fstride + 2);      // the owner's parameter table (ctx_init: one per slot, at the start of the block's LDS)
+        }
+      }
+    }
+    TS_SYNC();
+    evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, R(1), c.cv, c.ca, tang);      // (seeds of the Newton matrix: (1, cv, ca))
     const R gnew = block_norm2<LPE>(c.g, nr, lane);
-    bool solve = false;
-    if (!fin && !done) {
-      // what the evaluation just done means for this slot: 0 the full step across a kink comes next, 1 the step is halved, 2 the point is taken
+    // ---- this slot's helpers of this round (cold code, as above): their number, their slots in the order of the trials they evaluated, and the
+    //      ||g|| they found — scalars, not arrays: a dynamically indexed array would live in scratch memory
+    int nh = 0, hs0 = slot, hs1 = slot, hs2 = slot;
+    R gh0 = gnew, gh1 = gnew, gh2 = gnew;
+    if (TS_UNLIKELY(helpers_on && __any(done))) {
+      if (a.Fenv) c.F = lds + slot * (a.fstride + 2);
+      const bool need = !done && !fin && !held && ls >= 0 && !forced;      // (the state the helpers were assigned from: nothing has changed it)
+      unsigned cm, nm; slot_masks(need, cm, nm);
+      if (cm != 0 && nm != 0) {
+        const int m = __popc(nm), kc = __popc(cm), r_ = __popc(nm & ((1u << slot) - 1u));
+        if (need) nh = r_ < kc ? (kc - r_ + m - 1) / m : 0;
+        hs0 = nh > 0 ? nth(cm, r_) : slot;
+        gh0 = lane_gather(gnew, hs0 * LPE + lane);
+        if (NS > 2) { hs1 = nh > 1 ? nth(cm, r_ + m) : slot; gh1 = lane_gather(gnew, hs1 * LPE + lane); }
+        if (NS > 3) { hs2 = nh > 2 ? nth(cm, r_ + 2 * m) : slot; gh2 = lane_gather(gnew, hs2 * LPE + lane); }
+      }
+    }
+    bool solve = false, take = false;
+    R gtake = gnew;
+    // What an evaluation means for this slot — gj = ||g|| at the trial point, evaluated by this slot itself (j = 0) or by its helper in slot hj (j > 0):
+    // the full step across a kink comes next / the step is halved / the point is taken.  Returns true iff the step was halved (c.dl is the next
+    // trial point then, and a helper may have evaluated exactly that point already).
+    auto judge = [&](const R gj, const int j, const int hj) -> bool {
       int action = 2;                        // the first evaluation of the sub-step, an accepted trial, or the step across a kink
-      if (ls >= 0 && !forced && (!ts_finite(gnew) || gnew >= gn)) {              // a rejected trial (a non-finite one is rejected too)
+      if (ls >= 0 && !forced && (!ts_finite(gj) || gj >= gn)) {              // a rejected trial (a non-finite one is rejected too)
         if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) action = 0;
         else if (ls < c.max_ls) action = 1;
       }                                      // (else: the literal loop takes the last trial anyway)
-      bool take = false;                     // the point just evaluated becomes the iterate
-      if (action == 2 && !tang) vo = false;  // to be taken, but evaluated without tangents: the same point again, in full (nothing else changes)
-      else {
-        ++evals; ++sub_evals;
-        if (action == 0) {
-          ++crossings; forced = true; vo = false;      // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
-          if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
-        } else if (action == 1) {            // halve the step
-          alpha *= R(0.5); ++ls;
-          vo = a.vo_ls > 0 && ls >= a.vo_ls;
-          if (lane < nr) c.dl[lane] = dlbase[lane] + alpha * c.dq[lane];
-        } else { take = true; vo = false; }
+      if (action == 2) {
+        // to be taken — which needs H of this point in this slot's LDS.  Its own evaluation without tangents: the same point again, in full
+        // (nothing else changes).  A helper's: adopted if it came with tangents and a Newton step follows from it; if the sub-step ends
+        // there (its records, q and qd are the frame's), or without tangents, this slot evaluates the point again itself.
+        vo = false;
+        bool usable = tang;
+        if (j > 0) usable = tang && ts_finite(gj) && gj >= c.tol && iter + 1 < c.max_iter && !(a.eval_budget > 0 && sub_evals + 1 >= a.eval_budget);
+        if (usable) {
+          ++evals; ++sub_evals; take = true; gtake = gj;
+          if (j > 0) {
+            const int d = (hj - slot) * ts_lds_env_reals(c.nl, nr, nu, (int)sizeof(R));
+            if (lane < nr) c.g[lane] = c.g[lane + d];
+            for (int e = lane; e < nr * nr; e += LPE) c.H[e] = c.H[e + d];
+          }
+        }
+        return false;
+      }
+      ++evals; ++sub_evals;
+      if (action == 0) {
+        ++crossings; forced = true; vo = false;      // close to convergence and no decrease down to 2^-TSIM_KINK_LS: the full step across the kink
+        if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
+        return false;
+      }
+      alpha *= R(0.5); ++ls;                 // halve the step
+      vo = a.vo_ls > 0 && ls >= a.vo_ls;
+      if (lane < nr) c.dl[lane] = ts_trial_point(dlbase[lane], alpha, c.dq[lane]);
+      return true;
+    };
+    if (!fin && !done) {
+      bool halved = judge(gnew, 0, slot);      // this slot's own evaluation (the one straight-line call of every round) ...
+      if (TS_UNLIKELY(nh > 0)) {               // ... then its helpers', in the order the sequential loop would have made those evaluations
+#pragma unroll 1
+        for (int j = 1; halved && j <= nh; ++j) {      // (a loop, not unrolled: the kernels are as large as the instruction cache)
+          const R gj = (NS > 3 && j == 3) ? gh2 : (NS > 2 && j == 2) ? gh1 : gh0;
+          const int hj = (NS > 3 && j == 3) ? hs2 : (NS > 2 && j == 2) ? hs1 : hs0;
+          ++helped;
+          halved = judge(gj, j, hj);
+        }
       }
       if (take) {
         forced = false;
         if (ls >= 0) ++iter;
-        gn = gnew;
+        gn = gtake;
         if (!ts_finite(gn)) { nonfinite = true; fin = true; }
         else if (gn < c.tol) { conv = true; fin = true; }
         else if (iter >= c.max_iter || (a.eval_budget > 0 && sub_evals >= a.eval_budget)) fin = true;
@@ -406,6 +511,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     }
     if (a.status && lane == 0) a.status[env] = bad | (nonfinite ? (1 << 30) : 0);
     if (a.evals && lane == 0) a.evals[env] = evals;
+    if (a.helped && lane == 0) a.helped[env] = helped;
     if (a.gnorm && lane == 0) a.gnorm[env] = (float)gmax;
 #ifdef TS_PP_TIME
     if (a.gnorm && lane == 0) a.gnorm[env] = (float)((double)pp_cycles_ / (double)(clock64() - pp_t0_));
@@ -415,6 +521,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
 #endif
   }
 }
+#undef helpers_on
 
 
 // ================================================================================================ backward kernel

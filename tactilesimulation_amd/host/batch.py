@@ -250,6 +250,12 @@ class BatchSim:
         capi.check(capi.lib().tsim_last_evals(self._h, out.ctypes.data_as(capi._ip)))
         return out
 
+    def last_helper_trials(self):
+        """Line-search trials of the most recent forward launch that a helper slot evaluated, per environment (include/tsim.h TSIM_OPT_TRIAL_HELPERS)."""
+        out = np.zeros(self.B, dtype=np.int32)
+        capi.check(capi.lib().tsim_last_helper_trials(self._h, out.ctypes.data_as(capi._ip)))
+        return out
+
     def last_gnorm(self):
         """Largest ||g|| any sub-step of the most recent forward launch ended with, per environment (float32 [B])."""
         out = np.zeros(self.B, dtype=np.float32)
@@ -278,7 +284,7 @@ class BatchSim:
         """Name of the kernel instantiation the next launch uses: "generic", "static:<model>", "param:<model>" (include/tsim.h)."""
         return capi.lib().tsim_kernel_variant(self._h).decode()
 
-    OPT_PAIR_CULL, OPT_VALUE_TRIALS = 1, 2
+    OPT_PAIR_CULL, OPT_VALUE_TRIALS, OPT_TRIAL_HELPERS = 1, 2, 3
 
     def set_option(self, option, value):
         """include/tsim.h tsim_set_option (TSIM_OPT_*)."""

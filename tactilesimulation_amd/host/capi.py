@@ -40,6 +40,7 @@ _SIGS = {
     "tsim_kernel_variant": (C.c_char_p, [_vp]),
     "tsim_set_option": (C.c_int, [_vp, C.c_int, C.c_int]), "tsim_get_option": (C.c_int, [_vp, C.c_int]),
     "tsim_last_evals": (C.c_int, [_vp, _ip]),
+    "tsim_last_helper_trials": (C.c_int, [_vp, _ip]),
     "tsim_set_solver_options": (C.c_int, [_vp, C.c_int, C.c_int]),
     "tsim_last_gnorm": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "tsim_last_error": (C.c_char_p, []),

@@ -1,10 +1,13 @@
-"""The two exact shortcuts of the residual evaluation (include/tsim.h tsim_set_option) against the plain evaluation, on every model of
+"""The exact shortcuts of the residual evaluation and of the line search (include/tsim.h tsim_set_option) against the plain evaluation, on every model of
 BASELINE.json's configs, in both precisions, generic and compiled-in kernels:
 
   TSIM_OPT_PAIR_CULL     a contact pair whose points' bounding sphere is out of reach of its primitive in every environment of a wavefront is
                          skipped, and the generic fp32 kernels test a point's fp32 distance before its double-precision one (csrc/tsim_eval.h phase2);
   TSIM_OPT_VALUE_TRIALS  line-search trials deep in a backtracking evaluate the residual without its tangents; a trial that is taken is
                          re-evaluated in full first (csrc/tsim_kernels.h k_forward).
+
+  TSIM_OPT_TRIAL_HELPERS the slots of a wavefront whose environments are finished evaluate the next trial points of a slot that is still in a
+                         line search; the owner judges the results in the sequential loop's order with its decision code (k_forward).
 
 What they skip contributes exact zeros / is never read, so a batch with both off — every pair staged, every point through the double-precision
 law, every trial a full evaluation — must give the SAME outputs, the same evaluation counts and the same gradients (torch.equal: up to the sign
@@ -34,12 +37,15 @@ def _case(name, B):
     return m, q0, u[:, :30], 1
 
 
-def _run(m, q0, u, S, dtype, cull, trials, static):
+def _run(m, q0, u, S, dtype, cull, trials, static, helpers=False, lanes=0):
     B, T = u.shape[0], u.shape[1]
     sim = BatchSim(m, B, dtype=dtype, tape_capacity=T * S)
     sim.set_static(static)
+    if lanes:
+        sim.set_lanes_per_env(lanes)
     sim.set_option(BatchSim.OPT_PAIR_CULL, cull)
     sim.set_option(BatchSim.OPT_VALUE_TRIALS, trials)
+    sim.set_option(BatchSim.OPT_TRIAL_HELPERS, helpers)
     assert sim.get_option(BatchSim.OPT_PAIR_CULL) == int(cull) and sim.get_option(BatchSim.OPT_VALUE_TRIALS) == trials
     sim.reset(torch.tensor(q0, device=DEV, dtype=dtype), None, backward_flag=True)
     ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dtype).transpose(0, 1).contiguous(), S, want_qd=True)
@@ -50,7 +56,7 @@ def _run(m, q0, u, S, dtype, cull, trials, static):
     wt = torch.randn(T, B, m.ndof_tactile, generator=g, dtype=torch.float64).to(DEV, dtype)
     du = sim.backward_episode(T, S, wq, wv, wt)
     lq, lv = sim.get_adjoint()
-    return ro, ev, du, lq, lv, sim.kernel_variant()
+    return ro, ev, du, lq, lv, sim.kernel_variant(), sim.last_helper_trials().copy(), sim.launch_info()["lanes_per_env"]
 
 
 def _same(a, b, tag):
@@ -83,3 +89,55 @@ def test_the_shortcuts_change_no_number_on_the_compiled_in_kernels(pusher_model)
     assert plain[5] == "static:pusher"
     for trials in (1, 2, 3):
         _same(_run(pusher_model, q0, u, 5, torch.float32, True, trials, True), plain, ("static pusher", trials))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("name,lanes", [("pusher", 16), ("pusher", 32), ("dclaw_position_control", 32), ("tactile_insertion", 32)])
+def test_helper_slots_change_no_number_on_the_generic_kernels(name, lanes, dtype):
+    """Finished slots evaluating another slot's next line-search trials: same iterates, flags, evaluation counts (trial points judged), taped matrices
+    (the gradients come from them) as the loop without helpers, with and without the other two shortcuts — and the helper path did run."""
+    B = 256
+    m, q0, u, S = _case(name, B)
+    plain = _run(m, q0, u, S, dtype, False, 0, False, helpers=False, lanes=lanes)
+    assert plain[5] == "generic" and int(plain[6].sum()) == 0
+    if plain[7] != lanes:
+        pytest.skip("launch shape falls back to %d lanes per environment" % plain[7])
+    for cull, trials in ((False, 0), (True, 2)):
+        r = _run(m, q0, u, S, dtype, cull, trials, False, helpers=True, lanes=lanes)
+        _same(r, plain, (name, str(dtype), lanes, cull, trials, "helpers"))
+        assert int(r[6].sum()) > 0 and (r[6] <= r[1]).all(), "no line-search trial was evaluated by a helper slot"
+
+
+@pytest.mark.parametrize("lanes", [16, 32])
+@pytest.mark.parametrize("tables", [False, True])
+def test_helper_slots_change_no_number_on_the_compiled_in_kernels(pusher_model, lanes, tables):
+    """... on the static TactilePush instantiations (fully static; structure-static with one parameter table per environment: the helper reads
+    the OWNER's table)."""
+    import tactilesimulation_amd.model.blob as BL
+    B = 1024
+    q0, u, _ = push_workload(B, 12, seed=8)
+    T, S, dtype = u.shape[1], 5, torch.float32
+
+    def run(helpers):
+        sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+        sim.set_lanes_per_env(lanes)
+        if tables:
+            tab = sim.base_tables()
+            fo = int(pusher_model.I[BL.TSIM_IH_FOFF_DOF])
+            g = torch.Generator().manual_seed(4)
+            tab[:, fo + BL.TSIM_DF_DAMPING] = (0.5 + torch.rand(B, generator=g)).to(tab)      # joint damping of dof 0, drawn per environment
+            sim.set_env_tables(tab)
+        sim.set_option(BatchSim.OPT_TRIAL_HELPERS, helpers)
+        sim.reset(torch.tensor(q0, device=DEV, dtype=dtype), None, backward_flag=True)
+        ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dtype).transpose(0, 1).contiguous(), S, want_qd=True)
+        ev = sim.last_evals().copy()
+        g = torch.Generator().manual_seed(9)
+        wq, wv, wt = (torch.randn(T, B, n, generator=g).to(DEV) for n in (7, 6, 390))
+        du = sim.backward_episode(T, S, wq, wv, wt)
+        lq, lv = sim.get_adjoint()
+        return ro, ev, du, lq, lv, sim.kernel_variant(), sim.last_helper_trials().copy()
+
+    plain, r = run(False), run(True)
+    assert r[5] == ("param:pusher" if tables else "static:pusher") and plain[5] == r[5]
+    _same(r, plain, ("static pusher", lanes, tables, "helpers"))
+    assert int(plain[6].sum()) == 0 and int(r[6].sum()) > 0

@@ -29,7 +29,7 @@ def _run(sim, q0, u, T, S, wq, wv, wt):
     return ro, ev, du, lq, lv
 
 
-def test_static_pusher_kernels_equal_the_generic_ones_bit_for_bit(pusher_model):
+def test_static_pusher_kernels_agree_with_the_generic_ones_to_fp32_rounding(pusher_model):
     B, T, S = 4096, 12, 5
     q0, u, _ = push_workload(B, T, seed=5)
     g = torch.Generator().manual_seed(2)
@@ -47,7 +47,18 @@ def test_static_pusher_kernels_equal_the_generic_ones_bit_for_bit(pusher_model):
     rel = lambda x, y: float((x - y).abs().max()) / max(float(y.abs().max()), 1e-30)
     assert torch.equal(ra[0]["status"], rb[0]["status"]) and int(ra[0]["status"].abs().max()) == 0
     assert float((ra[0]["q"] - rb[0]["q"]).abs().max()) < 5e-6 and float((ra[0]["qd"] - rb[0]["qd"]).abs().max()) < 2e-4
-    assert rel(ra[0]["var"], rb[0]["var"]) < 1e-5 and rel(ra[0]["tactile"], rb[0]["tactile"]) < 1e-4
+    assert rel(ra[0]["var"], rb[0]["var"]) < 1e-5
+    # tactile forces: both are fp32 roundings of the fp64 kernels' values, which are the third party here — per environment, relative to the
+    # batch's largest taxel force: 99.9 % of the environments within 2e-5 of fp64 on either path, every environment within 2e-4 (measured: static
+    # 6.3e-5, generic 1.2e-4 in ONE environment of 4096 whose Newton iteration takes one evaluation less than in fp64; profiles/r05_static_vs_generic.json)
+    d = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0)
+    d.reset(torch.tensor(q0, device=DEV, dtype=torch.float64), None, backward_flag=False)
+    rd = d.rollout(torch.tensor(u, device=DEV, dtype=torch.float64).transpose(0, 1).contiguous(), S)
+    tmax = float(rd["tactile"].abs().max())
+    for name, r in (("static", ra), ("generic", rb)):
+        e = (r[0]["tactile"].double() - rd["tactile"]).abs().amax(dim=(0, 2)) / tmax
+        assert float(e.max()) < 2e-4 and float(torch.quantile(e, 0.999)) < 2e-5, (name, float(e.max()), float(torch.quantile(e, 0.999)))
+    assert rel(ra[0]["tactile"], rb[0]["tactile"]) < 3e-4
     assert float(ra[0]["tactile"].abs().max()) > 0
     assert (ra[1] == rb[1]).mean() > 0.99 and abs(int(ra[1].sum()) - int(rb[1].sum())) < 1e-3 * rb[1].sum()      # Newton work
     # gradients, environment by environment (du [T, B, nu], adjoints [B, nr]): two fp32 roundings of one trajectory agree to ~1e-6 unless it
@@ -57,7 +68,7 @@ def test_static_pusher_kernels_equal_the_generic_ones_bit_for_bit(pusher_model):
         return ((x - y).abs().max(1).values / y.abs().max(1).values.clamp_min(1e-30)).cpu().numpy()
     errs = {name: per_env(x, y) for x, y, name in ((ra[2], rb[2], "du"), (ra[3], rb[3], "lamq"), (ra[4], rb[4], "lamv"))}
     for name, e in errs.items():
-        assert np.median(e) < 1e-5 and (e < 1e-4).mean() > 0.995 and e.max() < 0.2, (name, float(np.median(e)), float((e < 1e-4).mean()), float(e.max()))
+        assert np.median(e) < 1e-5 and (e < 1e-4).mean() > 0.995 and (e > 1e-2).sum() <= 2 and e.max() < 0.2, (name, float(np.median(e)), float((e < 1e-4).mean()), int((e > 1e-2).sum()), float(e.max()))
     from _report import rep
     rep("static_vs_generic", q=float((ra[0]["q"] - rb[0]["q"]).abs().max()), qd=float((ra[0]["qd"] - rb[0]["qd"]).abs().max()), tactile=rel(ra[0]["tactile"], rb[0]["tactile"]),
         du_median=float(np.median(errs["du"])), du_p999=float(np.quantile(errs["du"], 0.999)), du_max=float(errs["du"].max()), du_within_1e4=float((errs["du"] < 1e-4).mean()),

@@ -27,4 +27,31 @@ d)  # the shortcuts A/B in one process (launch-by-launch times): D'Claw, Tactile
   for w in dclaw insertion push_fwd push; do timeout 600 python tools/option_ab.py $w >> ${O}_option_ab.jsonl 2>> ${O}_option_ab.err; done
   timeout 600 python tools/option_ab.py dclaw 8192 3 >> ${O}_option_ab.jsonl 2>> ${O}_option_ab.err
   ;;
+e)  # re-entry: where an evaluation's cycles go (generic kernels, D'Claw / TactileInsertion), the shortcuts A/B, evaluation totals per environment, static vs generic tolerance
+  for w in dclaw insertion; do for l in 32 16; do timeout 300 python tools/eval_stamps.py $w $l 20 >> ${O}_stamps.jsonl 2>> ${O}_stamps.err; done; done
+  timeout 300 python tools/static_vs_generic_probe.py > ${O}_static_vs_generic.json 2> ${O}_static_vs_generic.err
+  for w in dclaw insertion; do timeout 300 python tools/evals_distribution.py $w >> ${O}_evals.jsonl 2>> ${O}_evals.err; done
+  timeout 300 python tools/evals_distribution.py dclaw 8192 >> ${O}_evals.jsonl 2>> ${O}_evals.err
+  for w in dclaw insertion; do timeout 600 python tools/option_ab.py $w >> ${O}_option_ab.jsonl 2>> ${O}_option_ab.err; done
+  timeout 600 python tools/option_ab.py dclaw 8192 3 >> ${O}_option_ab.jsonl 2>> ${O}_option_ab.err
+  ;;
+f)  # helper slots: exactness, then the legs with the option off / on (one process per leg: launch-by-launch times)
+  timeout 900 python -m pytest tests/test_gpu_exact_options.py -x -q -m gpu 2>&1 | tail -15 > ${O}_tests.log
+  for w in dclaw insertion push_fwd push; do timeout 600 python tools/helpers_ab.py $w >> ${O}_helpers_ab.jsonl 2>> ${O}_helpers_ab.err; done
+  timeout 600 python tools/helpers_ab.py dclaw 8192 3 >> ${O}_helpers_ab.jsonl 2>> ${O}_helpers_ab.err
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > ${O}_bench.json 2> ${O}_bench.err
+  ;;
+g)  # headline with the helper slots compiled in: option on / off, three runs each (timed region only)
+  timeout 300 python -m pytest tests/test_gpu_exact_options.py -x -q -m gpu 2>&1 | tail -3 > ${O}_tests.log
+  for i in 1 2 3; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --timed-only --no-pmc >> ${O}_on.jsonl 2>> ${O}_on.err
+    TSIM_NO_TRIAL_HELPERS=1 timeout 300 python bench.py --steps 20 --warmup 5 --timed-only --no-pmc >> ${O}_off.jsonl 2>> ${O}_off.err
+  done
+  ;;
+h)  # headline: this build against an A/B library (csrc/ab/libtsim_$2.so), interleaved, timed region only
+  for i in 1 2 3; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --timed-only --no-pmc >> ${O}_new.jsonl 2>> ${O}_new.err
+    TSIM_HIP_LIB=$PWD/tactilesimulation_amd/csrc/ab/libtsim_$2.so timeout 300 python bench.py --steps 20 --warmup 5 --timed-only --no-pmc >> ${O}_$2.jsonl 2>> ${O}_$2.err
+  done
+  ;;
 esac
