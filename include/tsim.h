@@ -200,7 +200,11 @@ const char* tsim_kernel_variant(const tsim_batch* b);
  *                       in a line search; the owner judges the results in the order and with the decision code of the sequential loop.
  *                       Exact: iterates, convergence flags, taped matrices and tsim_last_evals are those of the loop without helpers
  *                       (tests/test_gpu_exact_options.py); a line search of n trials takes ceil(n / (1 + helpers)) rounds. */
-enum { TSIM_OPT_PAIR_CULL = 1, TSIM_OPT_VALUE_TRIALS = 2, TSIM_OPT_TRIAL_HELPERS = 3 };
+/*   TSIM_OPT_VALUE_FIRST (default 1; environment variable TSIM_NO_VALUE_FIRST=1 at creation: 0)  launches that record no tape (roll-out collection:
+ *                       tsim_reset with backward_flag 0) never use the Newton matrix of a sub-step's FINAL iterate.  Where the previous sub-step
+ *                       of an environment converged in one Newton step, the first trial of the next one evaluates the residual without its
+ *                       tangents; it is taken as it is if it ends the sub-step, and evaluated again in full otherwise.  Exact, as above. */
+enum { TSIM_OPT_PAIR_CULL = 1, TSIM_OPT_VALUE_TRIALS = 2, TSIM_OPT_TRIAL_HELPERS = 3, TSIM_OPT_VALUE_FIRST = 4 };
 int tsim_set_option(tsim_batch* b, int option, int value);
 int tsim_get_option(const tsim_batch* b, int option);
 

@@ -436,6 +436,7 @@ struct tsim_batch {
   int n_simd;                    // SIMDs of the device (CUs x 4)
   int value_trials = 2;          // line-search trials after this many rejected ones evaluate the residual only (0: off; tsim_set_option TSIM_OPT_VALUE_TRIALS; TSIM_VALUE_TRIALS=n at creation)
   int trial_helpers = 1;        // finished slots of a wavefront evaluate the next line-search trials of a slot that is still in one (tsim_set_option TSIM_OPT_TRIAL_HELPERS; TSIM_NO_TRIAL_HELPERS=1 at creation: off)
+  int value_first = 1;           // launches without a tape: the first trial after a Newton step evaluates the residual only where the previous sub-step converged in one step (tsim_set_option TSIM_OPT_VALUE_FIRST; TSIM_NO_VALUE_FIRST=1 at creation: off)
   int pair_cull = 1;             // phase 2 skips contact pairs out of reach of their primitive (tsim_set_option TSIM_OPT_PAIR_CULL; TSIM_NO_PAIR_CULL=1 at creation: off)
   // Compiled-in models (csrc/tsim_static.h).  static_id: the model whose STRUCTURE the batch's blob has (ints + the structural floats: 1 TactilePush);
   // static_exact: every float record equals the compiled asset's bit for bit as well (the fully static instantiation); env_struct_ok: the
@@ -790,7 +791,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.tape = (R*)b->tape; a.u = (const R*)u;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->B >= 256 && nframes == 1 && b->order_valid) ? b->order : (b->B >= 256 && nframes > 1 && b->order_ep_n == nframes * nsub && !getenv("TSIM_NO_EPISODE_LPT")) ? b->order_ep : nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
-  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials; a.helpers = b->trial_helpers; a.helped = b->helped;
+  a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials; a.vo_first = b->value_first; a.helpers = b->trial_helpers; a.helped = b->helped;
   const bool emit = pose_emit(b, st);
   a.nspt = b->nspt;
   if (emit) { a.poseR = (R*)b->poseR; a.poseD = b->poseD; }
@@ -886,6 +887,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->pair_cull = getenv("TSIM_NO_PAIR_CULL") ? 0 : 1;
   b->no_static = getenv("TSIM_NO_STATIC") != nullptr;
   b->trial_helpers = getenv("TSIM_NO_TRIAL_HELPERS") ? 0 : 1;
+  b->value_first = getenv("TSIM_NO_VALUE_FIRST") ? 0 : 1;
   if (const char* e = getenv("TSIM_VALUE_TRIALS")) b->value_trials = std::max(0, atoi(e));
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }
   b->cross_kinks = dtype == TSIM_F32 ? 1 : 0;
@@ -961,12 +963,14 @@ int tsim_set_option(tsim_batch* b, int option, int value) {
   if (option == TSIM_OPT_PAIR_CULL) { b->pair_cull = value != 0; return 0; }
   if (option == TSIM_OPT_VALUE_TRIALS) { if (value < 0) return fail("set_option: TSIM_OPT_VALUE_TRIALS >= 0"); b->value_trials = value; return 0; }
   if (option == TSIM_OPT_TRIAL_HELPERS) { b->trial_helpers = value != 0; return 0; }
+  if (option == TSIM_OPT_VALUE_FIRST) { b->value_first = value != 0; return 0; }
   return fail("set_option: unknown option " + std::to_string(option));
 }
 int tsim_get_option(const tsim_batch* b, int option) {
   if (option == TSIM_OPT_PAIR_CULL) return b->pair_cull;
   if (option == TSIM_OPT_VALUE_TRIALS) return b->value_trials;
   if (option == TSIM_OPT_TRIAL_HELPERS) return b->trial_helpers;
+  if (option == TSIM_OPT_VALUE_FIRST) return b->value_first;
   return -1;
 }
 int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {

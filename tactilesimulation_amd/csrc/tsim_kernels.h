@@ -107,6 +107,7 @@ template <class R> struct FwdArgs {
   int cull = 0;                // phase 2 skips contact pairs out of reach of their primitive (Ctx::cull)
   int vo_ls = 0;               // > 0: line-search trials after vo_ls rejected ones evaluate the residual only (k_forward, main loop; tsim_set_option TSIM_OPT_VALUE_TRIALS)
   int* helped = nullptr;        // [B] line-search trials of the launch that a helper slot evaluated for this environment (tsim_last_helper_trials)
+  int vo_first = 0;            // forward-only launches: the first trial after a Newton step is evaluated without tangents where the previous sub-step converged in one step (k_forward; TSIM_OPT_VALUE_FIRST)
   int helpers = 0;             // slots that have finished their environment evaluate the NEXT line-search trials of a slot that is still in one (k_forward, main loop; TSIM_OPT_TRIAL_HELPERS)
 };
 
@@ -212,6 +213,20 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
 #define helpers_on (NS > 1 && !POLICY && a.helpers != 0 && !a.lockstep && a.poseR == nullptr)      /* (re-read from the kernel arguments where it is asked: no register held for it) */
   if (helpers_on && !valid) { done = true; fs = false; ss = false; }      // an idle slot of the last wavefront helps from the start
   int helped = 0;
+  // Value-first trials (round 5; launches that record no tape).  A sub-step whose Newton iteration converges in ONE step — nearly all of them:
+  // 2.07 evaluations per sub-step on TactileInsertion, 2.5 on D'Claw and TactilePush — is an evaluation at the predictor (g and H: the Newton step)
+  // and one at the new point, of which only ||g|| < tol is used: H of the final iterate goes to the tape, and there is none.  So where the
+  // Newton step just solved is expected to END the sub-step (`kq` below), its first trial is marked value-only like the deep line-search trials: if it
+  // ends the sub-step (converged, or out of iterations / budget) it is taken as it is — q, qd, the link records are those of a full evaluation —
+  // otherwise it is evaluated again in full (H for the next step) exactly as the value-only trials are.  A round is value-only only if no live slot
+  // needs H from it, and free-running slots drift out of phase (one at its predictor while the other is at its trial: every round full); a slot
+  // about to START a sub-step therefore waits ONE round — at most once per sub-step — when that makes the round value-only, which puts it in
+  // phase with the others.  Same iterates, flags and evaluation counts as without the option (tests/test_gpu_exact_options.py).
+  const bool vfirst = a.vo_first != 0 && a.record == 0 && !POLICY && !a.lockstep;
+  // `kq`: the last measured contraction of a full Newton step of this slot, ||g_new|| / ||g||^2 (quadratic convergence: roughly a constant of
+  // the problem) — the first trial after a step from residual gn is expected to end the sub-step if kq gn^2 is well below tol.
+  R kq = R(1e30);
+  bool waited = false;
 #ifdef TS_ROUND_STATS   // A/B builds only (tools/round_stats.py): rounds of this wavefront and its shader clocks, left in status / gnorm
   int rounds_ = 0; const long long rs_t0_ = clock64();
 #endif
@@ -247,7 +262,14 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       tslot = a.tac_slot ? a.tac_slot[f] : f;      // used at the end of the frame: fetched here, the load is long done by then
       fs = false;
     }
-    if (ss) {
+    bool wait_ = false;                        // this slot sits this round out (see `vfirst` above): it re-evaluates its last point, nothing is judged
+    if (vfirst) {
+      const bool live = !done && !held && !fin;
+      if (__any(live && !ss && vo && ls == 0) && !__any(live && !ss && !vo)) wait_ = ss && !done && !waited;      // (ls == 0: a slot at such a first trial — one deep in a line search is value-only round after round, there is no phase to meet)
+      if (wait_) waited = true;
+    }
+    if (ss && !wait_) {
+      waited = false;
       // force-free predictor of the implicit step and the coefficients of qd1, qdd1 in the increment
       if (bdf2_model && has_prev) {
         c.cv = R(1.5) / c.h; c.ca = R(2.25) / (c.h * c.h);
@@ -289,7 +311,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     //    TactileInsertion grasp (||g|| ~ 1e-3, steps of 0.02 - 0.5) that reached roots 0.15 rad away from the literal one.
     //  * eval_budget (default 0 = none): an upper bound on the evaluations of one sub-step for throughput-minded roll-out collection;
     //    a sub-step cut short is flagged non-converged in status.
-    const bool tang = a.vo_ls <= 0 || __any(!fin && !done && !held && !vo);      // does any live slot need H from this round?
+    const bool tang = (a.vo_ls <= 0 && !vfirst) || __any(!fin && !done && !held && !vo && !wait_);      // does any live slot need H from this round?
     // ---- helper slots: who evaluates whose next trials this round (wave-uniform masks over the slots; see above).  Nothing of this is live
     //      across the evaluation (the kernels hold one wavefront per SIMD on their register count): the helpers are set up here, the owners
     //      find theirs again afterwards, from the same masks
@@ -304,7 +326,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       for (int s_ = 0; s_ < NS; ++s_) { if ((mask >> s_) & 1u) { if (n == 0) r = s_; --n; } } return r; };
     // (nothing to set up — and nothing spent on it — while every slot still has its own environment)
     if (TS_UNLIKELY(helpers_on && __any(done))) {               // (cold code: laid out behind the loop's straight-line path)
-      const bool need = !done && !fin && !held && ls >= 0 && !forced;      // in a line search: this round evaluates trial ls, the next would be ls + 1
+      const bool need = !done && !fin && !held && !wait_ && ls >= 0 && !forced;      // in a line search: this round evaluates trial ls, the next would be ls + 1
       unsigned cm, nm; slot_masks(need, cm, nm);
       if (cm != 0 && nm != 0) {                   // wave-uniform
         const int m = __popc(nm);
@@ -337,7 +359,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     R gh0 = gnew, gh1 = gnew, gh2 = gnew;
     if (TS_UNLIKELY(helpers_on && __any(done))) {
       if (a.Fenv) c.F = lds + slot * (a.fstride + 2);
-      const bool need = !done && !fin && !held && ls >= 0 && !forced;      // (the state the helpers were assigned from: nothing has changed it)
+      const bool need = !done && !fin && !held && !wait_ && ls >= 0 && !forced;      // (the state the helpers were assigned from: nothing has changed it)
       unsigned cm, nm; slot_masks(need, cm, nm);
       if (cm != 0 && nm != 0) {
         const int m = __popc(nm), kc = __popc(cm), r_ = __popc(nm & ((1u << slot) - 1u));
@@ -363,9 +385,12 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
         // to be taken — which needs H of this point in this slot's LDS.  Its own evaluation without tangents: the same point again, in full
         // (nothing else changes).  A helper's: adopted if it came with tangents and a Newton step follows from it; if the sub-step ends
         // there (its records, q and qd are the frame's), or without tangents, this slot evaluates the point again itself.
-        vo = false;
-        bool usable = tang;
-        if (j > 0) usable = tang && ts_finite(gj) && gj >= c.tol && iter + 1 < c.max_iter && !(a.eval_budget > 0 && sub_evals + 1 >= a.eval_budget);
+        // A launch that records no tape has no use for H of a point that ENDS the sub-step: this slot's own value-only evaluation of such a
+        // point is taken as it is, a helper's is evaluated again by this slot (its link records are the frame's) — value-only.
+        const bool ends = !ts_finite(gj) || gj < c.tol || (ls >= 0 && iter + 1 >= c.max_iter) || (a.eval_budget > 0 && sub_evals + 1 >= a.eval_budget);
+        const bool no_h = ends && a.record == 0;
+        bool usable = j == 0 ? (tang || no_h) : (tang && !ends);
+        vo = !usable && no_h && (a.vo_ls > 0 || vfirst);
         if (usable) {
           ++evals; ++sub_evals; take = true; gtake = gj;
           if (j > 0) {
@@ -387,7 +412,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       if (lane < nr) c.dl[lane] = ts_trial_point(dlbase[lane], alpha, c.dq[lane]);
       return true;
     };
-    if (!fin && !done) {
+    if (!fin && !done && !wait_) {
       bool halved = judge(gnew, 0, slot);      // this slot's own evaluation (the one straight-line call of every round) ...
       if (TS_UNLIKELY(nh > 0)) {               // ... then its helpers', in the order the sequential loop would have made those evaluations
 #pragma unroll 1
@@ -399,6 +424,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
         }
       }
       if (take) {
+        if (vfirst && ls >= 0) kq = (ls == 0 && !forced && gn > R(0)) ? gtake / (gn * gn) : R(1e30);      // a full Newton step taken at once: its contraction; a damped one: no prediction
         forced = false;
         if (ls >= 0) ++iter;
         gn = gtake;
@@ -416,6 +442,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
       solve_newton<R, NRM, LPE, double, ts_static_nr<MS>()>(c.H, c.rhs, c.dq, nr, false, lane, solve);      // (elimination in fp32: -0.7 %, not taken; profiles/r04_static_model.md)
       if (solve) {
         alpha = R(1); ls = 0;
+        vo = vfirst && kq * gn * gn < R(0.25) * c.tol;      // the trial that will most likely end the sub-step: ||g|| only (see `vfirst` above)
         if (lane < nr) c.dl[lane] = dlbase[lane] + c.dq[lane];
       }
       TS_SYNC();

@@ -37,7 +37,7 @@ def _case(name, B):
     return m, q0, u[:, :30], 1
 
 
-def _run(m, q0, u, S, dtype, cull, trials, static, helpers=False, lanes=0):
+def _run(m, q0, u, S, dtype, cull, trials, static, helpers=False, lanes=0, first=False, record=True):
     B, T = u.shape[0], u.shape[1]
     sim = BatchSim(m, B, dtype=dtype, tape_capacity=T * S)
     sim.set_static(static)
@@ -46,10 +46,14 @@ def _run(m, q0, u, S, dtype, cull, trials, static, helpers=False, lanes=0):
     sim.set_option(BatchSim.OPT_PAIR_CULL, cull)
     sim.set_option(BatchSim.OPT_VALUE_TRIALS, trials)
     sim.set_option(BatchSim.OPT_TRIAL_HELPERS, helpers)
+    sim.set_option(BatchSim.OPT_VALUE_FIRST, first)
     assert sim.get_option(BatchSim.OPT_PAIR_CULL) == int(cull) and sim.get_option(BatchSim.OPT_VALUE_TRIALS) == trials
-    sim.reset(torch.tensor(q0, device=DEV, dtype=dtype), None, backward_flag=True)
+    sim.reset(torch.tensor(q0, device=DEV, dtype=dtype), None, backward_flag=record)
     ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dtype).transpose(0, 1).contiguous(), S, want_qd=True)
     ev = sim.last_evals().copy()
+    if not record:
+        z = torch.zeros(1)
+        return ro, ev, z, z, z, sim.kernel_variant(), sim.last_helper_trials().copy(), sim.launch_info()["lanes_per_env"]
     g = torch.Generator().manual_seed(9)
     wq = torch.randn(T, B, m.ndof_r, generator=g, dtype=torch.float64).to(DEV, dtype)
     wv = torch.randn(T, B, m.ndof_var, generator=g, dtype=torch.float64).to(DEV, dtype) if m.ndof_var else None
@@ -141,3 +145,22 @@ def test_helper_slots_change_no_number_on_the_compiled_in_kernels(pusher_model, 
     assert r[5] == ("param:pusher" if tables else "static:pusher") and plain[5] == r[5]
     _same(r, plain, ("static pusher", lanes, tables, "helpers"))
     assert int(plain[6].sum()) == 0 and int(r[6].sum()) > 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("name,lanes,static", [("pusher", 16, False), ("pusher", 32, False), ("pusher", 16, True), ("pusher", 64, True), ("dclaw_position_control", 32, False),
+                                               ("tactile_insertion", 32, False), ("tactile_insertion", 64, False)])
+def test_value_first_trials_change_no_number_in_forward_only_launches(name, lanes, static, dtype):
+    """TSIM_OPT_VALUE_FIRST on launches that record no tape (roll-out collection): states, outputs, flags and evaluation counts of the loop
+    without it — alone, and together with the other three shortcuts."""
+    if static and dtype == torch.float64:
+        pytest.skip("the compiled-in kernels are fp32")
+    B = 256
+    m, q0, u, S = _case(name, B)
+    plain = _run(m, q0, u, S, dtype, False, 0, static, lanes=lanes, record=False)
+    if plain[7] != lanes:
+        pytest.skip("launch shape falls back to %d lanes per environment" % plain[7])
+    assert plain[5] == ("static:pusher" if static else "generic")
+    for cull, trials, helpers in ((False, 0, False), (True, 2, True)):
+        r = _run(m, q0, u, S, dtype, cull, trials, static, helpers=helpers, lanes=lanes, first=True, record=False)
+        _same(r, plain, (name, str(dtype), lanes, static, cull, trials, helpers, "value-first"))

@@ -54,4 +54,8 @@ h)  # headline: this build against an A/B library (csrc/ab/libtsim_$2.so), inter
     TSIM_HIP_LIB=$PWD/tactilesimulation_amd/csrc/ab/libtsim_$2.so timeout 300 python bench.py --steps 20 --warmup 5 --timed-only --no-pmc >> ${O}_$2.jsonl 2>> ${O}_$2.err
   done
   ;;
+i)  # value-first trials: exactness, the forward-only legs off / on, the headline against the round's first library
+  timeout 900 python -m pytest tests/test_gpu_exact_options.py -x -q -m gpu 2>&1 | tail -15 > ${O}_tests.log
+  for w in dclaw insertion push_fwd; do timeout 600 python tools/value_first_ab.py $w >> ${O}_value_first_ab.jsonl 2>> ${O}_value_first_ab.err; done
+  ;;
 esac
