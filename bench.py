@@ -152,6 +152,27 @@ def make_workload(name, B, T, S, rank, dev, tdt):
     return wl
 
 
+def kernel_record(sim, dtype, forward_only=False, policy=False):
+    """Which instantiation of the simulation kernels the batch's next launches run (include/tsim.h tsim_kernel_variant + the launch shape) and
+    what it uses: registers, spills, LDS, code bytes from the built code object's metadata (host/buildhash.py write_kernel_table)."""
+    from tactilesimulation_amd.host import buildhash
+    try:
+        table = json.load(open(buildhash.KERNELS_JSON))
+    except OSError:
+        table = {}
+    info = sim.launch_info()
+    variant = sim.kernel_variant()
+    I_ = np.asarray(sim.model.I)
+    has_exp = any(int(I_[int(I_[14]) + i * 8 + 1]) == 7 for i in range(int(I_[2])))      # a rotation-vector joint (include/tsim_blob.h TSIM_J_SPHERICAL_EXP): the EXPJ kernels
+    rec = {"variant": variant, "lanes_per_env": info["lanes_per_env"], "blocks": info["blocks"], "dynamic_lds_bytes": info["lds_bytes"],
+           "options": {"pair_cull": sim.get_option(sim.OPT_PAIR_CULL), "value_trials": sim.get_option(sim.OPT_VALUE_TRIALS),
+                       "trial_helpers": sim.get_option(sim.OPT_TRIAL_HELPERS), "value_first": sim.get_option(sim.OPT_VALUE_FIRST)}}
+    for k in ("k_forward",) + (() if forward_only else ("k_backward",)):
+        mangled, readable = buildhash.kernel_name(k, dtype, sim.ndof_r, has_exp, info["lanes_per_env"], variant, policy)
+        rec[k] = dict({"instantiation": readable, "symbol": mangled}, **(table.get(mangled) or {"metadata": "not found in %s" % os.path.basename(buildhash.KERNELS_JSON)}))
+    return rec
+
+
 class Leg:
     """One workload on one BatchSim: runs env-steps as episodes of <= T (forward all, then backward all) and keeps the HIP-event times
     of the launches of its timed part."""
@@ -285,7 +306,7 @@ class Leg:
                 "valu": None}, (dom, dom_ms, dom_frames)
 
 
-def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench"):
+def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench", pmc=False):
     """A short N = 1 leg of another BASELINE config (or of the headline workload in another dtype), reported inside the headline's JSON
     line: value, kernel times by HIP events, HBM roofline from the general formula of SURVEY.md §8d.  `steps` in env-steps (5 sub-steps)."""
     asset_, B, T, fwd_only, cfg = WORKLOADS[name]
@@ -303,13 +324,22 @@ def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench"):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     bad_sub, bad_env = leg.timed_nonconverged()
-    rl, _ = leg.roofline(esz)
+    rl, (dom, dom_ms, dom_frames) = leg.roofline(esz)
     info = leg.sim.launch_info()
     evals = leg.sim.last_evals()
+    helped = leg.sim.last_helper_trials()
+    krec = kernel_record(leg.sim, dtype, fwd_only)
     leg_solver = leg.solver
     del leg
     torch.cuda.empty_cache()
     S = wl["S"]
+    rl["kernel_instantiation"] = krec[dom]["instantiation"]
+    if pmc:      # the same counters as the headline's, from `bench.py --workload <name> --timed-only` under rocprofv3 --pmc (separate passes)
+        ns = argparse.Namespace(steps=T // fps, warmup=T // fps, dtype=dtype, workload=name, frame_skip=5, launch="episode", forward_only=False)
+        c = pmc_passes(ns, B, T, kernels=(dom,))
+        if c and dom in c:
+            fill_roofline_counters(rl, c[dom], "measured in this run: rocprofv3 --pmc passes of `bench.py --workload %s --timed-only`" % name, B, dom_frames, dom_ms)
+            rl["counters_per_launch"] = c
     return {"workload": cfg, "model": asset_, "batch": B, "dtype": dtype, "value": B * steps / dt, "unit": "env-steps/s",
             "solver": leg_solver,
             "what": ("forward only" if fwd_only else "forward + adjoint") + ", %s, episodes of %d frames, one launch per episode each way" % (
@@ -317,8 +347,11 @@ def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench"):
             "steps": steps, "ms_per_step": dt / steps * 1e3,
             # counted over the launches of the TIMED region itself (status is read after it)
             "nonconverged_envs": bad_env, "nonconverged_substeps": bad_sub, "substeps_timed": B * steps * fps * S,
-            "residual_evals_per_substep_last_launch": {"mean": float(evals.mean()) / (T * S), "max_env_total": int(evals.max())},
-            "launch_shape": info, "roofline": rl}
+            "residual_evals_per_substep_last_launch": {"mean": float(evals.mean()) / (T * S), "max_env_total": int(evals.max()), "mean_env_total": float(evals.mean()),
+                                                       # a launch lasts its slowest environment's chain: the share of the SIMD time of a launch that is idle by that alone
+                                                       "idle_share_if_launch_lasts_slowest_env": 1.0 - float(evals.mean()) / max(float(evals.max()), 1.0),
+                                                       "trials_evaluated_by_helper_slots": int(helped.sum()), "of_them_for_the_slowest_env": int(helped[int(evals.argmax())])},
+            "launch_shape": info, "kernel": krec, "roofline": rl}
 
 
 def plumbing_only(args, world, rank):
@@ -349,6 +382,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--frame-skip", type=int, default=5)
     ap.add_argument("--episode", type=int, default=None, help="env-steps per episode (tape length / frame_skip; default: the workload's)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps each; `value` is the median window (all are listed in `repeats`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic / roofline.valu then "
                     "come from the committed profile of this command, with the source stated)")
@@ -445,27 +479,39 @@ def main():
     if not args.timed_only:
         run_steps(T, False, args.launch)
     bad_warm = run_steps(args.warmup * fps, False, args.launch) if args.warmup > 0 else 0
-    sync_all()
-    t0 = time.perf_counter()
-    run_steps(args.steps * fps, True, args.launch)
-    torch.cuda.synchronize()
-    dt_own = time.perf_counter() - t0          # this rank's own work, before it waits for the others
-    sync_all()
-    dt = time.perf_counter() - t0
+    # The timed region of the contract — exactly K steps between barrier + synchronize on both sides, max over ranks — REPEATED (--repeats, default
+    # 5): at K = 20 the region is one forward and one backward launch, 4 ms, and run-to-run spread is +-5 %.  `value` is the MEDIAN window's;
+    # every window's value is listed next to it (`repeats`).  The HIP-event kernel times are those of all windows.
+    windows = []
+    for rep in range(max(1, args.repeats)):
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(args.steps * fps, True, args.launch)
+        torch.cuda.synchronize()
+        dt_own_ = time.perf_counter() - t0          # this rank's own work, before it waits for the others
+        sync_all()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt_], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        windows.append((dt_, dt_own_))
+    order_ = sorted(range(len(windows)), key=lambda i: windows[i][0])
+    dt, dt_own = windows[order_[len(order_) // 2]]
+    n_win = len(windows)
     per_rank = None
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
         # What a SCALE record needs to decompose its efficiency without another round: per rank, the kernel time of its launches (HIP
         # events), the all-reduce as its launching stream saw it (includes waiting for the slowest rank), and what is left of its own wall
         # clock — host launch gaps and idle time
         fm, _, _ = leg.ev_stats("fwd"); bm, _, _ = leg.ev_stats("bwd")
         ar = [a.elapsed_time(b) * 1e3 for a, b in leg.ar_ev]
-        k_ms = sum(a.elapsed_time(b) for a, b, _ in leg.ev["fwd"]) + sum(a.elapsed_time(b) for a, b, _ in leg.ev["bwd"])
+        k_ms = (sum(a.elapsed_time(b) for a, b, _ in leg.ev["fwd"]) + sum(a.elapsed_time(b) for a, b, _ in leg.ev["bwd"])) / n_win      # per window (the events cover all windows)
+        ar = ar[len(ar) - len(ar) // n_win:] if n_win > 1 and len(ar) >= n_win else ar                                                # the last window's all-reduces
         mine = {"rank": rank, "device": torch.cuda.get_device_name(dev), "k_forward_ms_per_launch": fm, "k_backward_ms_per_launch": bm,
-                "launches": len(leg.ev["fwd"]), "allreduce_us_mean": float(np.mean(ar)) if ar else None, "allreduce_us_max": float(np.max(ar)) if ar else None,
+                "launches": len(leg.ev["fwd"]) // n_win, "allreduce_us_mean": float(np.mean(ar)) if ar else None, "allreduce_us_max": float(np.max(ar)) if ar else None,
                 "own_wall_ms": dt_own * 1e3, "kernel_ms_total": k_ms, "allreduce_ms_total": sum(ar) / 1e3,
                 "host_gap_ms": dt_own * 1e3 - k_ms - sum(ar) / 1e3, "wait_for_slowest_rank_ms": (dt - dt_own) * 1e3}
         per_rank = [None] * world
@@ -477,6 +523,7 @@ def main():
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"timed_only": True, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                              "values": [B * world * args.steps / w[0] for w in windows], "kernel_variant": sim.kernel_variant(),
                               "kernel_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms}, "per_rank": per_rank}), flush=True)
         if world > 1:
             import torch.distributed as dist
@@ -522,6 +569,10 @@ def main():
                                    "%s; %s.xml, ndof_r %d, %d tactile values, frame_skip %d, batch %d envs/GPU, episodes of %d frames" % (cfg_text, asset_, nr, ntac, S, B, T),
                        "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
             "solver": leg.solver,
+            "repeats": {"windows": n_win, "steps_per_window": args.steps, "value_is": "median window", "values": [B * world * args.steps / w[0] for w in windows],
+                        "min": B * world * args.steps / max(w[0] for w in windows), "max": B * world * args.steps / min(w[0] for w in windows),
+                        "first": B * world * args.steps / windows[0][0], "timed_region_s_each": [w[0] for w in windows]},
+            "kernel": kernel_record(sim, args.dtype, forward_only),
             "ranks": {"world_size": world, "ranks_in_first_allreduce": ranks_seen, "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
                       "shared_gpu": share},
             "roofline": rl,
@@ -536,6 +587,7 @@ def main():
             "residual_evals_per_env_step": {"mean": float(evs.mean()), "p99": float(np.percentile(evs, 99)),
                                             "mean_of_per_step_max": float(evs.max(axis=1).mean()), "max": int(evs.max())},
         }
+        res["roofline"]["kernel_instantiation"] = res["kernel"][dom]["instantiation"]
         # free the batch before the other legs (tape: 0.6 GB) — and so that the profiled child runs see an idle GPU
         del sim, leg
         torch.cuda.empty_cache()
@@ -563,7 +615,7 @@ def main():
                     if key == "f64" and (args.dtype == "f64" or forward_only):
                         continue
                     try:
-                        res[key] = sub_record(nm, dty, dev)
+                        res[key] = sub_record(nm, dty, dev, pmc=(not args.no_pmc) and key in ("dclaw", "insertion"))
                     except Exception as e:      # the headline must not die with an optional leg
                         res[key] = {"error": repr(e)}
                     progress("sub-record %s done" % key)
@@ -617,7 +669,7 @@ def pmc_passes(args, B, T, kernels=("k_forward", "k_backward")):
             d = os.path.join(tmp, "p%d" % i)
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", str(args.steps), "--warmup", str(args.steps), "--batch", str(B), "--dtype", args.dtype, "--workload", args.workload,
-                   "--episode", str(T), "--frame-skip", str(args.frame_skip), "--launch", args.launch, "--timed-only", "--no-pmc",
+                   "--episode", str(T), "--frame-skip", str(args.frame_skip), "--launch", args.launch, "--timed-only", "--no-pmc", "--repeats", "1",
                    "--no-cpu-baseline"] + (["--forward-only"] if args.forward_only else [])
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
             per = {k: {} for k in kernels}

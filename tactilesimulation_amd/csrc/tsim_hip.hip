@@ -113,13 +113,9 @@ template <class R> struct TaxArgs { const int* I; const R* F; const R* Fenv; int
 enum { TX_MAXS = 16, TX_MAXK = 64 };
 // the three outputs of a taxel, as NON-TEMPORAL stores: the read-out is a pure write stream (0.49 GB at 1024 environments, 1.97 GB at 4096: 2 - 7 x
 // the Infinity Cache) that nothing on the device reads back.  Measured (profiles/r04_readout_hbm.md): 1024 environments 4.45 -> 5.40 TB/s,
-// 4096 environments 4.4 - 4.8 -> 4.7 - 5.0 TB/s; -DTS_TAX_PLAIN restores ordinary stores (A/B).
+// 4096 environments 4.4 - 4.8 -> 4.7 - 5.0 TB/s  (Ordinary stores, the A/B's losing side: profiles/r04_readout_hbm.md.)
 template <class R> __device__ __forceinline__ void ts_store3(R* o, R a, R b, R c) {
-#ifdef TS_TAX_PLAIN
-  o[0] = a; o[1] = b; o[2] = c;
-#else
   __builtin_nontemporal_store(a, o); __builtin_nontemporal_store(b, o + 1); __builtin_nontemporal_store(c, o + 2);
-#endif
 }
 // One taxel against the staged tables of its environment (LDS): per sensor the end of its taxel range, its first (sensor, primitive)
 // record and their number, its penalty parameters; per record the primitive type, its shape, the pose record (R part, double part) and
@@ -155,9 +151,6 @@ __device__ __forceinline__ void taxel_eval(int t, V3<R> xa, int nsensor, const i
     o1 = Fl.x * tp[6 * ntax] + Fl.y * tp[7 * ntax] + Fl.z * tp[8 * ntax];
     o2 = Fl.x * tp[9 * ntax] + Fl.y * tp[10 * ntax] + Fl.z * tp[11 * ntax];
   }
-#ifdef TS_TAX_ZEROS        // A/B only: the store pattern alone (no taxel arithmetic) — the ceiling of this write stream
-  o0 = o1 = o2 = R(0);
-#endif
   ts_store3(out + 3 * t, o0, o1, o2);
 }
 // bounding sphere of a (sensor, primitive) record in the sensor-link frame: centre c_A = -R_PA^T p_PA and (radius + margin)^2, < 0 for planes
@@ -170,9 +163,7 @@ template <class R> __device__ __forceinline__ void taxel_bound(const R* P, int p
   C[0] = cA.x; C[1] = cA.y; C[2] = cA.z;
   C[3] = rb < R(0) ? R(-1) : (rb + R(TS_FAR_MARGIN)) * (rb + R(TS_FAR_MARGIN));
 }
-#ifndef TS_TAX_UNROLL
-#define TS_TAX_UNROLL 2      // taxels per thread and loop iteration: their loads are in flight together (A/B: profiles/r03_readout_ab.md)
-#endif
+enum { TS_TAX_UNROLL = 2 };      // taxels per thread and loop iteration: their loads are in flight together (1 / 2 / 4 measured: profiles/r03_readout_ab.md)
 template <class R>
 __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
   const int rec_env = blockIdx.x, env = rec_env % a.B, frame = rec_env / a.B;
@@ -218,10 +209,7 @@ __global__ void __launch_bounds__(256) k_taxels(TaxArgs<R> a) {
     // Without the list a wavefront runs the ~1000-instruction law whenever ONE of its 64 taxels is near the primitive — 15 % of the
     // wavefronts of the RollingBall pad for 5 % of its taxels, and that was the kernel's time (12.4 M vector instructions for
     // 10.2 M taxels; profiles/r03_readout_ab.md).  A taxel's result does not depend on the lane that computes it: same bits as before.
-#ifndef TS_TAX_CH
-#define TS_TAX_CH 8
-#endif
-    enum { CH = TS_TAX_CH };
+    enum { CH = 8 };
     __shared__ int sList[256 * CH];
     __shared__ int sCount;
     const V3<R> cA = ldv(sC);
@@ -437,6 +425,9 @@ struct tsim_batch {
   int value_trials = 2;          // line-search trials after this many rejected ones evaluate the residual only (0: off; tsim_set_option TSIM_OPT_VALUE_TRIALS; TSIM_VALUE_TRIALS=n at creation)
   int trial_helpers = 1;        // finished slots of a wavefront evaluate the next line-search trials of a slot that is still in one (tsim_set_option TSIM_OPT_TRIAL_HELPERS; TSIM_NO_TRIAL_HELPERS=1 at creation: off)
   int value_first = 1;           // launches without a tape: the first trial after a Newton step evaluates the residual only where the previous sub-step converged in one step (tsim_set_option TSIM_OPT_VALUE_FIRST; TSIM_NO_VALUE_FIRST=1 at creation: off)
+  // A/B switches of the environment, read ONCE at creation (launches are on the host-bound path of the per-step collectors):
+  // TSIM_NO_EPISODE_LPT, TSIM_INKERNEL_READOUT, TSIM_NO_FREE_RUN, TSIM_LOCKSTEP, TSIM_TAXELS_PER_RECORD, TSIM_NO_ENVTAB_CPT
+  bool ab_no_episode_lpt = false, ab_inkernel_readout = false, ab_no_free_run = false, ab_lockstep = false, ab_taxels_per_record = false, ab_no_envtab_cpt = false;
   int pair_cull = 1;             // phase 2 skips contact pairs out of reach of their primitive (tsim_set_option TSIM_OPT_PAIR_CULL; TSIM_NO_PAIR_CULL=1 at creation: off)
   // Compiled-in models (csrc/tsim_static.h).  static_id: the model whose STRUCTURE the batch's blob has (ints + the structural floats: 1 TactilePush);
   // static_exact: every float record equals the compiled asset's bit for bit as well (the fully static instantiation); env_struct_ok: the
@@ -709,7 +700,7 @@ static LaunchShape launch_shape(const tsim_batch* b) {
 static void decide_stage_cpt(tsim_batch* b) {
   b->stage_cpt = 0;
   if ((size_t)3 * b->I[TSIM_IH_NCPT] * b->esz > TS_CPT_LDS_BYTES) return;
-  if (b->dFenv && getenv("TSIM_NO_ENVTAB_CPT")) return;      // A/B: the round-3 behaviour (contact points from global memory next to per-environment tables)
+  if (b->dFenv && b->ab_no_envtab_cpt) return;      // A/B: the round-3 behaviour (contact points from global memory next to per-environment tables)
   const int lpe0 = launch_shape(b).lpe;
   b->stage_cpt = 1;
   if (launch_shape(b).lpe != lpe0 || lds_bytes_for(b, 1) > 64 * 1024) b->stage_cpt = 0;
@@ -767,7 +758,7 @@ static int launch_taxels(tsim_batch* b, const void* poseR, const double* poseD, 
     b->tax_slots = (e_ == hipSuccess && per_cu > 0 ? per_cu : 4) * (b->n_simd / 4);
   }
   const long long nrec = (long long)frames * b->B;
-  if (nrec >= 4 * TXS_RPB && b->ntax <= TXS_MAX_TAXELS && b->nspt <= TXS_MAXK && b->I[TSIM_IH_NSENSOR] <= TXS_MAXS && !getenv("TSIM_TAXELS_PER_RECORD")) {
+  if (nrec >= 4 * TXS_RPB && b->ntax <= TXS_MAX_TAXELS && b->nspt <= TXS_MAXK && b->I[TSIM_IH_NSENSOR] <= TXS_MAXS && !b->ab_taxels_per_record) {
     TaxArgs<R> t{b->dI, (const R*)b->dF, (const R*)b->dFenv, b->nfrec, (const R*)poseR, poseD, b->nspt, (R*)tac_out, 0, b->B, tac_slot,
                  b->ntax, b->I[TSIM_IH_NSENSOR], b->I[TSIM_IH_FOFF_SENSOR], b->I[TSIM_IH_FOFF_PAIR], b->I[TSIM_IH_FOFF_TAXEL], b->tt_off};
     hipLaunchKernelGGL(k_taxels_small<R>, dim3((unsigned)((nrec + TXS_RPB - 1) / TXS_RPB)), dim3(256), 0, st, t, (int)nrec);
@@ -789,7 +780,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   FwdArgs<R> a;
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = tac_slot;
   a.tape = (R*)b->tape; a.u = (const R*)u;
-  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->B >= 256 && nframes == 1 && b->order_valid) ? b->order : (b->B >= 256 && nframes > 1 && b->order_ep_n == nframes * nsub && !getenv("TSIM_NO_EPISODE_LPT")) ? b->order_ep : nullptr;
+  a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = (b->B >= 256 && nframes == 1 && b->order_valid) ? b->order : (b->B >= 256 && nframes > 1 && b->order_ep_n == nframes * nsub && !b->ab_no_episode_lpt) ? b->order_ep : nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
   a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials; a.vo_first = b->value_first; a.helpers = b->trial_helpers; a.helped = b->helped;
   const bool emit = pose_emit(b, st);
@@ -800,7 +791,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   // (not when the per-frame pose records would take more than 1 GiB — 180-frame grasp episodes with 22 (sensor, primitive) combinations —: those
   // launches keep the in-kernel read-out)
   const size_t fpose_bytes = (size_t)nframes * b->B * (size_t)std::max(b->nspt, 1) * (TP_R_SIZE * b->esz + TP_D_SIZE * sizeof(double));
-  bool defer = tac_out && taxels_supported(b) && fpose_bytes <= ((size_t)1 << 30) && !getenv("TSIM_INKERNEL_READOUT");
+  bool defer = tac_out && taxels_supported(b) && fpose_bytes <= ((size_t)1 << 30) && !b->ab_inkernel_readout;
   if (defer && b->fpose_frames < nframes) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) defer = false;      // no allocation inside a capture: the in-kernel read-out
@@ -818,8 +809,8 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
     }
   }
   if (defer) { a.fposeR = (R*)b->fposeR; a.fposeD = b->fposeD; }
-  a.free_run = (defer || !tac_out || b->ntax == 0) && !getenv("TSIM_NO_FREE_RUN");
-  a.lockstep = getenv("TSIM_LOCKSTEP") ? 1 : 0;
+  a.free_run = (defer || !tac_out || b->ntax == 0) && !b->ab_no_free_run;
+  a.lockstep = b->ab_lockstep ? 1 : 0;
   if (a.lockstep) a.free_run = 0;
   TS_LAUNCH(k_forward, R, b, st, a);
   HIPCHK(hipGetLastError());
@@ -887,6 +878,9 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->pair_cull = getenv("TSIM_NO_PAIR_CULL") ? 0 : 1;
   b->no_static = getenv("TSIM_NO_STATIC") != nullptr;
   b->trial_helpers = getenv("TSIM_NO_TRIAL_HELPERS") ? 0 : 1;
+  b->ab_no_episode_lpt = getenv("TSIM_NO_EPISODE_LPT") != nullptr; b->ab_inkernel_readout = getenv("TSIM_INKERNEL_READOUT") != nullptr;
+  b->ab_no_free_run = getenv("TSIM_NO_FREE_RUN") != nullptr; b->ab_lockstep = getenv("TSIM_LOCKSTEP") != nullptr;
+  b->ab_taxels_per_record = getenv("TSIM_TAXELS_PER_RECORD") != nullptr; b->ab_no_envtab_cpt = getenv("TSIM_NO_ENVTAB_CPT") != nullptr;
   b->value_first = getenv("TSIM_NO_VALUE_FIRST") ? 0 : 1;
   if (const char* e = getenv("TSIM_VALUE_TRIALS")) b->value_trials = std::max(0, atoi(e));
   if (const char* e = getenv("TSIM_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->lpe_forced = v; }

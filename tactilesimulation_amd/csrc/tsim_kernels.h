@@ -112,11 +112,7 @@ template <class R> struct FwdArgs {
 };
 
 // -DTS_WAVES_PER_EU=n (A/B builds): ask the compiler for n wavefronts per SIMD in the two simulation kernels (2 -> at most 256 registers)
-#ifdef TS_NO_COLD_HINTS      // A/B
-#define TS_UNLIKELY(x) (x)
-#else
-#define TS_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#endif
+#define TS_UNLIKELY(x) __builtin_expect(!!(x), 0)      // cold code: laid out behind the loop's straight-line path
 #ifdef TS_WAVES_PER_EU
 #define TS_KLB __launch_bounds__(TS_WAVE, TS_WAVES_PER_EU)
 #else

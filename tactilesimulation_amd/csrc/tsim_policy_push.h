@@ -69,9 +69,6 @@ template <int LPE, class R> __device__ __forceinline__ PPScr<LPE, R> pp_scr(cons
 template <int NS, int ROWS, class R>
 __device__ __forceinline__ void pp_dense64(const R* W, int nrows, int wrows, const R* x0, int stride, R (&acc)[NS]) {
   const R* Wj = W + threadIdx.x;
-#ifdef TS_PP_SKIP_DENSE      // A/B builds only: what the weight streams cost (results are wrong)
-  nrows = 0;
-#endif
   for (int i0 = 0; i0 < nrows; i0 += ROWS) {
     R wb[ROWS];
 #pragma unroll
@@ -83,7 +80,7 @@ __device__ __forceinline__ void pp_dense64(const R* W, int nrows, int wrows, con
   }
 }
 
-// MFMA (fp32, four environments per wavefront; -DTS_PP_NO_MFMA builds the vector-ALU form for every shape: A/B).  The dense layers are the one contraction-shaped piece of this
+// MFMA (fp32, four environments per wavefront; every other shape and fp64 take the vector-ALU form pp_dense64).  The dense layers are the one contraction-shaped piece of this
 // path with a non-trivial K: out[unit j][env s] = sum_k W[k][j] x_s[k], i.e. per wavefront a (64 x K) (K x 4) product, K = 393 / 64.
 // v_mfma_f32_4x4x1_16b_f32 does one k of it per instruction: 16 blocks of (4 x 1)(1 x 4); block b takes A from lanes 4b .. 4b+3 (lane l: W[k][l],
 // exactly what the coalesced row load leaves in the lanes) and B from the same lanes (lane l: x_{l % 4}[k], one LDS read with a per-lane
@@ -91,10 +88,6 @@ __device__ __forceinline__ void pp_dense64(const R* W, int nrows, int wrows, con
 // 1 LDS read, 1 MFMA (8 cycles) against 1 load, 4 broadcast reads and 4 FMAs (16 cycles) on the vector ALU.  Full fp32 FMAs, another
 // summation order.  Result layout differs from pp_dense64 (lane = unit): lane 4b + s holds ITS environment's units 4b + i.
 // Measured: profiles/r04_mfma_ab.md (closed GD epoch 55.8 -> 55.4 ms, +0.8 %: kept).
-#ifndef TS_PP_NO_MFMA
-#define TS_PP_MFMA 1
-#endif
-#ifdef TS_PP_MFMA
 typedef float pp_v4f __attribute__((ext_vector_type(4)));
 template <int ROWS>
 __device__ __forceinline__ pp_v4f pp_dense64_mfma(const float* W, int nrows, int wrows, const float* x0, int stride) {
@@ -115,7 +108,6 @@ __device__ __forceinline__ pp_v4f pp_dense64_mfma(const float* W, int nrows, int
   }
   return (d0 + d1) + (d2 + d3);
 }
-#endif
 
 // Observation -> action for the environment of this slot.  tac_prev: the tactile frame the observation is built from (global; written by
 // this slot, hence the fence + bypassing loads).  q (double, the state before the frame) gives the goal in the gripper frame.
@@ -123,10 +115,6 @@ __device__ __forceinline__ pp_v4f pp_dense64_mfma(const float* W, int nrows, int
 template <int LPE, class R>
 __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, bool valid, const PushPolicy<R>& P, size_t rec /* f * B + env */, int env, const R* tac_prev) {
   constexpr int OPL = PP_HID / LPE;                    // hidden units per lane
-#ifdef TS_PP_SKIP_ALL        // A/B builds only: what the whole policy call costs (results are wrong)
-  if (lane < 6) c.u[lane] = (lane >= 3 && lane < 5) ? P.dist[rec * 2 + (lane - 3)] : R(0);
-  return;
-#endif
   // goal pose in the gripper frame: rotation by -yaw, then the gripper's position is subtracted (tactile_push_env.py:84-92)
   R gl[3];
   {
@@ -165,18 +153,12 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
   }
   TS_SYNC();
   R acc[NS], w[OPL];
-#ifdef TS_PP_MFMA
   constexpr bool kMfma = sizeof(R) == 4 && NS == 4;
-#else
-  constexpr bool kMfma = false;
-#endif
   if constexpr (kMfma) {
-#ifdef TS_PP_MFMA
     const pp_v4f d = pp_dense64_mfma<PP_ROWS1>((const float*)P.W1T, ts_u(P.nin_pad), ts_u(P.nin), (const float*)S.xs0, S.stride);
     const int u0 = (int)threadIdx.x & ~3, es = (int)threadIdx.x & 3;          // this lane: units u0 .. u0 + 3 of environment es
 #pragma unroll
     for (int i = 0; i < 4; ++i) S.hs0[es * S.stride + u0 + i] = pp_elu((R)d[i] + P.b1[u0 + i]);
-#endif
   } else {
     {
       const R bj = P.b1[threadIdx.x];
@@ -195,13 +177,11 @@ __device__ __forceinline__ void push_policy_forward(const Ctx<R>& c, int lane, b
     for (int o = 0; o < OPL; ++o) P.h1_out[rec * PP_HID + OPL * lane + o] = h1[o];
   }
   if constexpr (kMfma) {
-#ifdef TS_PP_MFMA
     const pp_v4f d = pp_dense64_mfma<PP_ROWS2>((const float*)P.W2T, PP_HID, PP_HID, (const float*)S.hs0, S.stride);
     const int u0 = (int)threadIdx.x & ~3, es = (int)threadIdx.x & 3;
     TS_SYNC();
 #pragma unroll
     for (int i = 0; i < 4; ++i) S.hs0[es * S.stride + PP_HID + u0 + i] = pp_elu((R)d[i] + P.b2[u0 + i]);
-#endif
   } else {
     {
       const R bj = P.b2[threadIdx.x];

@@ -86,3 +86,62 @@ def hip_sources():
 
 def hip_digest():
     return digest(hip_sources(), HIP_FLAGS + [u + ":" + " ".join(f) for u, f in HIP_UNITS])
+
+
+# ---------------------------------------------------------------------------------------------------- what the built kernels use
+KERNELS_JSON = HIP_SO + ".kernels.json"
+_LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def write_kernel_table(lib=None, out=None):
+    """Registers, spills, LDS and code bytes of every kernel of the built library, from the code object's own metadata (llvm-readelf --notes /
+    -s on the gfx950 image inside the .so), as JSON next to the library: bench.py names the instantiation it timed and quotes these."""
+    import json
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    lib, out = lib or HIP_SO, out or KERNELS_JSON
+    tmp = tempfile.mkdtemp(prefix="tsim_kt_")
+    try:
+        shutil.copy(lib, os.path.join(tmp, "lib.so"))
+        subprocess.run([os.path.join(_LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        table = {}
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            notes = subprocess.run([os.path.join(_LLVM, "llvm-readelf"), "--notes", f], cwd=tmp, capture_output=True, text=True, check=True).stdout
+            syms = subprocess.run([os.path.join(_LLVM, "llvm-readelf"), "-sW", f], cwd=tmp, capture_output=True, text=True, check=True).stdout
+            size = {}
+            for line in syms.splitlines():
+                t = line.split()
+                if len(t) >= 8 and t[3] == "FUNC":
+                    size[t[7]] = int(t[2])
+            for blk in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
+                blk = ".agpr_count:" + blk
+                g = lambda k: re.search(r"\.%s:\s+(\S+)" % k, blk)
+                name = g("name")
+                if not name:
+                    continue
+                name = name.group(1)
+                rec = {k: int(g(k).group(1)) for k in ("agpr_count", "vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count", "group_segment_fixed_size",
+                                                        "private_segment_fixed_size", "max_flat_workgroup_size") if g(k)}
+                rec["code_bytes"] = size.get(name)
+                table[name] = rec
+        with open(out, "w") as fh:
+            json.dump(table, fh, indent=0, sort_keys=True)
+        return table
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def kernel_name(kernel, dtype, nr, has_exp, lanes, variant, policy=False):
+    """Mangled name of the instantiation of k_forward / k_backward a batch launches (csrc/tsim_hip.hip TS_LAUNCH) and a readable form of it."""
+    nrm, expj, lpe = (16, True, 64) if has_exp else ((8 if nr <= 8 else 16), False, lanes)
+    if variant != "generic":
+        nrm = 8
+    ms = {"generic": ("v", "void"), "static:pusher": ("14TsStaticPusher", "TsStaticPusher"), "param:pusher": ("7TsParamI14TsStaticPusherE", "TsParam<TsStaticPusher>")}[variant]
+    r = {"f32": ("f", "float"), "f64": ("d", "double")}[dtype]
+    args = {"k_forward": "7FwdArgs", "k_backward": "7BwdArgs"}[kernel]
+    mangled = "_Z%d%sI%sLi%dELb%dELi%dELb%dE%sEv%sIT_E" % (len(kernel), kernel, r[0], nrm, int(expj), lpe, int(policy), ms[0], args)
+    return mangled, "%s<%s, NRM=%d, EXPJ=%s, LPE=%d, POLICY=%s, %s>" % (kernel, r[1], nrm, str(expj).lower(), lpe, str(policy).lower(), ms[1])

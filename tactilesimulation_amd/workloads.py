@@ -51,8 +51,8 @@ def dclaw_workload(B, T, seed=7):
 # The settled grasp every TactileInsertion episode starts from (envs/tactile_insertion_env.py:126-170, `generate_initial_pose`): fingers open at
 # -0.03 at height 0.2, 100 sub-steps to the grasp pose, the closing force ramped 0 -> 1 over 100 sub-steps, held for 300, the state lifted
 # by 0.029, 500 sub-steps of settling.  Computed ONCE ("computed once by the oracle"): these are the fp64 CPU
-# oracle's numbers (tests/test_insertion_workload.py recomputes them; the HIP path's own 1000 sub-steps land within 1e-9,
-# tests/test_gpu_configs.py).  Every sub-step of that script converges in <= 6 evaluations of the XML's Newton loop.
+# oracle's numbers (tests/test_reference_pins.py::test_insertion_settled_grasp_is_what_the_reference_script_produces recomputes them to 1e-12;
+# the HIP path's own 1000 sub-steps land within 2e-8, tests/test_gpu_reference_pins.py::test_settled_grasp_reproduced_by_the_kernels).  Every sub-step of that script converges in <= 6 evaluations of the XML's Newton loop.
 INSERTION_Q_REF = (-1.5060891958816560e-12, -1.4307747385982361e-15, 2.2585783843111251e-01, 3.4983025765399271e-17,
                    -2.2903846143541743e-02, -2.2903846134958005e-02, -5.6189946002572018e-12, 8.1323789918651949e-10,
                    2.5489690750464609e-02, -2.7179132731683355e-09, -1.6785018740271060e-14, 2.3422194581612920e-17)

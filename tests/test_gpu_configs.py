@@ -88,6 +88,7 @@ def test_config3_push_b4096_fwd_adjoint_fp32(pusher_model):
     sim = BatchSim(pusher_model, B, dtype=dt, tape_capacity=T * S)
     info = sim.launch_info()
     assert os.environ.get("TSIM_LPE") or (info["lanes_per_env"] == 16 and info["blocks"] == 1024), info   # the instantiation bench.py times (TSIM_LPE: the whole suite under a forced shape)
+    assert os.environ.get("TSIM_NO_STATIC") or (sim.static_model() == 1 and sim.kernel_variant() == "static:pusher")      # ... by name: the compiled-in TactilePush kernels, not the generic ones
     sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None, backward_flag=True)
     ud = torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous()
     ro = sim.rollout(ud, S, want_qd=True)
@@ -226,9 +227,11 @@ def test_fp32_gradients_within_1e4_where_branches_agree_b1024(pusher_model):
     # BASELINE.json configs[3]: D'Claw, 16 384 environments over 8 GPUs = 2048 per GPU, forward-only (PPO collection); here 12 of the
     # config's 200 env-steps at the real batch size and launch shape
     ("dclaw_position_control", 2048, 12, 6, 2e-5, 2e-3),
-    # configs[4]: TactileInsertion, 32 768 over 8 GPUs = 4096 per GPU, forward-only; the env's episode is 45 single sub-steps
-    # (envs/tactile_insertion_env.py:54), here 14 x 5 = 70 sub-steps of the grasp-and-drag inputs of test_gpu_models.py
-    ("tactile_insertion", 4096, 14, 4, 2e-5, 2e-3),
+    # configs[4]: TactileInsertion, 32 768 over 8 GPUs = 4096 per GPU, forward-only: the reference's episode, ONE insertion attempt of 45 single
+    # sub-steps from the settled grasp moved by U(+-6 mm, +-6 mm, +-10 deg) (envs/tactile_insertion_env.py:200-216,344-359; workloads.py) — what
+    # bench.py's `insertion` record times.  (Rounds 1 - 4 also kept a stand-in here that closed the grasp inside the episode and tolerated 1 % of
+    # non-converged environments; it was the wrong episode and is gone.)
+    ("tactile_insertion", 4096, 45, 4, 2e-5, 2e-3),
 ])
 def test_config4_config5_per_gpu_share_forward_only_fp32(name, B, T, n_oracle, tq, tt):
     """The other two multi-GPU configurations at the batch one GPU gets: all environments converge, rows that start from
@@ -242,8 +245,14 @@ def test_config4_config5_per_gpu_share_forward_only_fp32(name, B, T, n_oracle, t
     from tactilesimulation_amd.model.compiler import load_model
     from tactilesimulation_amd.workloads import asset
     from oracle.oracle import OracleSim
+    from tactilesimulation_amd.workloads import insertion_attempt_workload
     m = load_model(asset(name))
-    q0, u = _inputs(name, m, B, T)
+    S = 5
+    if name == "tactile_insertion":
+        q0, u = insertion_attempt_workload(B, seed=0)            # [B, 45, 6], one sub-step per frame
+        S = 1
+    else:
+        q0, u = _inputs(name, m, B, T)
     dup = [(0, B - 1), (1, B // 2), (2, B - 7)]                    # (source, copy) environments
     for a, b in dup:
         q0[b], u[b] = q0[a], u[a]
@@ -252,14 +261,9 @@ def test_config4_config5_per_gpu_share_forward_only_fp32(name, B, T, n_oracle, t
     Q0, U = torch.tensor(q0, device=DEV, dtype=dt), torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous()
     sim.reset(Q0, None, backward_flag=False)
     ro = sim.rollout(U, S, want_qd=True)
-    # TactilePush and D'Claw converge everywhere.  The insertion inputs close a stiff position-controlled grasp on a randomly offset
-    # box: in ~0.6 % of the environments one or two sub-steps of the closing phase end above the Newton tolerance (flagged in status;
-    # the fp64 kernels and the fp64 oracle show the same rate on the same inputs, tools/insertion_convergence_probe.py).  What must hold
-    # for ALL of them: flagged, bounded (the trust region of the Newton step keeps a hard sub-step from "converging" to a spun-up far
-    # root — before it, one environment in 4096 ended 2.5 turns away at 3 000 rad/s), finite.
+    # every environment of every config converges under the XML's Newton loop (+ kink crossing, the fp32 default)
     bad32 = (ro["status"] != 0)
-    assert int(bad32.sum()) <= (0 if name != "tactile_insertion" else B // 100), "%d environments did not converge" % int(bad32.sum())
-    assert int(ro["status"].max()) <= 8
+    assert int(bad32.sum()) == 0, "%d environments did not converge" % int(bad32.sum())
     assert float(ro["q"].abs().max()) < 4.0 and float(ro["qd"].abs().max()) < 200.0
     assert bool(torch.isfinite(ro["q"]).all()) and bool(torch.isfinite(ro["tactile"]).all())
     for a, b in dup:
@@ -273,8 +277,6 @@ def test_config4_config5_per_gpu_share_forward_only_fp32(name, B, T, n_oracle, t
     # oracle on a subset of THIS batch
     idx = np.linspace(3, B - 11, n_oracle).astype(int)
     for e in idx:
-        if bool(bad32[e]):
-            continue
         o = OracleSim(m); o.reset(q0[e])
         for t in range(T):
             assert o.forward(u[e, t], S) == 0

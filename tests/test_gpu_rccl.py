@@ -42,3 +42,62 @@ def test_one_rank_rccl_group_runs_the_policy_gradient_allreduce():
         assert float(t) == 1.25
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------- N ranks, one GPU each (skipped on a 1-GPU box)
+def _nrank_worker(rank, world, port, B, out_dir):
+    """One rank = one process = one GPU, RCCL between them: the real simulator on this rank's `env_shard` of one global batch (open loop: the
+    simulator exchanges nothing), then the closed loop's policy gradient reduced by `allreduce_policy_grad_` over xGMI."""
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_sharded import _open_loop, _run
+    from tactilesimulation_amd.dist import env_shard, allreduce_policy_grad_
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        lo, hi = env_shard(B, rank, world)
+        dev = "cuda:%d" % rank
+        open_loop = _open_loop(lo, hi, B, torch.float32, dev=dev)
+        rec, actor = _run(lo, hi, B, torch.float32, dev=dev)
+        flat = allreduce_policy_grad_([p for p in actor.parameters() if p.grad is not None], B)      # CUDA tensors on the nccl backend: RCCL
+        torch.cuda.synchronize()
+        torch.save({"rec": rec, "open": open_loop, "flat": flat.cpu(), "lo": lo, "hi": hi, "device": torch.cuda.get_device_name(rank)},
+                   os.path.join(out_dir, "rank%d.pt" % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_n_rank_rccl_sharded_simulator_equals_the_unsharded_batch(tmp_path):
+    """min(device_count, 8) `nccl` ranks, one GPU each (skipped on a 1-GPU box — the logic is the two-ranks-on-one-GPU gloo test's,
+    tests/test_gpu_sharded.py, on real RCCL): the concatenated simulator outputs and episode adjoints of the shards are BIT-EQUAL to the
+    single-process batch, every rank ends with the same reduced policy gradient, and it equals the single-process gradient to round-off.
+    Reference counterpart of the sharding: SubprocVecEnv workers (examples/TactilePushExp/cfg/ppo_tactile.yaml:24)."""
+    import sys
+    import torch.distributed as dist
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 8)
+    if world < 2:
+        pytest.skip("needs >= 2 GPUs (found %d): RCCL with N > 1 ranks cannot run here" % torch.cuda.device_count())
+    if not dist.is_nccl_available():
+        pytest.skip("torch was built without the nccl (RCCL) backend")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_sharded import _open_loop, _run, _free_port
+    B = 11 * world                                      # 11 environments per rank: the last wavefront of every shard has idle slots
+    mp.spawn(_nrank_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    assert [(p["lo"], p["hi"]) for p in parts] == [(11 * r, 11 * r + 11) for r in range(world)]
+    ref_open = _open_loop(0, B, B, torch.float32)
+    for k in ("q", "qd", "var", "tactile", "du"):
+        assert torch.equal(torch.cat([p["open"][k] for p in parts], dim=1), ref_open[k]), k      # the simulator exchanges nothing: a row does not know its batch (nor its GPU)
+    ref, actor = _run(0, B, B, torch.float32)
+    for k in ("q", "obs", "rew"):
+        got = torch.cat([p["rec"][k] for p in parts], dim=1)
+        assert float((got - ref[k]).abs().max()) <= 2e-5 * max(float(ref[k].abs().max()), 1.0), k
+    g_ref = torch.cat([p.grad.reshape(-1) for p in actor.parameters() if p.grad is not None]).cpu() / B
+    for p in parts[1:]:
+        assert torch.equal(p["flat"], parts[0]["flat"])                     # every rank holds the same reduced gradient
+    assert float((parts[0]["flat"] - g_ref).abs().max()) / float(g_ref.abs().max()) < 2e-5

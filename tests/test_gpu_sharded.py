@@ -29,12 +29,11 @@ def _tables(B):
     return q0, goal, u[:, :, 3:5].transpose(1, 0, 2).copy()            # disturbances [T, B, 2]
 
 
-def _run(lo, hi, B, dtype):
+def _run(lo, hi, B, dtype, dev="cuda:0"):
     """Episode + backward on the environments [lo, hi) of the global batch; returns per-step outputs and the actor."""
     from tactilesimulation_amd.algorithms.batched_gd import Actor
     from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
     from tactilesimulation_amd.workloads import PUSHER_BLOB
-    dev = "cuda:0"
     q0, goal, dist_tab = _tables(B)
     env = BatchedTactilePushEnv(PUSHER_BLOB, hi - lo, device=dev, dtype=dtype, gradient=True, tape_steps=T)
     env.sim.set_lanes_per_env(LANES)            # same launch shape whatever the shard size: same summation order
@@ -52,18 +51,18 @@ def _run(lo, hi, B, dtype):
     return {k: torch.stack(v).cpu() for k, v in rec.items()}, actor
 
 
-def _open_loop(lo, hi, B, dtype):
+def _open_loop(lo, hi, B, dtype, dev="cuda:0"):
     """BatchSim alone on the environments [lo, hi): episode launch forward, episode adjoint backward."""
     from tactilesimulation_amd.host.batch import BatchSim
     from tactilesimulation_amd.workloads import push_workload, PUSHER_BLOB
     from tactilesimulation_amd.model.compiler import load_model
     q0, u, _ = push_workload(B, T, seed=78)
-    sim = BatchSim(load_model(PUSHER_BLOB), hi - lo, dtype=dtype, tape_capacity=T * 5)
+    sim = BatchSim(load_model(PUSHER_BLOB), hi - lo, device=dev, dtype=dtype, tape_capacity=T * 5)
     sim.set_lanes_per_env(LANES)
-    sim.reset(torch.tensor(q0[lo:hi], device="cuda:0", dtype=dtype), None, backward_flag=True)
-    ro = sim.rollout(torch.tensor(u[lo:hi], device="cuda:0", dtype=dtype).transpose(0, 1).contiguous(), 5, want_qd=True)
+    sim.reset(torch.tensor(q0[lo:hi], device=dev, dtype=dtype), None, backward_flag=True)
+    ro = sim.rollout(torch.tensor(u[lo:hi], device=dev, dtype=dtype).transpose(0, 1).contiguous(), 5, want_qd=True)
     g = torch.Generator().manual_seed(3)
-    w = {k: torch.randn(T, B, d, generator=g, dtype=torch.float64)[:, lo:hi].to("cuda:0", dtype) for k, d in (("q", 7), ("var", 6), ("tactile", 390))}
+    w = {k: torch.randn(T, B, d, generator=g, dtype=torch.float64)[:, lo:hi].to(dev, dtype) for k, d in (("q", 7), ("var", 6), ("tactile", 390))}
     du = sim.backward_episode(T, 5, w["q"], w["var"], w["tactile"])
     out = {k: ro[k].cpu() for k in ("q", "qd", "var", "tactile")}
     out["du"] = du.cpu()

@@ -1,5 +1,5 @@
 """Build an A/B variant of the HIP library into tactilesimulation_amd/csrc/ab/libtsim_<name>.so with extra compiler flags (usually -D switches:
-TS_FINE_STAMPS, TS_PP_NO_MFMA, TS_SOLVE_PIVOT_ONLY, TS_TAX_PLAIN, TS_ISA_MARKS ...), by the same recipe as the shipped library (one compile per
+the ones tests/test_ab_macros_compile.py lists: TS_FINE_STAMPS, TS_SOLVE_PIVOT_ONLY, TS_ROUND_STATS, TS_PP_TIME, TS_WAVES_PER_EU, TS_ISA_MARKS ...), by the same recipe as the shipped library (one compile per
 translation unit, host/buildhash.py).  Use it on the GPU box through TSIM_HIP_LIB=<path>.
 
     python tools/build_ab.py fine -DTS_FINE_STAMPS
