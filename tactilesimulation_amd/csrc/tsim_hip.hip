@@ -578,8 +578,8 @@ static void detect_static_model(tsim_batch* b) {
 // which instantiation the next launch of the simulation kernels uses: 0 generic, 1 fully static, 2 structure-static (parameters at run time)
 enum { TS_KM_GENERIC = 0, TS_KM_STATIC = 1, TS_KM_PARAM = 2 };
 static int kernel_mode(const tsim_batch* b) {
-  if (b->static_id == 0 || b->no_static || b->dtype != TSIM_F32) return TS_KM_GENERIC;
-  if (b->dFenv) return b->env_struct_ok ? TS_KM_PARAM : TS_KM_GENERIC;
+  if (b->static_id == 0 || b->no_static) return TS_KM_GENERIC;
+  if (b->dFenv) return b->env_struct_ok ? TS_KM_PARAM : TS_KM_GENERIC;      // (the table check is fp32 only: fp64 batches with per-environment tables stay generic)
   return b->static_exact ? TS_KM_STATIC : TS_KM_PARAM;
 }
 static int upload_model(tsim_batch* b, hipStream_t st) {
@@ -715,6 +715,11 @@ void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_
 void ts_param_pusher_launch(const FwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
 void ts_param_pusher_launch(const BwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
 void ts_param_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
+// ... both in fp64 (two or one environments per wavefront)
+void ts_static_pusher_launch(const FwdArgs<double>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
+void ts_static_pusher_launch(const BwdArgs<double>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
+void ts_param_pusher_launch(const FwdArgs<double>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
+void ts_param_pusher_launch(const BwdArgs<double>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
 // kernel variants: NRM = 8 / 16 rows in the register solve; EXPJ = model has a rotation-vector joint (its code is
 // compiled out otherwise: it costs registers in every evaluation); LPE as above
 #define TS_LAUNCH_L(KERNEL, R, NRM, L, st, a) do {                                                                       \
@@ -724,7 +729,7 @@ void ts_param_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t
   } while (0)
 #define TS_LAUNCH(KERNEL, R, b, st, a) do {                                                                              \
     const LaunchShape L = launch_shape(b);                                                                               \
-    if constexpr (sizeof(R) == 4) {      /* a statically known model (tsim_static.h): instantiated in its own translation unit */ \
+    if (sizeof(R) == 4 || L.lpe != 16) {   /* a statically known model (tsim_static.h): instantiated in its own translation unit (fp64: not four environments per wavefront) */ \
       const int km_ = kernel_mode(b);                                                                                     \
       if (km_ == TS_KM_STATIC) { ts_static_pusher_launch(a, L.lpe, L.grid, L.lds, st); break; }                           \
       if (km_ == TS_KM_PARAM) { ts_param_pusher_launch(a, L.lpe, L.grid, L.lds, st); break; }                             \

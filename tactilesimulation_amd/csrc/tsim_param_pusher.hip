@@ -23,3 +23,15 @@ void ts_param_pusher_launch(const BwdArgs<float>& a, int lpe, unsigned grid, siz
 void ts_param_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((k_debug_eval<float, 16, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
 }
+
+// ... and in fp64 (round 5): the reference's arithmetic type (envs/tactile_push_env.py:29).  Two or one environments per wavefront: four do not fit the
+// block's LDS in fp64, and the host never asks for them (tsim_hip.hip TS_LAUNCH).  The Newton systems are solved with partial pivoting, as in every
+// fp64 kernel (solve_newton).
+void ts_param_pusher_launch(const FwdArgs<double>& a, int lpe, unsigned grid, size_t lds, hipStream_t st) {
+  if (lpe == 32) hipLaunchKernelGGL((k_forward<double, 8, false, 32, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+  else hipLaunchKernelGGL((k_forward<double, 8, false, 64, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+}
+void ts_param_pusher_launch(const BwdArgs<double>& a, int lpe, unsigned grid, size_t lds, hipStream_t st) {
+  if (lpe == 32) hipLaunchKernelGGL((k_backward<double, 8, false, 32, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+  else hipLaunchKernelGGL((k_backward<double, 8, false, 64, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+}

@@ -29,7 +29,7 @@ DEV = "cuda:0"
 S = 5
 
 
-def _hip_substep_states(model, q0, u, dt, lanes=0, S=5):
+def _hip_substep_states(model, q0, u, dt, lanes=0, S=5, static=True):
     """Roll the batch out one sub-step per launch and keep every state: q, qd [B, T*S + 1, nr] (float64 copies) and, per sub-step,
     whether the kernel flagged it as not converged: bad [B, T*S]."""
     from tactilesimulation_amd.host.batch import BatchSim
@@ -37,7 +37,10 @@ def _hip_substep_states(model, q0, u, dt, lanes=0, S=5):
     sim = BatchSim(model, B, dtype=dt, tape_capacity=0)
     if lanes:
         sim.set_lanes_per_env(lanes)
+    if not static:
+        sim.set_static(False)
     info = sim.launch_info()
+    info["variant"] = sim.kernel_variant()
     sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None, backward_flag=False)
     U = torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous()
     q = torch.empty(T * S + 1, B, sim.ndof_r, device=DEV, dtype=dt)
@@ -77,15 +80,23 @@ def _case_inputs(name, m, B, T):
     return _inputs(name, m, B, T)                              # the inputs of test_gpu_configs.py's config-4 / config-5 tests
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("dtype", ["f64", "f32", "f64-generic"])
 @pytest.mark.parametrize("name,B,T,n_sub,tol64,tol32", CASES)
 def test_every_substep_lands_on_the_literal_solvers_root(name, B, T, n_sub, tol64, tol32, dtype):
+    # "f64" / "f32": the kernels a batch of this model launches by default (TactilePush: the compiled-in static instantiations, fp64 since round 5);
+    # "f64-generic": TactilePush once more on the generic fp64 kernels
+    static = dtype != "f64-generic"
+    if not static and name != "pusher":
+        pytest.skip("only TactilePush has compiled-in kernels: the default run IS the generic one")
+    dtype = dtype[:3]
     m = load_model(asset(name))
     S = SUBSTEPS.get(name, 5)
     q0, u = _case_inputs(name, m, B, T)
     assert u.shape[:2] == (B, T)
     dt = torch.float64 if dtype == "f64" else torch.float32
-    q, qd, bad, info = _hip_substep_states(m, q0, u, dt, S=S)
+    q, qd, bad, info = _hip_substep_states(m, q0, u, dt, S=S, static=static)
+    if name == "pusher":
+        assert os.environ.get("TSIM_NO_STATIC") or info["variant"] == ("static:pusher" if static else "generic"), info
     if name == "pusher" and dtype == "f32":
         assert os.environ.get("TSIM_LPE") or (info["lanes_per_env"] == 16 and info["blocks"] == 1024), info   # the instantiation bench.py times (TSIM_LPE: the whole suite under a forced shape)
     flagged = np.nonzero(bad.any(axis=1))[0]

@@ -137,6 +137,7 @@ def test_one_structure_static_evaluation_against_the_fp64_one(pusher_model):
     m = _edited(pusher_model)
     q0, u, _ = push_workload(B, T, seed=11)
     d = BatchSim(m, B, dtype=torch.float64, tape_capacity=0)
+    d.set_static(False)                                                  # the generic fp64 kernels
     d.reset(torch.tensor(q0, device=DEV, dtype=torch.float64), None, backward_flag=False)
     ro = d.rollout(torch.tensor(u, device=DEV, dtype=torch.float64).transpose(0, 1).contiguous(), S, want_qd=True)
     q, qd = ro["q"][-1], ro["qd"][-1]

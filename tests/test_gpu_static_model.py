@@ -52,6 +52,7 @@ def test_static_pusher_kernels_agree_with_the_generic_ones_to_fp32_rounding(push
     # batch's largest taxel force: 99.9 % of the environments within 2e-5 of fp64 on either path, every environment within 2e-4 (measured: static
     # 6.3e-5, generic 1.2e-4 in ONE environment of 4096 whose Newton iteration takes one evaluation less than in fp64; profiles/r05_static_vs_generic.json)
     d = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0)
+    d.set_static(False)                                                  # the third party: the generic fp64 kernels
     d.reset(torch.tensor(q0, device=DEV, dtype=torch.float64), None, backward_flag=False)
     rd = d.rollout(torch.tensor(u, device=DEV, dtype=torch.float64).transpose(0, 1).contiguous(), S)
     tmax = float(rd["tactile"].abs().max())
@@ -81,6 +82,7 @@ def test_one_static_evaluation_against_the_generic_and_the_fp64_one(pusher_model
     B, T, S = 512, 8, 5
     q0, u, _ = push_workload(B, T, seed=11)
     d = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0)
+    d.set_static(False)                                                  # the generic fp64 kernels (debug_eval has no static fp64 instantiation anyway)
     d.reset(torch.tensor(q0, device=DEV, dtype=torch.float64), None, backward_flag=False)
     ro = d.rollout(torch.tensor(u, device=DEV, dtype=torch.float64).transpose(0, 1).contiguous(), S, want_qd=True)
     assert float((ro["tactile"][-1].abs().sum(1) > 0).float().mean()) > 0.05          # some environments are in contact at the probe state
@@ -161,5 +163,47 @@ def test_static_kernels_switch_off_for_other_blobs_shapes_and_tables(pusher_mode
     assert sim.static_model() == 0 and sim.kernel_variant() == "generic"
     sim.update_model(pusher_model)
     assert sim.kernel_variant() == "generic"                            # tsim_set_static(0) survives a model update
-    assert BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0).static_model() == 0
+    d = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0)      # fp64 (round 5): the same two instantiations, two or one environments per wavefront
+    assert d.static_model() == 1 and d.kernel_variant() == "static:pusher" and d.launch_info()["lanes_per_env"] in (32, 64)
+    d.update_model(m)
+    assert d.kernel_variant() == "param:pusher"
+    d.set_env_tables(d.base_tables())
+    assert d.kernel_variant() == "generic"                               # (the per-environment table check is fp32 only)
     assert BatchSim(pusher_model, 64, dtype=torch.float32, tape_capacity=0).static_model() == 1      # small batch: one environment per wavefront, static too
+
+
+@pytest.mark.parametrize("edited", [False, True])
+def test_fp64_static_kernels_against_the_generic_fp64_ones(pusher_model, edited):
+    """The fp64 instantiations of the compiled-in TactilePush kernels (fully static; structure-static on an edited model) against the generic fp64
+    kernels — the ones tests/test_gpu_literal.py walks the oracle's iterates with: the same arithmetic up to the order of a few sums, so states to
+    1e-11, tactile forces to 1e-9 of their maximum, the same Newton work in all but a handful of environments, episode gradients to 1e-7."""
+    B, T, S = 1024, 12, 5
+    m = pusher_model
+    if edited:
+        m = copy.copy(pusher_model); m.F = pusher_model.F.copy()
+        m.F[m.I[BL.TSIM_IH_FOFF_PAIR] + BL.TSIM_PF_KN] *= 1.5
+        m.F[m.I[BL.TSIM_IH_FOFF_DOF] + BL.TSIM_DF_DAMPING] = 0.7
+    q0, u, _ = push_workload(B, T, seed=5)
+    g = torch.Generator().manual_seed(2)
+    wq, wv, wt = (torch.randn(T, B, n, generator=g, dtype=torch.float64).to(DEV) for n in (7, 6, 390))
+
+    def run(static):
+        sim = BatchSim(m, B, dtype=torch.float64, tape_capacity=T * S)
+        sim.set_static(static)
+        assert sim.kernel_variant() == (("param:pusher" if edited else "static:pusher") if static else "generic")
+        sim.reset(torch.tensor(q0, device=DEV, dtype=torch.float64), None, backward_flag=True)
+        ro = sim.rollout(torch.tensor(u, device=DEV, dtype=torch.float64).transpose(0, 1).contiguous(), S, want_qd=True)
+        ev = sim.last_evals().copy()
+        du = sim.backward_episode(T, S, wq, wv, wt)
+        lq, lv = sim.get_adjoint()
+        return ro, ev, du, lq, lv
+    a, b = run(True), run(False)
+    assert torch.equal(a[0]["status"], b[0]["status"])
+    assert float((a[0]["q"] - b[0]["q"]).abs().max()) < 1e-11 and float((a[0]["qd"] - b[0]["qd"]).abs().max()) < 1e-8
+    tmax = float(b[0]["tactile"].abs().max())
+    assert tmax > 0 and float((a[0]["tactile"] - b[0]["tactile"]).abs().max()) < 1e-9 * tmax
+    assert (a[1] == b[1]).mean() > 0.99
+    for x, y, name in ((a[2], b[2], "du"), (a[3], b[3], "lamq"), (a[4], b[4], "lamv")):
+        x, y = (t.transpose(0, 1).reshape(B, -1) if t.dim() == 3 else t for t in (x, y))
+        e = ((x - y).abs().max(1).values / y.abs().max(1).values.clamp_min(1e-30)).cpu().numpy()
+        assert np.median(e) < 1e-10 and (e < 1e-7).mean() > 0.995, (name, float(np.median(e)), float((e < 1e-7).mean()), float(e.max()))
