@@ -175,3 +175,45 @@ def test_push_episode_and_gradients_against_a_literal_solver_rollout(pusher_mode
     print("literal-solver oracle: gradient error median %.2e, max on branch-agreeing environments %.2e (%d of 64 agree)"
           % (np.median(eg), eg[same].max(), same.sum()))
     assert eg[same].max() < 1e-4, eg[same].max()
+
+
+def test_fp64_nonconverged_environments_are_the_oracles_too(pusher_model):
+    """bench.py's fp64 leg under the library's default solver — the bare XML Newton loop — reports 2 of 4096 TactilePush environments with a
+    sub-step that ends above the tolerance after max_iter iterations of exhausted line searches (they cycle between the two sides of a contact
+    kink).  That is the LOOP's behaviour on these inputs, not the kernels': the fp64 oracle (the same loop, oracle/tsim_oracle.cpp
+    substep_literal) run on exactly those environments flags the same number of sub-steps, spends several times an ordinary episode's evaluations there and ends in the SAME state
+    (4e-16): the kernels walk the oracle's iterates through the non-converged sub-step as well.  Every other environment converges in both."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    from oracle.oracle import OracleSim
+    B, T = 4096, 20
+    q0, u, _ = push_workload(B, T, seed=0)                      # bench.py's rank-0 inputs (make_workload)
+    dt = torch.float64
+    out = {}
+    for static in (True, False):
+        sim = BatchSim(pusher_model, B, dtype=dt, tape_capacity=0)
+        sim.set_static(static)
+        assert sim.get_option(BatchSim.OPT_TRIAL_HELPERS) == 1            # ... with the helper slots at work on those line searches
+        sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None, backward_flag=False)
+        ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dt).transpose(0, 1).contiguous(), S, want_qd=True)
+        out[static] = (ro["status"].cpu().numpy() & 0x3FFFFFFF, sim.last_evals().copy(), ro["q"].cpu().numpy(), sim.last_helper_trials().copy())
+    st, ev, q, helped = out[True]
+    assert (st == out[False][0]).all() and (ev == out[False][1]).all()        # compiled-in and generic fp64 kernels: the same flags and work
+    assert st.shape == (B,)                                                    # an episode launch reports the non-converged sub-steps of the whole episode per environment
+    bad = np.nonzero(st)[0]
+    assert 1 <= len(bad) <= 4, bad                                            # (2 on this toolchain)
+    assert int(helped[bad].min()) > 0
+    good = np.setdiff1d(np.arange(5, B, 512), bad)
+    med, o_evals = float(np.median(ev)), {}
+    for e in list(good) + list(bad):
+        o = OracleSim(pusher_model, solver="literal")
+        o.reset(q0[e])
+        flags = np.array([o.forward(u[e, t], S) for t in range(T)])
+        assert int(flags.sum()) == int(st[e]), (e, flags, st[e])               # the same number of non-converged sub-steps
+        o_evals[e] = o.stats()["evals"]                                         # (the oracle counts the Jacobian evaluation of an iteration separately: another unit)
+        dq = np.abs(o.state()[0] - q[-1, e]).max()
+        assert dq < 1e-9, (e, dq)                                               # the same iterates to round-off — through the non-converged sub-steps as well
+        if e in bad:
+            o_med = float(np.median([o_evals[g] for g in good]))
+            assert o_evals[e] > 3 * o_med and int(ev[e]) > 3 * med, (e, o_evals[e], o_med, int(ev[e]), med)      # both spend several episodes' worth of evaluations there
+            print("env %d: non-converged sub-steps %d (oracle %d); evaluations: kernels %d (batch median %d), oracle %d (median %d, its own unit); final |dq| %.1e"
+                  % (e, st[e], flags.sum(), ev[e], med, o_evals[e], o_med, dq))
