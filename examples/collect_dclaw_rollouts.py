@@ -3,7 +3,7 @@ with PPO over SubprocVecEnv, one simulator per process; here one batch per GPU):
 environments are reset individually (with a new variant of the randomised model), and (obs, action, reward, done) batches come out.
 The policy here is a random linear map — the point is the collector and its rate, not the learning.
 
-    python examples/collect_dclaw_rollouts.py --batch 2048 --steps 200 --variants 16
+    python examples/collect_dclaw_rollouts.py --batch 2048 --steps 200
     python -m torch.distributed.run --nproc-per-node 8 examples/collect_dclaw_rollouts.py       # 16 384 environments, no collective
 """
 import argparse
@@ -22,7 +22,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2048, help="environments per GPU (16 384 / 8 in BASELINE configs[3])")
     ap.add_argument("--steps", type=int, default=200, help="env-steps to collect per environment (the env's episode limit)")
-    ap.add_argument("--variants", type=int, default=16, help="pool of randomised models (damping, cap radius, end-effector, location); 0: none")
+    ap.add_argument("--variants", type=int, default=0, help="pool of K host-compiled randomised models instead of continuous draws (rounds 3-4); 0: off")
+    ap.add_argument("--no-randomize", action="store_true", help="no domain randomisation (default: every environment draws its own damping, cap radius, "
+                    "end-effector offset and cap location on the device at each reset, envs/dclaw_rotate_env.py:164-184)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--eager", action="store_true", help="plain python loop instead of one HIP graph per collection step")
@@ -32,7 +34,7 @@ def main():
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dt = torch.float32 if a.dtype == "f32" else torch.float64
-    env = BatchedDClawRotateEnv(a.batch, device="cuda:%d" % local, dtype=dt, seed=a.seed + rank, variants=a.variants)
+    env = BatchedDClawRotateEnv(a.batch, device="cuda:%d" % local, dtype=dt, seed=a.seed + rank, variants=a.variants, randomize=not a.no_randomize and not a.variants)
     env.sim.set_solver_options(cross_kinks=True, eval_budget=a.eval_budget)
     torch.manual_seed(a.seed)
     W = torch.randn(env.obs_dim, env.act_dim, device=env.device, dtype=dt) * 0.02

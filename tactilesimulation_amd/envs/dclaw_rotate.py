@@ -11,7 +11,10 @@ The environment-side arithmetic is the reference's, pinned on golden vectors rec
     — with the contact term computed from the flow images of the PREVIOUS observation, as the reference does (its step() calls
     _get_reward before _get_obs refreshes tactile_force_buf, :211-222).
 The reset-time randomisers (cap joint damping, cap radius, end-effector offset, cap location: :165-178) edit constants of the model; for a
-batch they become per-environment parameter tables drawn from a pool of compiled variants (include/tsim.h tsim_set_env_tables).
+batch they become per-environment parameter tables (include/tsim.h tsim_set_env_tables): `randomize=True` draws every environment its OWN
+damping ~ U(0.01, 0.7), radius ~ U(0.02, 0.08), (dx, dy) ~ U(+-0.02)^2 at each (masked) reset, on the device, and writes the float records
+those four edits touch — what the reference does per environment per reset; `variants=K` (rounds 3-4) assigns environments to a pool of K
+host-compiled variants instead.
 Forward-only: PPO needs no simulator gradients.
 """
 import math
@@ -57,7 +60,7 @@ class BatchedDClawRotateEnv:
     frame_skip = 5                                                                        # :59
     max_episode_steps = 200                                                               # envs/__init__.py
 
-    def __init__(self, batch_size, model=None, device="cuda:0", dtype=torch.float32, seed=0, variants=0):
+    def __init__(self, batch_size, model=None, device="cuda:0", dtype=torch.float32, seed=0, variants=0, randomize=False):
         self.model = mc.load_model(asset("dclaw_position_control")) if model is None else model
         self.B, self.device, self.dtype = int(batch_size), torch.device(device), dtype
         self.sim = BatchSim(self.model, self.B, device=device, dtype=dtype, tape_capacity=0)
@@ -80,8 +83,13 @@ class BatchedDClawRotateEnv:
         self._q_init = torch.tensor(q_init, device=self.device, dtype=self.dtype)[None]
         self._gen = torch.Generator(device=self.device); self._gen.manual_seed(seed)
         self.tables = None
+        self.randomize = bool(randomize)
+        if variants and randomize:
+            raise ValueError("variants=K (a pool of compiled models) and randomize=True (continuous draws per environment) exclude each other")
         if variants:
             self._build_variants(int(variants))
+        if randomize:
+            self._build_randomisers()
         # persistent state buffers, updated in place: a collector's step can be captured in a HIP graph and replayed
         z = lambda *shape: torch.zeros(*shape, device=self.device, dtype=self.dtype)
         self.q, self.var, self.flow = z(self.B, 10), z(self.B, 12), z(self.B, 3, 20, 20, 3)
@@ -107,6 +115,68 @@ class BatchedDClawRotateEnv:
         self.variant_of = torch.zeros(self.B, device=self.device, dtype=torch.long)
         self.tables = self._variant_rows[self.variant_of].contiguous()          # persistent: rewritten in place at every reset
 
+    RANDOMISER_RANGES = {"damping": (0.01, 0.7), "radius": (0.02, 0.08), "dx": (-0.02, 0.02), "dy": (-0.02, 0.02)}        # :169-178
+
+    @staticmethod
+    def edited_model(model, damping, radius, dx, dy):
+        """The model with the reference's four reset-time edits applied on the host (update_joint_damping, update_body_size,
+        update_endeffector_position, update_joint_location: envs/dclaw_rotate_env.py:169-178), compiled: what one environment's table must equal."""
+        spec = mc.compile_spec(model.spec).spec
+        mc.edit_spec(spec, "joint_damping", "cap", float(damping))
+        mc.edit_spec(spec, "body_size", "cap", np.array([0.03, float(radius)]))
+        mc.edit_spec(spec, "endeffector_position", "cap", np.array([float(radius), 0.0, 0.0]))
+        mc.edit_spec(spec, "joint_location", "cap", np.array([float(dx), float(dy), 0.075]))
+        return mc.compile_spec(spec)
+
+    def _build_randomisers(self):
+        """Which float records the four randomisers touch, and how: found by compiling edited models on the host ONCE (no assumption about the
+        compiler's formulas: the cap's mass ~ r^2 and inertia ~ r^4, r^2 come out of it as polynomials in the radius of degree <= 4, the
+        primitive radius of the three fingertip-cap pairs and the end-effector offset as r itself, damping / dx / dy as themselves), then
+        written per environment on the device at every reset.  Checked here against three more host compilations to 1e-13."""
+        n = self.sim.base_tables().shape[1]
+        lo_r, hi_r = self.RANDOMISER_RANGES["radius"]
+        mid = {"damping": 0.3, "radius": 0.05, "dx": 0.0, "dy": 0.0}
+        row = lambda **kw: self._row(n, **dict(mid, **kw))
+        base = row()
+        self._rand_single = {}                                     # parameter -> indices of the records that ARE the parameter
+        for k, v in (("damping", 0.55), ("dx", 0.013), ("dy", -0.017)):
+            r_ = row(**{k: v})
+            idx = np.nonzero(r_ != base)[0]
+            assert len(idx) >= 1 and np.all(r_[idx] == v), (k, idx, r_[idx])
+            self._rand_single[k] = torch.tensor(idx, device=self.device, dtype=torch.long)
+        nodes = 0.5 * (lo_r + hi_r) + 0.5 * (hi_r - lo_r) * np.cos(np.pi * (np.arange(7) + 0.5) / 7)            # Chebyshev nodes: a well-conditioned fit
+        rows = np.array([row(radius=r) for r in nodes])
+        idx = np.nonzero((rows != rows[0]).any(0))[0]
+        t = (nodes - 0.05) / 0.03                                   # the polynomial's variable: radius mapped to [-1, 1]
+        coef = np.linalg.solve(np.vander(t, 7, increasing=True), rows[:, idx])[:5]              # degree <= 4 (the higher coefficients must vanish)
+        for r in (0.0231, 0.0507, 0.0789):
+            got = (((r - 0.05) / 0.03) ** np.arange(5)) @ coef
+            want = row(radius=r)[idx]
+            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max() + 1e-300, (r, np.abs(got - want).max())
+        self._rand_ridx = torch.tensor(idx, device=self.device, dtype=torch.long)
+        self._rand_rcoef = torch.tensor(coef, device=self.device, dtype=torch.float64)          # [5, len(idx)]
+        self.params = torch.zeros(self.B, 4, device=self.device, dtype=torch.float64)           # damping, radius, dx, dy of every environment
+        self._rand_lo = torch.tensor([self.RANDOMISER_RANGES[k][0] for k in ("damping", "radius", "dx", "dy")], device=self.device, dtype=torch.float64)
+        self._rand_hi = torch.tensor([self.RANDOMISER_RANGES[k][1] for k in ("damping", "radius", "dx", "dy")], device=self.device, dtype=torch.float64)
+        self.tables = self.sim.base_tables().contiguous()                                       # persistent: rewritten in place at every reset
+
+    def _row(self, n, damping, radius, dx, dy):
+        m = self.edited_model(self.model, damping, radius, dx, dy)
+        assert np.array_equal(m.I, self.model.I) and np.array_equal(m.F[n:], self.model.F[n:]), "a randomiser changed more than the float records"
+        return m.F[:n].copy()
+
+    def _randomise(self, mask):
+        """New draws for the environments with mask set; every environment's table rewritten from `params` (device only, no synchronisation)."""
+        lo, hi = self._rand_lo, self._rand_hi                      # (made once: nothing here touches the host, a collector's reset is captured in a HIP graph)
+        draw = lo + (hi - lo) * torch.rand(self.B, 4, device=self.device, dtype=torch.float64, generator=self._gen)
+        self.params.copy_(torch.where(mask[:, None], draw, self.params))
+        t = (self.params[:, 1:2] - 0.05) / 0.03
+        pw = torch.cat([torch.ones_like(t), t, t * t, t * t * t, t * t * t * t], dim=1)          # [B, 5]
+        self.tables[:, self._rand_ridx] = (pw @ self._rand_rcoef).to(self.dtype)
+        for j, k in ((0, "damping"), (2, "dx"), (3, "dy")):
+            self.tables[:, self._rand_single[k]] = self.params[:, j:j + 1].to(self.dtype)
+        self.sim.set_env_tables(self.tables)
+
     # ------------------------------------------------------------------ read-out helpers
     def flow_images(self, tactile):
         t = tactile.reshape(tactile.shape[0], -1, 3)
@@ -128,7 +198,9 @@ class BatchedDClawRotateEnv:
         m = torch.ones(B, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
         q0 = self._q_init.repeat(B, 1)
         q0[:, :9] += 0.05 * torch.randn(B, 9, device=self.device, dtype=self.dtype, generator=self._gen)
-        if self.tables is not None:
+        if self.randomize:
+            self._randomise(m)
+        elif self.tables is not None:
             new = torch.randint(0, self._variant_rows.shape[0], (B,), device=self.device, generator=self._gen)
             self.variant_of.copy_(torch.where(m, new, self.variant_of))
             self.tables.copy_(self._variant_rows[self.variant_of])
