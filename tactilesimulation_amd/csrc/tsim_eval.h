@@ -382,8 +382,10 @@ __device__ __forceinline__ bool pair_points_matrix(const Ctx<R>& c, int pt0, int
   return any_hit;
 }
 
+// Returns whether any environment of the wavefront has a penetrating point of this pair (wave-uniform): if none has, the pair's staged wrench and
+// wrench tangents are the zeros they were staged with, and the fold has nothing to add (phase2).
 template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
-__device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
+__device__ __forceinline__ bool pair_contacts_matrix(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
@@ -398,7 +400,7 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
   R w0[6], M[6][12];               // value wrench (n; F) and d(n; F) / d(dth, drho, dw, dv)
   const bool any_hit = pair_points_matrix<R, LPE, PRIMC, FLAGSC>(c, pt0, npt, prim, sphere_plane, pf, P, lane, w0, M, tang);
   TS_STAMP2(c);
-  if (!any_hit) return;
+  if (!any_hit) return false;
   constexpr bool kHalfRow = NPTC >= 0 && NPTC <= 8 && NRM <= 8;      // all points (and all directions) in the first 8 lanes of the slot
   if constexpr (kHalfRow) {
 #pragma unroll
@@ -434,13 +436,14 @@ __device__ __forceinline__ void pair_contacts_matrix(const Ctx<R>& c, int pk, in
       T[PT_WN + e] = acc;
     }
   }
+  return true;
 }
 
 // The per-direction form: dF, dn evaluated per point and per relevant direction (54 FMA each), 6 (1 + directions)
 // accumulators.  Kept for fp64, where the 78 accumulators of the matrix form cost 156 registers and the kernel loses more
 // to spills than it gains (measured: 3.07 M vs 2.84 M env-steps/s at two environments per wavefront).
 template <class R, int NRM, int LPE>
-__device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
+__device__ __forceinline__ bool pair_contacts_per_direction(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
   const int nd = c.nd;
   const int* pi = c.I + c.off_pair + pk * TSIM_PI_SIZE;
   const R* pf = c.F + c.foff_pair + pk * TSIM_PF_SIZE;
@@ -494,7 +497,7 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
       }
     }
   }
-  if (!any_hit) return;
+  if (!any_hit) return false;
   {
     R s[6];
 #pragma unroll
@@ -504,7 +507,7 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
       for (int e = 0; e < 6; ++e) S[PP_WN + e] = s[e];
     }
   }
-  if (!tang) return;
+  if (!tang) return true;
 #pragma unroll
   for (int d = 0; d < NRM; ++d) {
     if (d < nd && ((anc >> d) & 1)) {
@@ -518,22 +521,25 @@ __device__ __forceinline__ void pair_contacts_per_direction(const Ctx<R>& c, int
       }
     }
   }
+  return true;
 }
 
 template <class R, int NRM, int LPE, int PRIMC = -1, int FLAGSC = -1, int NPTC = -1>
-__device__ __forceinline__ void pair_contacts(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
-  if (sizeof(R) == 4) pair_contacts_matrix<R, NRM, LPE, PRIMC, FLAGSC, NPTC>(c, pk, slot, lane, tang);
-  else pair_contacts_per_direction<R, NRM, LPE>(c, pk, slot, lane, tang);
+__device__ __forceinline__ bool pair_contacts(const Ctx<R>& c, int pk, int slot, int lane, bool tang = true) {
+  if (sizeof(R) == 4) return pair_contacts_matrix<R, NRM, LPE, PRIMC, FLAGSC, NPTC>(c, pk, slot, lane, tang);
+  else return pair_contacts_per_direction<R, NRM, LPE>(c, pk, slot, lane, tang);
 }
 // the contact loops of a group of pairs with each pair's primitive type / flags taken from the static model (template recursion over the pairs)
 template <class R, int NRM, int LPE, class MS, int PK>
-__device__ __forceinline__ void pair_contacts_static(const Ctx<R>& c, int p0, int pe, unsigned act, int lane, bool tang = true) {
+__device__ __forceinline__ unsigned pair_contacts_static(const Ctx<R>& c, int p0, int pe, unsigned act, int lane, bool tang = true) {
   constexpr int NP = MS::Iv(TSIM_IH_NPAIR);
+  unsigned hit = 0;
   if constexpr (PK < NP) {
     constexpr int o = MS::Iv(TSIM_IH_OFF_PAIR) + PK * TSIM_PI_SIZE, flags = MS::Iv(o + TSIM_PI_FLAGS), prim = MS::Iv(o + TSIM_PI_PRIM), npt = MS::Iv(o + TSIM_PI_NPT);
-    if constexpr ((flags & 1) != 0) { if (PK >= p0 && PK < pe && ((act >> (PK - p0)) & 1u)) pair_contacts<R, NRM, LPE, prim, flags, npt>(c, PK, PK - p0, lane, tang); }
-    pair_contacts_static<R, NRM, LPE, MS, PK + 1>(c, p0, pe, act, lane, tang);
+    if constexpr ((flags & 1) != 0) { if (PK >= p0 && PK < pe && ((act >> (PK - p0)) & 1u)) { if (pair_contacts<R, NRM, LPE, prim, flags, npt>(c, PK, PK - p0, lane, tang)) hit |= 1u << (PK - p0); } }
+    hit |= pair_contacts_static<R, NRM, LPE, MS, PK + 1>(c, p0, pe, act, lane, tang);
   }
+  return hit;
 }
 
 // lanes = directions: bring the staged pair's wrench (value + tangent k) to the world frame and fold it into the links
@@ -595,14 +601,20 @@ __device__ __forceinline__ void phase2(const Ctx<R>& c, int lane, R sq, bool tan
     }
     TS_SYNC();
     TS_STAMP(c);
+    // bit j of `hit`: some environment of the wavefront has a penetrating point of pair p0 + j (wave-uniform).  A near pair without one — most of
+    // TactileInsertion's eleven during an attempt: the bounding spheres of the hole's walls and of the object's faces overlap long before a sampled
+    // point is inside the other body — keeps the zero wrench and zero wrench tangents it was staged with: the fold would add x + 0 (round 5; with c.cull
+    // == 0 every live pair is folded, as before)
+    unsigned hit = 0;
     if constexpr (std::is_void<MS>::value) {
       for (int pk = p0; pk < pe; ++pk)        // lanes = contact points
-        if ((ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) && ((act >> (pk - p0)) & 1u)) pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane, tang);
-    } else pair_contacts_static<R, NRM, LPE, MS, 0>(c, p0, pe, act, lane, tang);
+        if ((ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) && ((act >> (pk - p0)) & 1u)) { if (pair_contacts<R, NRM, LPE>(c, pk, pk - p0, lane, tang)) hit |= 1u << (pk - p0); }
+    } else hit = pair_contacts_static<R, NRM, LPE, MS, 0>(c, p0, pe, act, lane, tang);
+    if (!c.cull) hit = act;
     TS_SYNC();
     TS_STAMP(c);
     for (int pk = p0; pk < pe; ++pk)        // lanes = directions; serial over pairs: two pairs may touch the same link
-      if ((ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) && ((act >> (pk - p0)) & 1u)) pair_fold(c, pk, pk - p0, lane, sq, tang);
+      if ((ts_u(c.I[c.off_pair + pk * TSIM_PI_SIZE + TSIM_PI_FLAGS]) & 1) && ((hit >> (pk - p0)) & 1u)) pair_fold(c, pk, pk - p0, lane, sq, tang);
     TS_SYNC();
   }
 }
