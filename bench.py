@@ -306,7 +306,7 @@ class Leg:
                 "valu": None}, (dom, dom_ms, dom_frames)
 
 
-def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench", pmc=False):
+def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench", pmc=False, env_tables=False):
     """A short N = 1 leg of another BASELINE config (or of the headline workload in another dtype), reported inside the headline's JSON
     line: value, kernel times by HIP events, HBM roofline from the general formula of SURVEY.md §8d.  `steps` in env-steps (5 sub-steps)."""
     asset_, B, T, fwd_only, cfg = WORKLOADS[name]
@@ -316,6 +316,8 @@ def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench", pmc=Fals
     wl = make_workload(name, B, T, 5, 0, dev, tdt)
     fps = wl["fps"]
     leg = Leg(wl, dev, tdt, fwd_only, solver=solver)
+    if env_tables:      # one parameter table per environment (domain randomisation, include/tsim.h tsim_set_env_tables): here every row the model's own
+        leg.sim.set_env_tables(leg.sim.base_tables())
     steps = steps or 2 * T // fps                       # two episodes
     leg.run(warm * fps if warm else T, False, "episode")
     torch.cuda.synchronize()
@@ -619,6 +621,11 @@ def main():
                     except Exception as e:      # the headline must not die with an optional leg
                         res[key] = {"error": repr(e)}
                     progress("sub-record %s done" % key)
+                try:      # the headline workload with one parameter table per environment: must stay on compiled-in kernels (round 4: fell to the generic ones)
+                    res["push_env_tables"] = sub_record("push", args.dtype, dev, steps=20, warm=20, env_tables=True)
+                except Exception as e:
+                    res["push_env_tables"] = {"error": repr(e)}
+                progress("sub-record push_env_tables done")
                 if "f64" in res and "value" in res["f64"]:
                     res["f64_value"] = res["f64"]["value"]      # NB: the bench's solver options (kink crossing + a budget of 256), see f64.solver
                     try:                                          # ... and the same leg under the library's fp64 default: the loop the parity tests pin
