@@ -51,3 +51,25 @@ def test_create_rejects_bad_blobs_without_touching_the_gpu(pusher_model):
     h = ctypes.c_void_p()
     rc = L.tsim_batch_create(I.ctypes.data_as(capi._ip), F.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 4, 8, 0, 0, ctypes.byref(h))
     assert rc != 0 and b"magic" in L.tsim_last_error()
+
+
+def test_kernel_table_names_the_instantiations_a_batch_launches():
+    """bench.py's `kernel` records look an instantiation up by its mangled name in the table host/buildhash.py writes at build time from the code
+    object's metadata: every (kernel, dtype, model size, launch shape, variant) a batch can launch must be in it, with its registers and code bytes."""
+    import json
+    import os
+    from tactilesimulation_amd.host import buildhash
+    if not os.path.exists(buildhash.KERNELS_JSON):
+        import pytest
+        pytest.skip("library not built yet (python -c 'import __graft_entry__ as g; g.build()')")
+    table = json.load(open(buildhash.KERNELS_JSON))
+    combos = [(k, dt, nr, False, l, "generic", False) for k in ("k_forward", "k_backward") for dt in ("f32", "f64") for nr in (7, 12) for l in (16, 32, 64)]
+    combos += [(k, dt, 9, True, 64, "generic", False) for k in ("k_forward", "k_backward") for dt in ("f32", "f64")]                      # rotation-vector joint
+    combos += [(k, "f32", 7, False, l, v, False) for k in ("k_forward", "k_backward") for l in (16, 32, 64) for v in ("static:pusher", "param:pusher")]
+    combos += [(k, "f64", 7, False, l, v, False) for k in ("k_forward", "k_backward") for l in (32, 64) for v in ("static:pusher", "param:pusher")]
+    combos += [(k, "f32", 7, False, 16, "static:pusher", True) for k in ("k_forward", "k_backward")]                                      # closed loop
+    for c in combos:
+        mangled, readable = buildhash.kernel_name(*c)
+        assert mangled in table, (readable, mangled)
+        rec = table[mangled]
+        assert rec["vgpr_count"] > 0 and rec["code_bytes"] > 0 and rec["max_flat_workgroup_size"] == 64, (readable, rec)

@@ -201,7 +201,7 @@ def test_fp64_nonconverged_environments_are_the_oracles_too(pusher_model):
     assert st.shape == (B,)                                                    # an episode launch reports the non-converged sub-steps of the whole episode per environment
     bad = np.nonzero(st)[0]
     assert 1 <= len(bad) <= 4, bad                                            # (2 on this toolchain)
-    assert int(helped[bad].min()) > 0
+    assert int(helped[bad].min()) > 0 or sim.launch_info()["lanes_per_env"] == 64      # (one environment per wavefront, TSIM_LPE=64: no slot to help)
     good = np.setdiff1d(np.arange(5, B, 512), bad)
     med, o_evals = float(np.median(ev)), {}
     for e in list(good) + list(bad):
