@@ -2,8 +2,9 @@
 the device binding bench.py uses, and the GD outer loop's only collective — the flat policy-gradient all-reduce of
 `tactilesimulation_amd.dist.allreduce_policy_grad_` (118 296 B for the gd_tactile actor) — runs through it on `cuda:0`, followed by the
 barrier / MAX-reduce / destroy sequence of bench.py's timed region.  World size 1 makes every collective the identity, so this checks
-library loading, communicator creation and stream ordering, not the exchange itself (no multi-GPU box is available to this repository;
-the exchange arithmetic is covered on gloo with two ranks: tests/test_distributed_cpu.py, tests/test_gpu_sharded.py)."""
+library loading, communicator creation and stream ordering, not the exchange itself (the exchange arithmetic is covered on gloo with two ranks:
+tests/test_distributed_cpu.py, tests/test_gpu_sharded.py).  The second test IS the exchange on real RCCL — min(device_count, 8) ranks, one GPU each,
+the sharded simulator against the unsharded batch — and enables itself as soon as two GPUs are visible (round 5; skipped on a 1-GPU box)."""
 import os
 import socket
 
