@@ -164,3 +164,41 @@ def test_value_first_trials_change_no_number_in_forward_only_launches(name, lane
     for cull, trials, helpers in ((False, 0, False), (True, 2, True)):
         r = _run(m, q0, u, S, dtype, cull, trials, static, helpers=helpers, lanes=lanes, first=True, record=False)
         _same(r, plain, (name, str(dtype), lanes, static, cull, trials, helpers, "value-first"))
+
+
+@pytest.mark.parametrize("record", [True, False])
+@pytest.mark.parametrize("name,lanes", [("pusher", 16), ("dclaw_position_control", 32)])
+def test_the_shortcuts_under_an_evaluation_budget_on_a_ragged_batch(name, lanes, record):
+    """All four options together against none of them where the loop is cut short: an evaluation budget of 3 per sub-step (flagged sub-steps, the
+    take-or-reject decisions at the budget's edge) on a batch that does not fill its last wavefront (67 environments: the idle slots of the last
+    wavefront are helpers from the first round)."""
+    B = 67
+    m, q0, u, S = _case(name, B)
+    dtype = torch.float32
+
+    def run(on):
+        sim = BatchSim(m, B, dtype=dtype, tape_capacity=u.shape[1] * S if record else 0)
+        sim.set_static(False)
+        sim.set_lanes_per_env(lanes)
+        sim.set_solver_options(cross_kinks=True, eval_budget=3)
+        for opt, v in ((BatchSim.OPT_PAIR_CULL, on), (BatchSim.OPT_VALUE_TRIALS, 2 if on else 0), (BatchSim.OPT_TRIAL_HELPERS, on), (BatchSim.OPT_VALUE_FIRST, on)):
+            sim.set_option(opt, v)
+        sim.reset(torch.tensor(q0, device=DEV, dtype=dtype), None, backward_flag=record)
+        ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dtype).transpose(0, 1).contiguous(), S, want_qd=True)
+        ev = sim.last_evals().copy()
+        z = torch.zeros(1)
+        du, lq, lv = z, z, z
+        if record:
+            T = u.shape[1]
+            g = torch.Generator().manual_seed(9)
+            wq = torch.randn(T, B, m.ndof_r, generator=g).to(DEV)
+            wv = torch.randn(T, B, m.ndof_var, generator=g).to(DEV) if m.ndof_var else None
+            wt = torch.randn(T, B, m.ndof_tactile, generator=g).to(DEV)
+            du = sim.backward_episode(T, S, wq, wv, wt)
+            lq, lv = sim.get_adjoint()
+        return ro, ev, du, lq, lv, sim.launch_info()["lanes_per_env"], sim.last_helper_trials().copy()
+    plain, r = run(False), run(True)
+    if plain[5] != lanes:
+        pytest.skip("launch shape falls back to %d lanes per environment" % plain[5])
+    _same(r, plain, (name, lanes, record, "budget"))
+    assert int((plain[0]["status"] != 0).sum()) > 0                                # the budget does cut sub-steps short
