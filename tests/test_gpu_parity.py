@@ -5,6 +5,8 @@ simulator source is absent) — the oracle is this build's restatement, see orac
 Tolerances (stated per test): fp64 kernels must agree with the oracle to round-off; fp32 kernels to the fp32
 tolerance of DESIGN.md §Precision.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -34,9 +36,22 @@ def _oracle(model):
 LANES = [64, 32, 16]          # lanes per environment = 1 / 2 / 4 environments per wavefront; bench.py (B = 4096) runs 16
 
 
-def _batch(model, B, dtype, cap=64, lanes=0):
+KERNELS = ["default", "generic", "tables"]
+# "default": what a TactilePush batch launches — the compiled-in instantiations (fully static where the blob is the asset's, structure-static where a
+# test edits the Newton tolerance; fp32 and, since round 5, fp64); "generic": the same batch kept on the generic kernels (tsim_set_static 0);
+# "tables": one parameter table per environment (fp32: the structure-static instantiation reading its parameters from the table; fp64: generic).
+
+
+def _batch(model, B, dtype, cap=64, lanes=0, kernels="default"):
     from tactilesimulation_amd.host.batch import BatchSim
     sim = BatchSim(model, B, device="cuda:0", dtype=dtype, tape_capacity=cap)
+    if kernels == "generic":
+        sim.set_static(False)
+    if kernels == "tables":
+        sim.set_env_tables(sim.base_tables())
+    if not os.environ.get("TSIM_NO_STATIC"):
+        want = {"default": ("static:pusher", "param:pusher"), "generic": ("generic",), "tables": ("param:pusher",) if dtype == torch.float32 else ("generic",)}[kernels]
+        assert sim.kernel_variant() in want, (kernels, sim.kernel_variant())
     if lanes:
         sim.set_lanes_per_env(lanes)
         got = sim.launch_info()["lanes_per_env"]
@@ -91,13 +106,14 @@ def test_residual_and_newton_matrix(pusher_model, dtype, tol, lanes):
     (torch.float64, 1e-13, 1e-9, 1e-6),      # arithmetic parity: round-off only
     (torch.float64, None, 1e-5, 1e-2),       # XML tolerance (1e-8): solver-tolerance bound
     (torch.float32, None, 2e-5, 2e-3)])      # fp32 path (mixed precision: double pose chain)
+@pytest.mark.parametrize("kernels", KERNELS)
 @pytest.mark.parametrize("lanes", LANES)
-def test_forward_rollout(pusher_model, dtype, newton_tol, tol_q, tol_tac, lanes):
+def test_forward_rollout(pusher_model, dtype, newton_tol, tol_q, tol_tac, lanes, kernels):
     """20 env-steps (100 implicit sub-steps) of 16 envs: q, qd, variables, tactile vs oracle."""
     m = pusher_model if newton_tol is None else _with_tol(pusher_model, newton_tol)
     B, T = 16, 20
     q0, u, _ = push_workload(B, T, seed=0)
-    sim = _batch(m, B, dtype, lanes=lanes)
+    sim = _batch(m, B, dtype, lanes=lanes, kernels=kernels)
     sim.reset(torch.tensor(q0), None, backward_flag=False)
     var0, tac0 = sim.readout()
     o = _oracle(m)
@@ -131,16 +147,17 @@ def test_forward_rollout(pusher_model, dtype, newton_tol, tol_q, tol_tac, lanes)
             assert np.abs(outs[t]["tactile"][e] - tc).max() <= tol_tac * scale, (e, t)
 
 
+@pytest.mark.parametrize("kernels", KERNELS)
 @pytest.mark.parametrize("lanes", LANES)
 @pytest.mark.parametrize("dtype,newton_tol,tol", [(torch.float64, 1e-13, 1e-7), (torch.float64, None, 1e-4), (torch.float32, None, 1e-4)])
-def test_adjoint_vs_oracle(pusher_model, dtype, newton_tol, tol, lanes):
+def test_adjoint_vs_oracle(pusher_model, dtype, newton_tol, tol, lanes, kernels):
     """dL/du for L = sum_t w_q.q_t + w_v.var_t + w_t.tactile_t over 10 env-steps, 8 envs; plus carried adjoint."""
     m = pusher_model if newton_tol is None else _with_tol(pusher_model, newton_tol)
     B, T, S = 8, 10, 5
     q0, u, _ = push_workload(B, T, seed=1)
     rng = np.random.default_rng(5)
     wq, wv, wt = rng.normal(size=(T, 7)), rng.normal(size=(T, 6)), rng.normal(size=(T, 390)) * 10.0
-    sim = _batch(m, B, dtype, cap=T * S, lanes=lanes)
+    sim = _batch(m, B, dtype, cap=T * S, lanes=lanes, kernels=kernels)
     sim.reset(torch.tensor(q0), None, backward_flag=True)
     ud = torch.tensor(u)
     for t in range(T):

@@ -43,14 +43,16 @@ def test_pusher_kinematics_on_the_kernels(pusher_model, dt):
     assert np.allclose(dv[6], (0, 0, 0, -0.025 * (math.cos(d) - 1), -0.025 * math.sin(d), 0), atol=t)
 
 
+@pytest.mark.parametrize("static", [True, False])
 @pytest.mark.parametrize("dt", [torch.float64, torch.float32])
-def test_push_taxel_magnitudes_on_the_kernels(pusher_model, dt):
+def test_push_taxel_magnitudes_on_the_kernels(pusher_model, dt, static):
     """envs/tactile_push_env.py:285-286 draws shear / 3e-6 and normal / 3e-3: a steady straight push puts the kernels' taxel outputs within
     a decade of both (and the two three decades apart)."""
     forces = (0.2, 0.3)
     B = len(forces)
     q0, _, _ = W.push_workload(B, 1, seed=0)
     sim = BatchSim(pusher_model, B, dtype=dt, tape_capacity=0)
+    sim.set_static(static)                                      # the compiled-in TactilePush kernels (both precisions) and the generic ones
     sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None)
     u = torch.zeros(100, B, 6, device=DEV, dtype=dt)
     for e, f in enumerate(forces):
