@@ -206,17 +206,44 @@ class Leg:
             self.wqT, self.wvT, self.wtT = ((w.unsqueeze(0).expand(T, -1, -1).contiguous() if w is not None else None) for w in (self.wq, self.wv, self.wt))
         self.grad_buf = torch.zeros(POLICY_GRAD_FLOATS, device=dev, dtype=torch.float32)
         self.out = {}
-        self.ev = {"fwd": [], "bwd": []}
+        self.ev = {"fwd": [], "bwd": [], "episode": []}
+        self.graph = None
 
-    def run(self, k_total, timed, launch):
+    def capture(self, n):
+        """An episode of n frames — reset, episode launch forward, episode launch backward, reduction of dL/du into the gradient buffer — as ONE HIP
+        graph (host/graphed.GraphedEpisode).  Replayed by run(..., graphed=True) for episodes of exactly that length; BDF1 models only."""
+        from tactilesimulation_amd.host.graphed import GraphedEpisode
+        wl, S = self.wl, self.wl["S"]
+        ng = min(6, self.nu)
+
+        def post(ro, du):
+            if du is not None:
+                self.grad_buf[:ng] = du.sum((0, 1)).float()[:ng]
+            return None
+        seeds = None if self.forward_only else (self.wqT[:n], self.wvT[:n] if self.wvT is not None else None, self.wtT[:n])
+        mask = wl["tactile_mask"][:n] if "tactile_mask" in wl else None
+        self.graph = GraphedEpisode(self.sim, wl["q0"], wl["u"][:n], S, seeds=seeds, tactile_mask=mask, post=post)
+        self.graph_n = n
+
+    def run(self, k_total, timed, launch, graphed=False):
         sim, wl, T, S, u = self.sim, self.wl, self.wl["T"], self.wl["S"], self.wl["u"]
         done = bad = 0
         Ev = lambda: torch.cuda.Event(enable_timing=True)
         ng = min(6, self.nu)
         while done < k_total:
             n = min(T, k_total - done)
-            sim.reset(wl["q0"], None, backward_flag=not self.forward_only)
-            if launch == "episode":
+            if graphed and launch == "episode" and self.graph is not None and n == self.graph_n:
+                # one replay = one whole episode (reset, forward launch, backward launch, gradient reduction): no events INSIDE a graph, the pair brackets it
+                e0, e1 = Ev(), Ev()
+                e0.record()
+                ro, _, _ = self.graph.replay()
+                e1.record()
+                status = ro["status"]
+                if timed:
+                    self.status_log.append(status.clone())
+                    self.ev["episode"].append((e0, e1, n))
+            elif launch == "episode":
+                sim.reset(wl["q0"], None, backward_flag=not self.forward_only)
                 e0, e1, e2 = Ev(), Ev(), Ev()
                 e0.record()
                 ro = sim.rollout(u[:n], S, tactile_mask=wl["tactile_mask"][:n]) if "tactile_mask" in wl else sim.rollout(u[:n], S)
@@ -233,6 +260,7 @@ class Leg:
                     if not self.forward_only:
                         self.ev["bwd"].append((e1, e2, n))
             else:
+                sim.reset(wl["q0"], None, backward_flag=not self.forward_only)
                 for t in range(n):
                     if timed:
                         e0, e1 = Ev(), Ev()
@@ -385,6 +413,8 @@ def main():
     ap.add_argument("--frame-skip", type=int, default=5)
     ap.add_argument("--episode", type=int, default=None, help="env-steps per episode (tape length / frame_skip; default: the workload's)")
     ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps each; `value` is the median window (all are listed in `repeats`)")
+    ap.add_argument("--graph", action="store_true", help="replay each episode of the timed windows from ONE HIP graph (host/graphed.GraphedEpisode) after two eager windows that carry the kernels' HIP events; "
+                    "measured at the headline's shape: 20.95 M against 20.97 M eager — the window is kernel time, not host time (profiles/r05_graphed_episode.md) — so off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (roofline.traffic / roofline.valu then "
                     "come from the committed profile of this command, with the source stated)")
@@ -484,11 +514,10 @@ def main():
     # The timed region of the contract — exactly K steps between barrier + synchronize on both sides, max over ranks — REPEATED (--repeats, default
     # 5): at K = 20 the region is one forward and one backward launch, 4 ms, and run-to-run spread is +-5 %.  `value` is the MEDIAN window's;
     # every window's value is listed next to it (`repeats`).  The HIP-event kernel times are those of all windows.
-    windows = []
-    for rep in range(max(1, args.repeats)):
+    def timed_window(graphed):
         sync_all()
         t0 = time.perf_counter()
-        run_steps(args.steps * fps, True, args.launch)
+        run_steps(args.steps * fps, True, args.launch, graphed=graphed)
         torch.cuda.synchronize()
         dt_own_ = time.perf_counter() - t0          # this rank's own work, before it waits for the others
         sync_all()
@@ -498,10 +527,25 @@ def main():
             tt = torch.tensor([dt_], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
-        windows.append((dt_, dt_own_))
+        return dt_, dt_own_
+    # --graph: the episode as ONE HIP graph (reset, forward launch, backward launch, gradient reduction; host/graphed.GraphedEpisode).  The value then comes
+    # from graph-replayed windows; two EAGER windows are timed the same way before them — they carry the HIP events of the individual kernels (no events
+    # inside a graph) and are listed next to the others (`repeats.eager_values`).  Default: eager windows only (at the headline's shape a window IS its
+    # kernels: 3.08 + 0.83 ms of 3.91).
+    graph_note = None
+    n_ep = min(T, args.steps * fps)
+    if args.launch == "episode" and args.graph:
+        try:
+            leg.capture(n_ep)
+            graph_note = {"used": True, "frames_per_replay": n_ep, "what": "reset + tsim_rollout + tsim_backward_episode + reduction of dL/du, one HIP graph per episode"}
+        except Exception as e:          # the eager path is always there
+            leg.graph = None
+            graph_note = {"used": False, "error": repr(e)}
+    eager_windows = [timed_window(False) for _ in range(2 if leg.graph is not None else max(1, args.repeats))]
+    windows = [timed_window(True) for _ in range(max(1, args.repeats))] if leg.graph is not None else eager_windows
     order_ = sorted(range(len(windows)), key=lambda i: windows[i][0])
     dt, dt_own = windows[order_[len(order_) // 2]]
-    n_win = len(windows)
+    n_win = len(eager_windows)                       # the windows the HIP events of the individual kernels cover
     per_rank = None
     if world > 1:
         import torch.distributed as dist
@@ -571,7 +615,9 @@ def main():
                                    "%s; %s.xml, ndof_r %d, %d tactile values, frame_skip %d, batch %d envs/GPU, episodes of %d frames" % (cfg_text, asset_, nr, ntac, S, B, T),
                        "global_batch": B * world, "parallelism": "env-sharded x%d, policy-grad all-reduce %d B/episode" % (world, 4 * POLICY_GRAD_FLOATS)},
             "solver": leg.solver,
-            "repeats": {"windows": n_win, "steps_per_window": args.steps, "value_is": "median window", "values": [B * world * args.steps / w[0] for w in windows],
+            "repeats": {"windows": len(windows), "steps_per_window": args.steps, "value_is": "median window" + (" (episodes replayed from one HIP graph each)" if leg.graph is not None else ""),
+                        "graph": graph_note, "eager_values": [B * world * args.steps / w[0] for w in eager_windows],
+                        "values": [B * world * args.steps / w[0] for w in windows],
                         "min": B * world * args.steps / max(w[0] for w in windows), "max": B * world * args.steps / min(w[0] for w in windows),
                         "first": B * world * args.steps / windows[0][0], "timed_region_s_each": [w[0] for w in windows]},
             "kernel": kernel_record(sim, args.dtype, forward_only),

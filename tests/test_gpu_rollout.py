@@ -305,3 +305,42 @@ def test_full_episodes_against_the_oracle(pusher_model, dtype, tq, tt, tg, lanes
     assert np.abs(ro["tactile"].double().cpu().numpy() - TAC).max() < tt * np.abs(TAC).max()
     eg = np.abs(du - G).max(axis=(0, 2)) / np.abs(G).max(axis=(0, 2))
     assert eg.max() < tg, eg.max()
+
+
+@pytest.mark.parametrize("name,adjoint", [("pusher", True), ("pusher", False), ("dclaw_position_control", False)])
+def test_graphed_open_loop_episode_equals_the_eager_calls(name, adjoint):
+    """host/graphed.GraphedEpisode: reset + episode launch forward + episode launch backward replayed from ONE HIP graph give the bits of the eager
+    calls — also after new episode data was written into the static inputs, and replay after replay."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.host.graphed import GraphedEpisode
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd.workloads import asset, dclaw_random_workload, push_workload
+    B, T, S, dt = 512, 8, 5, torch.float32
+    m = load_model(asset(name))
+    data = [push_workload(B, T, seed=s_)[:2] if name == "pusher" else dclaw_random_workload(B, T, seed=s_) for s_ in (1, 2)]
+    g = torch.Generator().manual_seed(4)
+    seeds = None
+    if adjoint:
+        seeds = tuple(torch.randn(T, B, n, generator=g).to("cuda") for n in (m.ndof_r, m.ndof_var, m.ndof_tactile))
+
+    def eager(q0, u):
+        sim = BatchSim(m, B, dtype=dt, tape_capacity=T * S if adjoint else 0)
+        for _ in range(2):                                      # twice: the second episode launch runs in the LPT order of the first, as a replay does
+            sim.reset(torch.tensor(q0, device="cuda", dtype=dt), None, backward_flag=adjoint)
+            ro = sim.rollout(torch.tensor(u, device="cuda", dtype=dt).transpose(0, 1).contiguous(), S)
+            du = sim.backward_episode(T, S, *seeds) if adjoint else None
+        return ro, du
+    sim = BatchSim(m, B, dtype=dt, tape_capacity=T * S if adjoint else 0)
+    q0s = torch.tensor(data[0][0], device="cuda", dtype=dt)
+    us = torch.tensor(data[0][1], device="cuda", dtype=dt).transpose(0, 1).contiguous()
+    ge = GraphedEpisode(sim, q0s, us, S, seeds=seeds)
+    for k in (0, 1, 0):
+        q0s.copy_(torch.tensor(data[k][0], device="cuda", dtype=dt)); us.copy_(torch.tensor(data[k][1], device="cuda", dtype=dt).transpose(0, 1))
+        ro, du, _ = ge.replay()
+        torch.cuda.synchronize()
+        ro_e, du_e = eager(*data[k])
+        for key in ("q", "var", "tactile", "status"):
+            if key in ro_e:
+                assert torch.equal(ro[key], ro_e[key]), (name, k, key)
+        if adjoint:
+            assert torch.equal(du, du_e), (name, k)

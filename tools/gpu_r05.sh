@@ -63,9 +63,10 @@ z)  # the round's evidence run: full GPU suite, the driver's bench command (with
   ( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 ) > ${O}_tests.log 2>&1
   timeout 900 python bench.py --steps 20 --warmup 5 --pmc-dump ${O}_pmc_f32.json > ${O}_bench.json 2> ${O}_bench.err
   R=$PWD
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_push -o kt -- python $R/bench.py --steps 20 --warmup 5 --timed-only --no-pmc > /dev/null 2>&1 ); cp $(find /tmp/kt_push -name "*kernel_stats.csv" | head -1) ${O}_rocprof_kernel_stats_f32_steps20.csv
-  for w in dclaw insertion; do ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -o kt -- python $R/bench.py --workload $w --timed-only --no-pmc --repeats 1 > /dev/null 2>&1 ); cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) ${O}_rocprof_kernel_stats_$w.csv; done
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_f64 -o kt -- python $R/bench.py --dtype f64 --steps 20 --warmup 5 --timed-only --no-pmc > /dev/null 2>&1 ); cp $(find /tmp/kt_f64 -name "*kernel_stats.csv" | head -1) ${O}_rocprof_kernel_stats_f64_steps20.csv
+  # (warm-up as long as an episode: every dispatch of a kernel in the stats is then ONE full launch — a 5-step warm-up launch would be averaged in)
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_push -o kt -- python $R/bench.py --steps 20 --warmup 20 --timed-only --no-pmc > /dev/null 2>&1 ); cp $(find /tmp/kt_push -name "*kernel_stats.csv" | head -1) ${O}_rocprof_kernel_stats_f32_steps20.csv
+  for w in dclaw insertion; do ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -o kt -- python $R/bench.py --workload $w --steps $([ $w = dclaw ] && echo 50 || echo 9) --warmup $([ $w = dclaw ] && echo 50 || echo 9) --timed-only --no-pmc --repeats 2 > /dev/null 2>&1 ); cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) ${O}_rocprof_kernel_stats_$w.csv; done
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_f64 -o kt -- python $R/bench.py --dtype f64 --steps 20 --warmup 20 --timed-only --no-pmc > /dev/null 2>&1 ); cp $(find /tmp/kt_f64 -name "*kernel_stats.csv" | head -1) ${O}_rocprof_kernel_stats_f64_steps20.csv
   timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-sub-records --no-closed-loop > ${O}_bench_steps100.json 2> ${O}_bench_steps100.err
   ;;
 esac
