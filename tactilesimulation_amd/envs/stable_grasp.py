@@ -10,8 +10,11 @@ The environment-side arithmetic is the reference's, pinned on golden vectors rec
   * observation: shear components of that frame, normalised to a largest vector of 30, flattened (1, 2, 13, 10, 2)  (:246-262)
   * success: the bar's rotation vector at the captured frame shorter than 0.02 and the bar lifted (q[8] > 0.005): reward 100 and done;
     otherwise reward -10 |rotation vector|                                                                       (:264-283)
-The reset-time randomisation of the eleven block densities (:68-129) changes the composite inertia of the bar: per-environment tables
-drawn from a pool of compiled variants, as for D'Claw.
+The reset-time randomisation of the eleven block densities (:68-129) changes the composite inertia of the bar: per-environment tables, either
+drawn from a pool of compiled variants (`variants=K`, rounds 3-4) or — `randomize=True`, round 5: what the reference does, a fresh draw per
+environment per reset — computed on the device from per-environment density draws: the bar's mass, first moment and second moment about the
+link origin are LINEAR in the eleven densities (coefficients fitted once from host compilations, checked to 1e-13), its centre of mass and
+inertia about it follow from them.
 """
 import numpy as np
 import torch
@@ -87,7 +90,7 @@ def draw_block_densities(rng):
 class BatchedStableGraspEnv:
     max_episode_steps = 10                                            # envs/__init__.py
 
-    def __init__(self, batch_size, model=None, device="cuda:0", dtype=torch.float32, seed=0, variants=8):
+    def __init__(self, batch_size, model=None, device="cuda:0", dtype=torch.float32, seed=0, variants=8, randomize=False):
         self.model = mc.load_model(asset("stable_grasp")) if model is None else model
         self.B, self.device, self.dtype = int(batch_size), torch.device(device), dtype
         self.sim = BatchSim(self.model, self.B, device=device, dtype=dtype, tape_capacity=0)
@@ -98,7 +101,11 @@ class BatchedStableGraspEnv:
         self.mask = torch.zeros(sum(GRASP_STEPS), dtype=torch.bool)
         self.mask[CAPTURE_FRAME] = True
         self.q_reference = self._generate_initial_state()
-        self._build_variants(int(variants))
+        self.randomize = bool(randomize)
+        if self.randomize:
+            self._build_randomiser()
+        else:
+            self._build_variants(int(variants))
         self.current_q = self.q_reference.repeat(self.B, 1)
         self.grasp_position = torch.zeros(self.B, device=self.device, dtype=dtype)
         self.steps = torch.zeros(self.B, device=self.device, dtype=torch.long)
@@ -125,6 +132,82 @@ class BatchedStableGraspEnv:
         self._variant_rows = torch.tensor(np.array(rows), device=self.device, dtype=self.dtype)
         self.variant_of = torch.zeros(self.B, device=self.device, dtype=torch.long)
 
+    # ------------------------------------------------------------------ continuous density draws on the device (randomize=True)
+    @staticmethod
+    def edited_model(model, densities):
+        """The model with the eleven block densities set on the host (update_body_density, envs/stable_grasp_env.py:117-129), compiled."""
+        spec = mc.compile_spec(model.spec).spec
+        for i, b in enumerate(BOX_IDS):
+            mc.edit_spec(spec, "body_density", "box_%d" % b, float(densities[i]))
+        return mc.compile_spec(spec)
+
+    def _build_randomiser(self):
+        """The bar is ONE link made of eleven blocks: its mass M, first moment S = M c and second moment about the link origin
+        J = I_c + M (|c|^2 1 - c c^T) are linear in the densities.  The 10 x 11 coefficients are fitted from host compilations of drawn density
+        vectors (no assumption about the blocks' geometry), checked on held-out draws to 1e-13; the ten float records of that link — mass, centre of
+        mass, inertia about it — are then written per environment on the device."""
+        from ..model import blob as Bl
+        n = self.sim.base_tables().shape[1]
+        D = np.array([draw_block_densities(self.rng) for _ in range(16)])
+        rows = []
+        for d in D:
+            m = self.edited_model(self.model, d)
+            assert np.array_equal(m.I, self.model.I) and np.array_equal(m.F[n:], self.model.F[n:])
+            rows.append(m.F[:n])
+        R = np.array(rows)
+        changed = np.nonzero((R != R[0]).any(0))[0]
+        fl = int(self.model.I[Bl.TSIM_IH_FOFF_LINK])
+        link = (int(changed[0]) - fl) // Bl.TSIM_LF_SIZE                        # the bar's link (0-based record)
+        base = fl + link * Bl.TSIM_LF_SIZE
+        rec = np.concatenate([[base + Bl.TSIM_LF_MASS], base + Bl.TSIM_LF_COM + np.arange(3), base + Bl.TSIM_LF_INERTIA + np.arange(6)])
+        assert set(changed) <= set(rec), "the densities change records outside the bar's mass / centre of mass / inertia"
+        Y = np.array([self._moments(r[rec]) for r in R])
+        A = np.concatenate([D, np.ones((len(D), 1))], axis=1)
+        coef = np.linalg.lstsq(A[:13], Y[:13], rcond=None)[0]
+        assert np.abs(A[13:] @ coef - Y[13:]).max() <= 1e-13 * np.abs(Y).max()
+        self._rec = torch.tensor(rec, device=self.device, dtype=torch.long)
+        self._coef = torch.tensor(coef, device=self.device, dtype=torch.float64)          # [12, 10]: rows = eleven densities + intercept
+        self.densities = torch.zeros(self.B, 11, device=self.device, dtype=torch.float64)
+        self.tables = self.sim.base_tables().contiguous()
+
+    @staticmethod
+    def _moments(r):
+        """(mass, com[3], inertia about com xx yy zz xy xz yz) -> (M, S[3], J[6] about the origin)."""
+        M, c, (xx, yy, zz, xy, xz, yz) = r[0], r[1:4], r[4:10]
+        cc = float(c @ c)
+        return np.array([M, M * c[0], M * c[1], M * c[2], xx + M * (cc - c[0] ** 2), yy + M * (cc - c[1] ** 2), zz + M * (cc - c[2] ** 2),
+                         xy - M * c[0] * c[1], xz - M * c[0] * c[2], yz - M * c[1] * c[2]])
+
+    def _draw_densities(self):
+        """draw_block_densities (the reference's :68-115) for every environment at once, on the device: [B, 11] float64."""
+        B, dev, f64 = self.B, self.device, torch.float64
+        u = lambda *shape: torch.rand(*shape, device=dev, dtype=f64, generator=self.gen)
+        com = 1.0 + 9.0 * u(B)
+        nl = torch.floor(com).clamp(max=9.0)
+        nr = 10.0 - nl
+        mid_left = com - nl
+        mid = 600.0 + 100.0 * u(B)
+        side = 600.0 + 100.0 * u(B)
+        small = mid_left < 0.5
+        right = torch.where(small, side * nr, side * nl + (mid_left * 2 - 1) * mid)
+        left = torch.where(small, side * nr + (1 - mid_left * 2) * mid, side * nl)
+        i = torch.arange(11, device=dev, dtype=f64)[None]
+        wl = (u(B, 11) + 0.1) * (i < nl[:, None])
+        wr = (u(B, 11) + 0.1) * (i > nl[:, None])
+        d = left[:, None] * wl / wl.sum(1, keepdim=True).clamp_min(1e-300) + right[:, None] * wr / wr.sum(1, keepdim=True).clamp_min(1e-300) + mid[:, None] * (i == nl[:, None])
+        tot = d.sum(1, keepdim=True)
+        return d / tot * tot.clamp(3000.0, 7000.0)
+
+    def _randomise(self, mask):
+        self.densities.copy_(torch.where(mask[:, None], self._draw_densities(), self.densities))
+        Y = torch.cat([self.densities, torch.ones(self.B, 1, device=self.device, dtype=torch.float64)], dim=1) @ self._coef      # M, S, J
+        M, c = Y[:, 0:1], Y[:, 1:4] / Y[:, 0:1]
+        cc = (c * c).sum(1, keepdim=True)
+        diag = Y[:, 4:7] - M * (cc - c * c)
+        off = Y[:, 7:10] + M * torch.stack([c[:, 0] * c[:, 1], c[:, 0] * c[:, 2], c[:, 1] * c[:, 2]], dim=1)
+        self.tables[:, self._rec] = torch.cat([M, c, diag, off], dim=1).to(self.dtype)
+        self.sim.set_env_tables(self.tables)
+
     def _grasp(self):
         start, act = grasp_actions(self.current_q, self.grasp_position)
         self.sim.reset(start, None, backward_flag=False)
@@ -138,9 +221,12 @@ class BatchedStableGraspEnv:
         """New episodes for the environments in mask (all when None): a new bar (density variant), grasp position 0, the settled open
         gripper; then one grasp (the first observation)."""
         m = torch.ones(self.B, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).bool()
-        new = torch.randint(0, self._variant_rows.shape[0], (self.B,), device=self.device, generator=self.gen)
-        self.variant_of = torch.where(m, new, self.variant_of)
-        self.sim.set_env_tables(self._variant_rows[self.variant_of].contiguous())
+        if self.randomize:
+            self._randomise(m)
+        else:
+            new = torch.randint(0, self._variant_rows.shape[0], (self.B,), device=self.device, generator=self.gen)
+            self.variant_of = torch.where(m, new, self.variant_of)
+            self.sim.set_env_tables(self._variant_rows[self.variant_of].contiguous())
         self.current_q = torch.where(m[:, None], self.q_reference.repeat(self.B, 1), self.current_q)
         self.grasp_position = torch.where(m, torch.zeros_like(self.grasp_position), self.grasp_position)
         self.steps = torch.where(m, torch.zeros_like(self.steps), self.steps)

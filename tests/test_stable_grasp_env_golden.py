@@ -56,3 +56,36 @@ def test_batched_env_on_the_simulator():
     assert torch.equal(E.observation(ro["tactile"][0])[0], obs[e]) and torch.equal(ro["q"][-1][0], env.current_q[e])
     # densities matter: variants differ in the tilt of the lifted bar
     assert float(r.std()) > 0
+
+
+@pytest.mark.gpu
+def test_continuous_density_draws_per_environment_on_the_device():
+    """randomize=True: every environment its own eleven block densities at each (masked) reset, as the reference draws them per environment per reset
+    (envs/stable_grasp_env.py:68-129), and the bar's mass / centre of mass / inertia written into its table on the device from the linear moments.
+    Rows equal the float records of the model compiled on the host from the same densities (1e-12); one environment alone on that compiled model
+    gives the same grasp (q to 1e-9: the rows differ in the last bits)."""
+    from tactilesimulation_amd.envs import stable_grasp as E
+    from tactilesimulation_amd.host.batch import BatchSim
+    B = 16
+    env = E.BatchedStableGraspEnv(B, dtype=torch.float64, seed=6, randomize=True)
+    env.reset()
+    d = env.densities.cpu().numpy()
+    assert (d > 0).all() and (d.sum(1) >= 3000 - 1e-6).all() and (d.sum(1) <= 7000 + 1e-6).all() and len(np.unique(d[:, 0])) == B
+    tables = env.tables.cpu().numpy()
+    n = tables.shape[1]
+    u = torch.tensor(np.random.default_rng(1).uniform(-1.2, 1.2, size=(B, 1)), device="cuda")
+    q_prev = env.current_q.clone()
+    obs, r, done, info = env.step(u)
+    assert int((info["status"] != 0).sum()) == 0 and float(r.std()) > 0
+    for e in (0, 5, B - 1):
+        m = E.BatchedStableGraspEnv.edited_model(env.model, d[e])
+        assert (np.abs(tables[e] - m.F[:n]) <= 1e-12 * np.maximum(np.abs(m.F[:n]), 1e-6)).all(), (e, np.abs(tables[e] - m.F[:n]).max())
+        one = BatchSim(m, 1, dtype=torch.float64, tape_capacity=0)
+        start, act = E.grasp_actions(q_prev[e:e + 1], env.grasp_position[e:e + 1])
+        one.reset(start, None, backward_flag=False)
+        ro = one.rollout(act, 1, want_var=False, tactile_mask=env.mask)
+        assert float((ro["q"][-1][0] - env.current_q[e]).abs().max()) < 1e-9
+    mask = torch.zeros(B, dtype=torch.bool, device="cuda"); mask[::4] = True
+    env.reset(mask)
+    d2, mk = env.densities.cpu().numpy(), mask.cpu().numpy()
+    assert np.array_equal(d2[~mk], d[~mk]) and (d2[mk] != d[mk]).any(1).all()
