@@ -165,6 +165,14 @@ int tsim_debug_stamps(tsim_batch* b, long long* cycles);
  * from the batch size and the device's SIMD count, override with the environment variable TSIM_LPE at
  * tsim_batch_create). out = int32[4]. */
 int tsim_launch_info(const tsim_batch* b, int32_t* out);
+/* Measurement (no reference counterpart; what bench.py's per-kernel roofline is timed with): while enabled, every launch of the simulation
+ * kernels by this batch — k_forward, the tactile read-out kernel that follows it (k_taxels / k_taxels_small), k_backward — is bracketed by a
+ * pair of HIP events recorded on the stream the kernel is launched on (never inside a stream capture).  tsim_kernel_times waits for the
+ * recorded pairs, returns per kind the summed milliseconds and the number of launches since the previous call (HOST double[TSIM_KT_COUNT],
+ * int32[TSIM_KT_COUNT]) and forgets them. */
+enum { TSIM_KT_FORWARD = 0, TSIM_KT_TAXELS = 1, TSIM_KT_BACKWARD = 2, TSIM_KT_COUNT = 3 };
+int tsim_kernel_timing(tsim_batch* b, int enable);
+int tsim_kernel_times(tsim_batch* b, double* ms_sum, int32_t* launches);
 /* Force 16 / 32 / 64 lanes per environment (0 = automatic again).  For callers that split a batch into groups on several
  * streams: each group is then small, but the groups together should still fill the device. */
 int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes effect with the next launch */

@@ -399,6 +399,7 @@ struct DeviceGuard {
 #define TS_DEVICE(b) DeviceGuard guard_((b)->device); if (!guard_.ok) return fail("hipSetDevice(" + std::to_string((b)->device) + ") failed")
 
 struct CacheEntry { void* buf; int len; int record; };
+struct KtPair { hipEvent_t a, b; int kind; };
 struct tsim_batch {
   int B, dtype, device, cap;
   std::vector<int32_t> I; std::vector<double> F;
@@ -445,6 +446,28 @@ struct tsim_batch {
   std::vector<void*> pool;          // spare tape buffers
   std::vector<void*> retired;       // per-frame pose records replaced by larger ones while a captured graph may still name them (launch_forward)
   long long* bwd_stamps = nullptr;  // diagnostics (tsim_debug_stamps)
+  // tsim_kernel_timing: HIP events around every launch of the simulation kernels, on the stream they are launched on
+  int kt_on = 0;
+  std::vector<KtPair> kt;           // pairs recorded since the last tsim_kernel_times
+  std::vector<hipEvent_t> kt_free;  // events to reuse
+};
+// One timed launch: start event in the constructor, stop event in the destructor (nothing under stream capture: no events inside a graph).
+struct KtScope {
+  tsim_batch* b; hipStream_t st; KtPair p; bool on = false;
+  KtScope(tsim_batch* b_, int kind, hipStream_t st_) : b(b_), st(st_) {
+    if (!b->kt_on) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+    hipEvent_t e[2];
+    for (int i = 0; i < 2; ++i) {
+      if (!b->kt_free.empty()) { e[i] = b->kt_free.back(); b->kt_free.pop_back(); }
+      else if (hipEventCreate(&e[i]) != hipSuccess) { (void)hipGetLastError(); if (i) b->kt_free.push_back(e[0]); return; }
+    }
+    p.a = e[0]; p.b = e[1]; p.kind = kind;
+    on = hipEventRecord(p.a, st) == hipSuccess;
+    if (!on) { b->kt_free.push_back(e[0]); b->kt_free.push_back(e[1]); }
+  }
+  ~KtScope() { if (on) { (void)hipEventRecord(p.b, st); b->kt.push_back(p); } }
 };
 // The state changed other than by a forward launch (or is about to, in a captured graph): tsim_readout recomputes the kinematics.
 static void pose_invalidate(tsim_batch* b, hipStream_t st) {
@@ -817,9 +840,9 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.free_run = (defer || !tac_out || b->ntax == 0) && !b->ab_no_free_run;
   a.lockstep = b->ab_lockstep ? 1 : 0;
   if (a.lockstep) a.free_run = 0;
-  TS_LAUNCH(k_forward, R, b, st, a);
+  { KtScope kt_(b, TSIM_KT_FORWARD, st); TS_LAUNCH(k_forward, R, b, st, a); }
   HIPCHK(hipGetLastError());
-  if (defer && launch_taxels<R>(b, b->fposeR, b->fposeD, nframes, tac_slot, tac_out, st)) return 1;
+  if (defer) { KtScope kt_(b, TSIM_KT_TAXELS, st); if (launch_taxels<R>(b, b->fposeR, b->fposeD, nframes, tac_slot, tac_out, st)) return 1; }
   b->pose_valid = emit ? 1 : 0;
   if (b->B >= 256) {
     const int ns = TS_WAVE / launch_shape(b).lpe, nsv = (b->B % ns == 0) ? ns : 1;
@@ -842,7 +865,7 @@ static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, co
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames; a.tac_slot = tac_slot;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = b->bwd_stamps; a.cull = b->pair_cull;
-  TS_LAUNCH(k_backward, R, b, st, a);
+  { KtScope kt_(b, TSIM_KT_BACKWARD, st); TS_LAUNCH(k_backward, R, b, st, a); }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -921,6 +944,8 @@ void tsim_batch_destroy(tsim_batch* b) {
   for (auto& e : b->cache) (void)hipFree(e.buf);
   for (void* p : b->pool) (void)hipFree(p);
   for (void* p : b->retired) (void)hipFree(p);
+  for (auto& k : b->kt) { (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b); }
+  for (hipEvent_t e : b->kt_free) (void)hipEventDestroy(e);
   (void)hipFree(b->dFenv); (void)hipFree(b->dI); (void)hipFree(b->dF); (void)hipFree(b->tape); (void)hipFree(b->lamq); (void)hipFree(b->lamv); (void)hipFree(b->evals); (void)hipFree(b->helped); (void)hipFree(b->gnorm); (void)hipFree(b->order); (void)hipFree(b->order_ep); (void)hipFree(b->prev); (void)hipFree(b->poseR); (void)hipFree(b->poseD); (void)hipFree(b->fposeR); (void)hipFree(b->fposeD); (void)hipFree(b->dKmask); (void)hipFree(b->dFlag);
   delete b;
 }
@@ -936,6 +961,21 @@ int tsim_tape_len(const tsim_batch* b) { return b->record ? b->t_cur : 0; }
 int tsim_launch_info(const tsim_batch* b, int32_t* out) {
   const LaunchShape L = launch_shape(b);
   out[0] = (int32_t)L.lds; out[1] = TS_WAVE; out[2] = (int32_t)L.grid; out[3] = L.lpe;
+  return 0;
+}
+int tsim_kernel_timing(tsim_batch* b, int enable) { b->kt_on = enable ? 1 : 0; return 0; }
+int tsim_kernel_times(tsim_batch* b, double* ms_sum, int32_t* launches) {
+  if (!ms_sum || !launches) return fail("kernel_times: null argument");
+  TS_DEVICE(b);
+  for (int k = 0; k < TSIM_KT_COUNT; ++k) { ms_sum[k] = 0.0; launches[k] = 0; }
+  for (auto& p : b->kt) {
+    float ms = 0.f;
+    HIPCHK(hipEventSynchronize(p.b));
+    HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+    ms_sum[p.kind] += ms; launches[p.kind] += 1;
+    b->kt_free.push_back(p.a); b->kt_free.push_back(p.b);
+  }
+  b->kt.clear();
   return 0;
 }
 int tsim_set_lanes_per_env(tsim_batch* b, int lanes) {
@@ -1112,11 +1152,11 @@ int tsim_readout(tsim_batch* b, void* var_out, void* tac_out, void* stream) {
   if (b->dtype == TSIM_F32) {
     ReadArgs<float> a{b->dI, (const float*)b->dF, (const float*)b->dFenv, b->nfrec, b->B, b->t_cur, (const float*)b->tape, (float*)var_out, tac ? (float*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
     if (fk) hipLaunchKernelGGL(k_readout<float>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
-    if (tac && launch_taxels<float>(b, b->poseR, b->poseD, 1, nullptr, tac_out, st)) return 1;
+    if (tac) { KtScope kt_(b, TSIM_KT_TAXELS, st); if (launch_taxels<float>(b, b->poseR, b->poseD, 1, nullptr, tac_out, st)) return 1; }
   } else {
     ReadArgs<double> a{b->dI, (const double*)b->dF, (const double*)b->dFenv, b->nfrec, b->B, b->t_cur, (const double*)b->tape, (double*)var_out, tac ? (double*)b->poseR : nullptr, b->poseD, b->nspt, b->stage_cpt};
     if (fk) hipLaunchKernelGGL(k_readout<double>, dim3(b->B), dim3(TS_WAVE), lds_bytes_for(b, 1), st, a);
-    if (tac && launch_taxels<double>(b, b->poseR, b->poseD, 1, nullptr, tac_out, st)) return 1;
+    if (tac) { KtScope kt_(b, TSIM_KT_TAXELS, st); if (launch_taxels<double>(b, b->poseR, b->poseD, 1, nullptr, tac_out, st)) return 1; }
   }
   HIPCHK(hipGetLastError());
   return 0;

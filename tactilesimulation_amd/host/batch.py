@@ -293,6 +293,18 @@ class BatchSim:
     def get_option(self, option):
         return capi.lib().tsim_get_option(self._h, int(option))
 
+    KERNEL_KINDS = ("k_forward", "k_taxels", "k_backward")
+
+    def kernel_timing(self, enable=True):
+        """HIP events around every simulation-kernel launch of this batch, on the launching stream (include/tsim.h tsim_kernel_timing)."""
+        capi.check(capi.lib().tsim_kernel_timing(self._h, int(bool(enable))))
+
+    def kernel_times(self):
+        """{kernel: (summed ms, launches)} since the previous call; waits for the recorded events (include/tsim.h tsim_kernel_times)."""
+        ms, n = (C.c_double * 3)(), (C.c_int32 * 3)()
+        capi.check(capi.lib().tsim_kernel_times(self._h, ms, n))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.KERNEL_KINDS)}
+
     def launch_info(self):
         out = (C.c_int32 * 4)()
         capi.lib().tsim_launch_info(self._h, out)

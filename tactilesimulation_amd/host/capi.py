@@ -36,6 +36,7 @@ _SIGS = {
     "tsim_debug_stamps": (C.c_int, [_vp, _vp]),
     "tsim_launch_info": (C.c_int, [_vp, _ip]),
     "tsim_set_lanes_per_env": (C.c_int, [_vp, C.c_int]),
+    "tsim_kernel_timing": (C.c_int, [_vp, C.c_int]), "tsim_kernel_times": (C.c_int, [_vp, C.POINTER(C.c_double), _ip]),
     "tsim_static_model": (C.c_int, [_vp]), "tsim_set_static": (C.c_int, [_vp, C.c_int]),
     "tsim_kernel_variant": (C.c_char_p, [_vp]),
     "tsim_set_option": (C.c_int, [_vp, C.c_int, C.c_int]), "tsim_get_option": (C.c_int, [_vp, C.c_int]),

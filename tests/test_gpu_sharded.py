@@ -124,7 +124,8 @@ def test_bench_gpus_2_self_launched_on_one_gpu():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["ranks"]["ranks_in_first_allreduce"] == 2 and j["ranks"]["shared_gpu"] is True
-    assert j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["roofline"]["kernel_ms"]["k_forward"] > 0
+    assert j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["roofline"]["per_kernel"]["k_forward"]["ms"] > 0
+    assert len(lines[0].encode()) < 6144 and len(j["per_rank"]) == 2 and j["per_rank"][1]["kernel_ms_total"] > 0
 
 
 def test_two_ranks_train_the_fused_loop_to_identical_parameters(tmp_path):
