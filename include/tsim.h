@@ -52,7 +52,11 @@ int tsim_update_model(tsim_batch* b, const int32_t* I, const double* F, void* st
  * parameters per episode; with B environments each one gets its own): `tables` is a DEVICE array [B][tsim_table_size]
  * of the batch's real type whose rows are copies of the leading `tsim_table_size` reals of the blob's F[] (all numeric
  * tables: links, dofs, motors, variables, pairs, sensors) with the randomised entries overwritten. NULL reverts to the
- * shared model. Point arrays (contact points, taxels) are always shared. */
+ * shared model. Point arrays (contact points, taxels) are always shared.  The float header of a row (time step, gravity, Newton tolerance:
+ * F[0 .. TSIM_FH_SIZE)) is NOT per environment: it is overwritten with the shared model's (the reference's randomisers never touch it).
+ * On an fp32 batch whose model has a compiled-in structure this call checks on the device that every row keeps it and reads one int back: it
+ * synchronises `stream` then.  Inside a stream capture the check cannot run: the batch then takes the generic kernels for as long as these tables
+ * are set (tsim_kernel_variant says so) — set the tables before capturing to keep the compiled-in instantiation in the graph. */
 int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream);
 int tsim_table_size(const tsim_batch* b);
 

@@ -71,6 +71,8 @@ def lib(native=False):
         L.orc_get_adjoint.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_clear_adjoint.argtypes = [C.c_void_p]
         L.orc_residual.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
+        L.orc_contact_list.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.POINTER(C.c_int), _dp]
+        L.orc_contact_list.restype = C.c_int
         L.orc_inverse_dynamics.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
         L.orc_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
         L.orc_bench_rollout.restype = C.c_long
@@ -184,6 +186,13 @@ class OracleSim:
         J = np.zeros((self.nr, max(ncol, 1)))
         self._L.orc_residual(self._h, _p(_f(q1)), _p(_f(q0)), _p(_f(qd0)), _p(_f(u, self.nu)), int(which), _p(g), _p(J))
         return (g, J[:, :ncol]) if which >= 0 else g
+
+    def contact_list(self, q, qd, max_rows=256):
+        """Penetrating dynamics contact points of the state (q, qd): [(pair, point, branch, depth, medial distance)] (diagnostics)."""
+        oi = np.zeros((max_rows, 3), dtype=np.int32)
+        od = np.zeros((max_rows, 2))
+        n = self._L.orc_contact_list(self._h, _p(_f(q, self.nr)), _p(_f(qd, self.nr)), max_rows, oi.ctypes.data_as(C.POINTER(C.c_int)), _p(od))
+        return [(int(oi[i, 0]), int(oi[i, 1]), int(oi[i, 2]), float(od[i, 0]), float(od[i, 1])) for i in range(min(n, max_rows))]
 
     def inverse_dynamics(self, q, qd, qdd, u=None):
         r = np.zeros(self.nr)

@@ -765,6 +765,42 @@ int orc_backward_steps(void* h, int n, const double* df_dq, const double* df_dva
 void orc_get_adjoint(void* h, double* lam_q, double* lam_v) { Sim& S = *(Sim*)h; for (int k = 0; k < S.m.nr; ++k) { lam_q[k] = S.lam_q[k]; lam_v[k] = S.lam_v[k]; } }
 void orc_clear_adjoint(void* h) { Sim& S = *(Sim*)h; std::fill(S.lam_q.begin(), S.lam_q.end(), 0.0); std::fill(S.lam_v.begin(), S.lam_v.end(), 0.0); std::fill(S.lam_q1.begin(), S.lam_q1.end(), 0.0); std::fill(S.lam_v1.begin(), S.lam_v1.end(), 0.0); }
 
+// diagnostics: the penetrating dynamics contact points of the state (q, qd), up to `max` rows of (pair, point index, branch, cylinder / cuboid
+// medial distance): out_i [max][3], out_d [max][2] = (penetration depth d < 0, for a cylinder dr - dz: 0 = equidistant from side and cap,
+// where the normal of the penalty force JUMPS from radial to axial — see tools/dclaw_nonconv_probe.py).  Returns the number of penetrating points.
+int orc_contact_list(void* h, const double* q, const double* qd, int max, int* out_i, double* out_d) {
+  Sim& S = *(Sim*)h; const Model& m = S.m;
+  Link<double> L[MAXL]; V3<double> Ww[MAXR], Wv[MAXR];
+  double zero[MAXR]; for (int k = 0; k < m.nr; ++k) zero[k] = 0.0;
+  kinematics<double>(m, q, qd, zero, L, Ww, Wv, false);
+  int n = 0;
+  for (int pk = 0; pk < m.npair; ++pk) {
+    const int* pi = m.pi(pk); const double* pf = m.pf(pk);
+    if (!(pi[TSIM_PI_FLAGS] & 1)) continue;
+    M3<double> RP; V3<double> pP; prim_pose(m, pk, L, RP, pP);
+    const Link<double>& A = L[pi[TSIM_PI_LINKA]]; const Link<double>& Bk = L[pi[TSIM_PI_LINKB]];
+    for (int i = 0; i < pi[TSIM_PI_NPT]; ++i) {
+      int c = pi[TSIM_PI_PT0] + i;
+      V3<double> xw = mul(A.R, mk<double>(m.cpt(0, c), m.cpt(1, c), m.cpt(2, c))) + A.p;
+      if (pi[TSIM_PI_FLAGS] & 2) xw = xw - mk<double>(RP.m[2], RP.m[5], RP.m[8]) * pf[TSIM_PF_SHAPE];
+      V3<double> vrel = (A.v + cross(A.w, xw)) - (Bk.v + cross(Bk.w, xw)), Fw; int br = 0;
+      if (!contact_force<double>(pi[TSIM_PI_PRIM], pf + TSIM_PF_SHAPE, pf + TSIM_PF_KN, RP, pP, xw, vrel, Fw, &br)) continue;
+      if (n < max) {
+        const double* sh = pf + TSIM_PF_SHAPE;
+        V3<double> x = mulT(RP, xw - pP);
+        double d = 0, med = 0;
+        if (pi[TSIM_PI_PRIM] == TSIM_P_CYLINDER) { double dr = std::sqrt(x.x * x.x + x.y * x.y) - sh[0], dz = std::fabs(x.z) - sh[1]; d = std::max(dr, dz); med = dr - dz; }
+        else if (pi[TSIM_PI_PRIM] == TSIM_P_CUBOID) { double e[3] = {std::fabs(x.x) - sh[0], std::fabs(x.y) - sh[1], std::fabs(x.z) - sh[2]}; std::sort(e, e + 3); d = e[2]; med = e[2] - e[1]; }
+        else if (pi[TSIM_PI_PRIM] == TSIM_P_PLANE) d = x.z;
+        else d = std::sqrt(x.x * x.x + x.y * x.y + x.z * x.z) - sh[0];
+        out_i[3 * n] = pk; out_i[3 * n + 1] = i; out_i[3 * n + 2] = br; out_d[2 * n] = d; out_d[2 * n + 1] = med;
+      }
+      ++n;
+    }
+  }
+  return n;
+}
+
 // diagnostics for the tests: residual g and Jacobian `which` at an arbitrary point
 void orc_residual(void* h, const double* q1, const double* q0, const double* qd0, const double* u, int which, double* g, double* J) {
   Sim& S = *(Sim*)h;

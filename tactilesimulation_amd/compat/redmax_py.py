@@ -241,13 +241,17 @@ class Simulation:
         return [tuple(p) for p in self._model.meta["image_pos"][name]]
 
     def get_tactile_flow_images(self):
-        """list[n_sensor] of [rows][cols][3] (envs/dclaw_rotate_env.py:103-105); empty cells are zero."""
+        """list[n_sensor] of [rows][cols][3] (envs/dclaw_rotate_env.py:103-105); empty cells are zero.  One fancy-index scatter per sensor
+        (the (row, col) index arrays are built once per model: D'Claw has 3 x 302 taxels and the env calls this every step)."""
         tac = self.get_tactile_force_vector().reshape(-1, 3)
+        idx = getattr(self, "_flow_idx", None)
+        if idx is None:
+            idx = self._flow_idx = [(t0, nt, rows, cols, np.asarray(self._model.meta["image_pos"][name], dtype=np.intp).reshape(-1, 2))
+                                    for name, (t0, nt, rows, cols) in zip(self._model.meta["sensor_names"], self._model.meta["sensor_taxels"])]
         imgs = []
-        for name, (t0, nt, rows, cols) in zip(self._model.meta["sensor_names"], self._model.meta["sensor_taxels"]):
+        for t0, nt, rows, cols, rc in idx:
             img = np.zeros((rows, cols, 3))
-            for k, (r, c) in enumerate(self._model.meta["image_pos"][name]):
-                img[r, c] = tac[t0 + k]
+            img[rc[:, 0], rc[:, 1]] = tac[t0:t0 + rc.shape[0]]
             imgs.append(img)
         return imgs
 
@@ -273,8 +277,27 @@ class Simulation:
                 a = full.reshape(-1)
             if a.size != n * dim:
                 raise RuntimeError("backward_info.%s has %d values, expected num_steps * %d = %d" % (name, a.size, dim, n * dim))
-            return self._t(a, n * dim, name)
-        return seed(bi.df_dq, nr, "df_dq"), seed(bi.df_dvar, nv, "df_dvar"), seed(bi.df_dtactile, nt, "df_dtactile")
+            return a
+        parts = [seed(bi.df_dq, nr, "df_dq"), seed(bi.df_dvar, nv, "df_dvar"), seed(bi.df_dtactile, nt, "df_dtactile")]
+        # the three seeds go up through ONE pinned staging buffer and one asynchronous copy (three pageable torch.from_numpy(...).to(device)
+        # copies cost three synchronisations: more than the B = 1 adjoint kernel itself)
+        total = sum(p.size for p in parts if p is not None)
+        if total == 0:
+            return None, None, None
+        if getattr(self, "_seed_host", None) is None or self._seed_host.numel() < total:
+            self._seed_host = torch.empty(total, dtype=self._dtype).pin_memory()
+            self._seed_dev = torch.empty(total, device=self._dev, dtype=self._dtype)
+        hv = self._seed_host.numpy()
+        out, o = [], 0
+        for p in parts:
+            if p is None:
+                out.append(None)
+                continue
+            hv[o:o + p.size] = p                      # (casts to the batch's real type)
+            out.append(self._seed_dev[o:o + p.size].reshape(1, p.size))
+            o += p.size
+        self._seed_dev[:total].copy_(self._seed_host[:total], non_blocking=True)      # stream-ordered before the adjoint launch that reads it
+        return tuple(out)
 
     def backward_steps(self, num_steps):
         """envs/redmax_torch_functions.py:167 — newest num_steps sub-steps, continuing the carried adjoint."""

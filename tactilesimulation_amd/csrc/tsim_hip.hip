@@ -602,6 +602,7 @@ static void detect_static_model(tsim_batch* b) {
 enum { TS_KM_GENERIC = 0, TS_KM_STATIC = 1, TS_KM_PARAM = 2 };
 static int kernel_mode(const tsim_batch* b) {
   if (b->static_id == 0 || b->no_static) return TS_KM_GENERIC;
+  if (b->dtype == TSIM_F64 && b->lpe_forced == 16) return TS_KM_GENERIC;    // fp64: no compiled-in instantiation with four environments per wavefront (16 lanes only when forced: its LDS is over the automatic cap)
   if (b->dFenv) return b->env_struct_ok ? TS_KM_PARAM : TS_KM_GENERIC;      // (the table check is fp32 only: fp64 batches with per-environment tables stay generic)
   return b->static_exact ? TS_KM_STATIC : TS_KM_PARAM;
 }
@@ -648,6 +649,11 @@ __global__ void k_check_structure(const float* tables, const float* ref, const u
   if (i >= n) return;
   const int f = (int)(i % (size_t)nfrec);
   if (km[f] && !(tables[i] == ref[f])) atomicOr(flag, 1);
+}
+// the float header of every per-environment row (time step, gravity, Newton tolerance) is the shared model's: see tsim_set_env_tables
+template <class R> __global__ void k_env_header(R* tables, const R* ref, int nfrec, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * TSIM_FH_SIZE) tables[(size_t)(i / TSIM_FH_SIZE) * nfrec + i % TSIM_FH_SIZE] = ref[i % TSIM_FH_SIZE];
 }
 // scatter [B][nr] q / qd into tape record 0
 template <class R> __global__ void k_set_state(R* tape, const R* q, const R* qd, int B, int nr, int rec) {
@@ -1055,6 +1061,15 @@ int tsim_set_env_tables(tsim_batch* b, const void* tables, void* stream) {
   const bool fresh = !b->dFenv;
   if (fresh) HIPCHK(hipMalloc(&b->dFenv, bytes));
   HIPCHK(hipMemcpyAsync(b->dFenv, tables, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  // Time step, gravity and Newton tolerance are properties of the batch, not of an environment (the reference's randomisers never touch them, and
+  // the kernels cache them per wavefront: a helper slot evaluating another environment's trial point would use its own): the header of every row
+  // is overwritten with the shared model's.
+  {
+    const unsigned nh = (unsigned)((b->B * TSIM_FH_SIZE + 255) / 256);
+    if (b->dtype == TSIM_F32) hipLaunchKernelGGL(k_env_header<float>, dim3(nh), dim3(256), 0, (hipStream_t)stream, (float*)b->dFenv, (const float*)b->dF, b->nfrec, b->B);
+    else hipLaunchKernelGGL(k_env_header<double>, dim3(nh), dim3(256), 0, (hipStream_t)stream, (double*)b->dFenv, (const double*)b->dF, b->nfrec, b->B);
+    HIPCHK(hipGetLastError());
+  }
   // A batch whose model has a compiled-in structure stays on that instantiation if every environment's table keeps the structural floats
   // (the exact 0 / 1 / -1 entries the instantiation has folded away): checked here, on the device, once per call — one small kernel and a
   // 4-byte read-back (this call synchronises then; inside a stream capture the check is skipped and the batch takes the generic kernels).

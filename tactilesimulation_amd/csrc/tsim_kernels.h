@@ -192,7 +192,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   // (accepted, or the last of max_ls) is evaluated once more, with tangents, before anything is decided: g comes out bit-identical, so the
   // decision repeats itself and H is the full evaluation's.  Iterates, convergence and the taped matrices are exactly those of the loop
   // without the option; `evals` counts trial points (the repeats are not counted).  Where it pays: the environments a launch waits for
-  // are the ones in long line searches (a D'Claw fingertip jammed against the cap: 100 iterations x 12 trials; profiles/r05_value_trials.md).
+  // are the ones in long line searches (a D'Claw fingertip jammed against the cap: 100 iterations x 12 trials; profiles/r05_helpers.md, profiles/r05_option_ab.jsonl).
   bool vo = false;
   // Helper slots (round 5).  What a launch waits for is its slowest environment's CHAIN of evaluations, and those chains are long line
   // searches (D'Claw: a fingertip jammed against the cap, 100 iterations x 12 trials; TactileInsertion: one sub-step of 60 - 300 trials) —
@@ -207,6 +207,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   // the loop without helpers, bit for bit (tests/test_gpu_exact_options.py); a line search of n trials takes ceil(n / (1 + helpers)) rounds.
   // Not in launches that leave their final link records for tsim_readout (a helper's records are not its environment's).
 #define helpers_on (NS > 1 && !POLICY && a.helpers != 0 && !a.lockstep && a.poseR == nullptr)      /* (re-read from the kernel arguments where it is asked: no register held for it) */
+  static_assert(NS <= 4, "helper slots: three result registers (gh0..gh2) and step factors 1/2, 1/4, 1/8 — at most three helpers per owner");
   if (helpers_on && !valid) { done = true; fs = false; ss = false; }      // an idle slot of the last wavefront helps from the start
   int helped = 0;
   // Value-first trials (round 5; launches that record no tape).  A sub-step whose Newton iteration converges in ONE step — nearly all of them:

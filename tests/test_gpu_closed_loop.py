@@ -143,7 +143,7 @@ def test_simulator_gradients_in_the_regime_a_trained_policy_reaches():
     assert f32["q_err_max"] < 1e-5 and f64["q_err_max"] < 1e-10, (f32, f64)
     # What a trained policy does to 4096 environments depends on the build's fp32 roundings (40 epochs of training amplify them), so the 48
     # environments looked at are a different draw for every build.  Measured on 8 trained policies (two builds x 30 / 36 / 40 / 44 epochs,
-    # tools/gpu_r04.sh w2, profiles/r04_trained_regime.md): 45 - 48 of 48 fp32 trajectories on the oracle's contact / friction branches; dL/du
+    # tools/archive/gpu_r04.sh w2, profiles/r04_trained_regime.md): 45 - 48 of 48 fp32 trajectories on the oracle's contact / friction branches; dL/du
     # within 1.1e-5 ... 7.3e-5 of the oracle on all of them but at most ONE environment per policy (2.4e-3, 2.7e-3, 3.9e-4: an environment
     # that passes a kink inside a sub-step — the branch signature is taken at the sub-steps' ends and does not always see it).  Asserted: what
     # holds for every draw.

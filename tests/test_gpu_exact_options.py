@@ -112,6 +112,47 @@ def test_helper_slots_change_no_number_on_the_generic_kernels(name, lanes, dtype
         assert int(r[6].sum()) > 0 and (r[6] <= r[1]).all(), "no line-search trial was evaluated by a helper slot"
 
 
+def test_helper_slots_with_per_environment_tables_on_the_generic_kernels():
+    """D'Claw (generic kernels, two environments per wavefront) with one parameter table per environment — a helper slot evaluates the
+    OWNER's trial point with the owner's table.  The header of a row (time step, gravity, tolerance) is a property of the batch: rows that carry
+    another gravity are overwritten with the model's (include/tsim.h tsim_set_env_tables), so helpers — whose world record holds their own slot's
+    gravity — and owners cannot disagree.  Helpers on == helpers off, bit for bit; a corrupted header changes nothing."""
+    import tactilesimulation_amd.model.blob as BL
+    B = 256
+    m, q0, u, S = _case("dclaw_position_control", B)
+    T, dtype = u.shape[1], torch.float32
+
+    def run(helpers, bad_header):
+        sim = BatchSim(m, B, dtype=dtype, tape_capacity=T * S)
+        sim.set_lanes_per_env(32)
+        tab = sim.base_tables()
+        fo = int(m.I[BL.TSIM_IH_FOFF_PAIR])
+        g = torch.Generator().manual_seed(4)
+        tab[:, fo + BL.TSIM_PF_MU] *= (0.5 + torch.rand(B, generator=g)).to(tab)              # friction of the first contact pair, drawn per environment
+        tab[:, fo + BL.TSIM_PF_KN] *= (0.8 + 0.4 * torch.rand(B, generator=g)).to(tab)
+        if bad_header:
+            tab[::3, BL.TSIM_FH_GZ] = -3.0
+            tab[1::3, BL.TSIM_FH_H] *= 2.0
+        sim.set_env_tables(tab)
+        sim.set_option(BatchSim.OPT_TRIAL_HELPERS, helpers)
+        sim.reset(torch.tensor(q0, device=DEV, dtype=dtype), None, backward_flag=True)
+        ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dtype).transpose(0, 1).contiguous(), S, want_qd=True)
+        ev = sim.last_evals().copy()
+        g = torch.Generator().manual_seed(9)
+        wq, wv, wt = (torch.randn(T, B, n, generator=g).to(DEV) for n in (m.ndof_r, m.ndof_var, m.ndof_tactile))
+        du = sim.backward_episode(T, S, wq, wv, wt)
+        lq, lv = sim.get_adjoint()
+        return ro, ev, du, lq, lv, sim.kernel_variant(), sim.last_helper_trials().copy(), sim.launch_info()["lanes_per_env"]
+
+    plain, r, rb = run(False, False), run(True, False), run(True, True)
+    if plain[7] != 32:
+        pytest.skip("launch shape falls back to %d lanes per environment" % plain[7])
+    assert plain[5] == "generic" and r[5] == "generic"
+    _same(r, plain, ("dclaw, per-environment tables", "helpers"))
+    _same(rb, plain, ("dclaw, per-environment tables", "rows with another gravity / time step in their header"))
+    assert int(plain[6].sum()) == 0 and int(r[6].sum()) > 0
+
+
 @pytest.mark.parametrize("lanes", [16, 32])
 @pytest.mark.parametrize("tables", [False, True])
 def test_helper_slots_change_no_number_on_the_compiled_in_kernels(pusher_model, lanes, tables):

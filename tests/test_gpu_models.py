@@ -266,3 +266,20 @@ def test_cylinder_primitive_read_out_closed_forms_on_the_kernels(dtype, tol):
     sim.reset(torch.tensor(q, device="cuda", dtype=dtype), torch.tensor(qd, device="cuda", dtype=dtype), backward_flag=False)
     tac = sim.readout(want_var=False)[1].double().cpu().numpy().reshape(len(q), 3, 3)
     assert np.abs(tac - want).max() <= tol, np.abs(tac - want).max()
+
+
+def test_cylinder_medial_surface_jump_on_the_kernels():
+    """tests/test_oracle_physics.py::test_cylinder_medial_surface_is_a_jump_of_the_penalty_force on the HIP read-out (fp64 kernels: the two states
+    differ by 2 nm): nearest-face normal inside the cylinder, so the taxel force turns by 90 degrees across rho - r = |z| - l/2 — what leaves 3 of
+    2048 D'Claw environments of BASELINE configs[3] at max_iter (profiles/r06_dclaw_nonconv.md); the kernels implement the oracle's law there."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    q = np.array([[-0.001, 0.0, 0.029 - 1e-9, 0, 0, 0], [-0.001, 0.0, 0.029 + 1e-9, 0, 0, 0]])
+    sim = BatchSim(_load("cyl_press"), 2, dtype=torch.float64, tape_capacity=0)
+    sim.reset(torch.tensor(q, device="cuda"), None, backward_flag=False)
+    tac = sim.readout(want_var=False)[1].cpu().numpy().reshape(2, 3, 3)[:, 0]
+    from oracle.oracle import OracleSim
+    o = OracleSim(_load("cyl_press"))
+    for k in range(2):
+        o.reset(q[k], np.zeros(6))
+        assert np.abs(tac[k] - o.outputs()[1].reshape(3, 3)[0]).max() < 1e-13
+    assert abs(tac[0, 2] + 0.1) < 1e-9 and abs(abs(tac[1, 0]) - 0.1) < 1e-7 and np.linalg.norm(tac[0] - tac[1]) > 0.14

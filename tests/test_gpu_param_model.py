@@ -25,12 +25,56 @@ def _run(sim, q0, u, T, S, wq, wv, wt):
     sim.reset(torch.tensor(q0, device=DEV, dtype=torch.float32), None, backward_flag=True)
     ro = sim.rollout(torch.tensor(u, device=DEV, dtype=torch.float32).transpose(0, 1).contiguous(), S, want_qd=True)
     ev = sim.last_evals().copy()
+    sig = sim.branch_signature().cpu().numpy()          # [T S, B, 2] smooth pieces of the contact / friction law each sub-step was on (read before the tape is popped)
     du = sim.backward_episode(T, S, wq, wv, wt)
     lq, lv = sim.get_adjoint()
-    return ro, ev, du, lq, lv
+    return ro, ev, du, lq, lv, sig
 
 
-def _agree(ra, rb, B, tag, allow_bad=0):
+MAX_OUTLIERS = 2        # environments whose gradients differ by more than 1e-2 between the two kernels (tests/test_gpu_static_model.py caps them the same way)
+
+
+def _oracle_gradient(model, q0, u, T, S, wq, wv, wt, e):
+    """dL/du [T, nu] and the branch signature [T S, 2] of environment e from the fp64 CPU oracle (the checker: oracle/), same seeds."""
+    from oracle.oracle import OracleSim
+    o = OracleSim(model)
+    o.reset(q0[e], record=True)
+    sig = np.zeros((T * S, 2), dtype=np.int64)
+    for t in range(T):
+        _, sg = o.forward_sig(u[e, t], S)
+        sig[t * S:(t + 1) * S] = sg
+    G = np.zeros((T, u.shape[2]))
+    for t in reversed(range(T)):
+        dq = np.zeros((S, q0.shape[1])); dq[-1] = wq[t, e].double().cpu().numpy()
+        dv = np.zeros((S, wv.shape[2])); dv[-1] = wv[t, e].double().cpu().numpy()
+        dt = np.zeros((S, wt.shape[2])); dt[-1] = wt[t, e].double().cpu().numpy()
+        G[t] = o.backward_steps(S, dq, dv, dt).sum(0)
+    return G, sig
+
+
+def _check_outliers(outliers, ra, rb, tag, oracle_of):
+    """Two fp32 roundings of one trajectory may cross a contact / friction kink on different sides; the gradient is discontinuous there, so a large
+    per-environment difference is legitimate ONLY if the two runs went through different smooth pieces.  VERDICT r05 #7: a wrong adjoint term in a
+    rare branch must not hide under `e.max() < 0.2` — so (1) at most MAX_OUTLIERS environments, (2) an outlier whose two runs report the SAME
+    branch signature is an error outright, (3) every outlier is taken to the fp64 oracle (the reference's own criterion is analytic-vs-third-party:
+    algorithms/gd.py:459-465): whichever run shares the oracle's signature must have the oracle's gradient to 1e-4."""
+    assert len(outliers) <= MAX_OUTLIERS, (tag, "environments with gradient differences > 1e-2", list(outliers))
+    for e in outliers:
+        sa, sb = ra[5][:, e], rb[5][:, e]
+        assert not (sa == sb).all(), (tag, "environment %d: same smooth pieces in every sub-step, yet the gradients of the two kernels differ by > 1e-2" % e)
+        G, so = oracle_of(int(e))
+        n_on_oracle_branch = 0
+        for name, r in (("a", ra), ("b", rb)):
+            if (r[5][:, e] == so).all():
+                n_on_oracle_branch += 1
+                g = r[2][:, e].double().cpu().numpy()
+                err = np.abs(g - G).max() / max(np.abs(G).max(), 1e-30)
+                assert err < 1e-4, (tag, "environment %d, run %s: on the oracle's branches but dL/du differs from the oracle's by %.2e" % (e, name, err))
+        print("%s: outlier environment %d explained — the runs differ in %d of %d sub-step signatures; %d of the two on the oracle's branches (checked to 1e-4)"
+              % (tag, e, int((sa != sb).any(axis=1).sum()), sa.shape[0], n_on_oracle_branch))
+
+
+def _agree(ra, rb, B, tag, allow_bad=0, oracle_of=None):
     rel = lambda x, y: float((x - y).abs().max()) / max(float(y.abs().max()), 1e-30)
     assert torch.equal(ra[0]["status"], rb[0]["status"]) and int((ra[0]["status"] != 0).sum()) <= allow_bad, tag
     assert float((ra[0]["q"] - rb[0]["q"]).abs().max()) < 5e-6 and float((ra[0]["qd"] - rb[0]["qd"]).abs().max()) < 2e-4, tag
@@ -41,9 +85,12 @@ def _agree(ra, rb, B, tag, allow_bad=0):
     def per_env(x, y):
         x, y = (t.transpose(0, 1).reshape(B, -1) if t.dim() == 3 else t for t in (x, y))
         return ((x - y).abs().max(1).values / y.abs().max(1).values.clamp_min(1e-30)).cpu().numpy()
+    outliers = set()
     for x, y, name in ((ra[2], rb[2], "du"), (ra[3], rb[3], "lamq"), (ra[4], rb[4], "lamv")):
         e = per_env(x, y)
         assert np.median(e) < 1e-5 and (e < 1e-4).mean() > 0.995 and e.max() < 0.2, (tag, name, float(np.median(e)), float((e < 1e-4).mean()), float(e.max()))
+        outliers.update(int(i) for i in np.nonzero(e > 1e-2)[0])
+    _check_outliers(sorted(outliers), ra, rb, tag, oracle_of)
     return {"q": float((ra[0]["q"] - rb[0]["q"]).abs().max()), "tactile": rel(ra[0]["tactile"], rb[0]["tactile"]),
             "du_median": float(np.median(per_env(ra[2], rb[2]))), "same_evals": float((ra[1] == rb[1]).mean())}
 
@@ -76,7 +123,7 @@ def test_an_edited_model_stays_on_the_compiled_in_structure(pusher_model):
     b.set_static(False)
     assert b.kernel_variant() == "generic" and b.static_model() == 0
     ra, rb = _run(a, q0, u, T, S, wq, wv, wt), _run(b, q0, u, T, S, wq, wv, wt)
-    out = _agree(ra, rb, B, "edited model")
+    out = _agree(ra, rb, B, "edited model", oracle_of=lambda e: _oracle_gradient(m, q0, u, T, S, wq, wv, wt, e))
     # ... and the edit matters: against the XML's model the trajectories differ visibly
     c = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=T * S)
     rc = _run(c, q0, u, T, S, wq, wv, wt)
@@ -101,7 +148,7 @@ def test_per_environment_tables_stay_on_the_compiled_in_structure(pusher_model):
     s = BatchSim(pusher_model, B, dtype=torch.float32, tape_capacity=T * S)
     assert s.kernel_variant() == "static:pusher"
     ra, rs = _run(a, q0, u, T, S, wq, wv, wt), _run(s, q0, u, T, S, wq, wv, wt)
-    o1 = _agree(ra, rs, B, "base tables vs static")
+    o1 = _agree(ra, rs, B, "base tables vs static", oracle_of=lambda e: _oracle_gradient(pusher_model, q0, u, T, S, wq, wv, wt, e))
     # (2) every environment its own draw of contact / tactile parameters, box mass, yaw damping — as the reference's reset-time randomisers draw them
     I = pusher_model.I
     fp, fs, fd, fl = I[BL.TSIM_IH_FOFF_PAIR], I[BL.TSIM_IH_FOFF_SENSOR], I[BL.TSIM_IH_FOFF_DOF], I[BL.TSIM_IH_FOFF_LINK]
@@ -118,7 +165,12 @@ def test_per_environment_tables_stay_on_the_compiled_in_structure(pusher_model):
     a.set_env_tables(tab); b.set_env_tables(tab)
     assert a.kernel_variant() == "param:pusher" and b.kernel_variant() == "generic"
     ra, rb = _run(a, q0, u, T, S, wq, wv, wt), _run(b, q0, u, T, S, wq, wv, wt)
-    o2 = _agree(ra, rb, B, "randomised tables vs generic", allow_bad=4)      # (a random draw may leave an environment at max_iter: both kernels must flag the same ones)
+    def model_of_env(e):      # the oracle takes a model: the XML's with environment e's row of the table in place of the shared records
+        m_ = copy.copy(pusher_model); m_.F = pusher_model.F.copy()
+        row = tab[e].double().cpu().numpy()
+        m_.F[:row.size] = row
+        return m_
+    o2 = _agree(ra, rb, B, "randomised tables vs generic", allow_bad=4, oracle_of=lambda e: _oracle_gradient(model_of_env(e), q0, u, T, S, wq, wv, wt, e))      # (a random draw may leave an environment at max_iter: both kernels must flag the same ones)
     assert float((ra[0]["q"] - rs[0]["q"]).abs().max()) > 1e-4       # the randomisation matters
     # (3) a table that breaks the structure (a joint axis that is no unit vector of the joint frame any more) takes the batch to the generic kernels
     bad = a.base_tables()

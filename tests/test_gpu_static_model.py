@@ -20,13 +20,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(sim, q0, u, T, S, wq, wv, wt):
-    sim.reset(torch.tensor(q0, device=DEV, dtype=torch.float32), None, backward_flag=True)
-    ro = sim.rollout(torch.tensor(u, device=DEV, dtype=torch.float32).transpose(0, 1).contiguous(), S, want_qd=True)
-    ev = sim.last_evals().copy()
-    du = sim.backward_episode(T, S, wq, wv, wt)
-    lq, lv = sim.get_adjoint()
-    return ro, ev, du, lq, lv
+from test_gpu_param_model import _run, _check_outliers, _oracle_gradient      # noqa: E402  (the run + the outlier-vs-oracle check are shared)
 
 
 def test_static_pusher_kernels_agree_with_the_generic_ones_to_fp32_rounding(pusher_model):
@@ -70,6 +64,9 @@ def test_static_pusher_kernels_agree_with_the_generic_ones_to_fp32_rounding(push
     errs = {name: per_env(x, y) for x, y, name in ((ra[2], rb[2], "du"), (ra[3], rb[3], "lamq"), (ra[4], rb[4], "lamv"))}
     for name, e in errs.items():
         assert np.median(e) < 1e-5 and (e < 1e-4).mean() > 0.995 and (e > 1e-2).sum() <= 2 and e.max() < 0.2, (name, float(np.median(e)), float((e < 1e-4).mean()), int((e > 1e-2).sum()), float(e.max()))
+    # every outlier environment: different smooth pieces in the two runs, and whichever run is on the ORACLE's pieces has the oracle's gradient (1e-4)
+    outl = sorted(set(int(i) for e in errs.values() for i in np.nonzero(e > 1e-2)[0]))
+    _check_outliers(outl, ra, rb, "static vs generic", lambda e: _oracle_gradient(pusher_model, q0, u, T, S, wq, wv, wt, e))
     from _report import rep
     rep("static_vs_generic", q=float((ra[0]["q"] - rb[0]["q"]).abs().max()), qd=float((ra[0]["qd"] - rb[0]["qd"]).abs().max()), tactile=rel(ra[0]["tactile"], rb[0]["tactile"]),
         du_median=float(np.median(errs["du"])), du_p999=float(np.quantile(errs["du"], 0.999)), du_max=float(errs["du"].max()), du_within_1e4=float((errs["du"] < 1e-4).mean()),

@@ -402,3 +402,25 @@ def test_cylinder_primitive_tactile_closed_forms():
     for k in range(len(q)):
         o.reset(q[k], qd[k])
         assert np.allclose(o.outputs()[1].reshape(3, 3), want[k], rtol=0, atol=1e-14), k
+
+
+def test_cylinder_medial_surface_is_a_jump_of_the_penalty_force():
+    """[CHOICE] pinned as a known answer (profiles/r06_dclaw_nonconv.md): a penetrating point is pushed out along the normal of the NEAREST face
+    of the primitive — inside a cylinder that is the side wall where rho - r > |z| - l/2 and the cap face otherwise.  Across the surface where the
+    two distances are equal the force keeps its magnitude kn d and turns by 90 degrees: the residual of a sub-step is DISCONTINUOUS there, which
+    is why 3 of the 2048 D'Claw environments of BASELINE configs[3] (a fingertip point 0.1 - 0.3 mm inside the cap's rim) run the XML's Newton
+    loop to max_iter in the oracle and in the kernels alike.  tests/models/cyl_press.xml: taxel 0 of the pad, 1 mm inside the wall and
+    1 mm -/+ 1e-9 below the cap face."""
+    m = _model("cyl_press")
+    o = OracleSim(m)
+    out = []
+    for eps in (-1e-9, +1e-9):                       # taxel 0 sits at rho = 0.02 + qx, z = 0.01 + qz;  cylinder r = 0.02, l / 2 = 0.04
+        q = np.array([-0.001, 0.0, 0.029 + eps, 0.0, 0.0, 0.0])
+        o.reset(q, np.zeros(6))
+        out.append(o.outputs()[1].reshape(3, 3)[0].copy())
+    side, cap = out
+    # side wall nearest: the force is radial = along the pad's normal (third component; negative under compression), 100 N/m x 1 mm
+    assert abs(side[2] + 0.1) < 1e-9 and abs(side[0]) < 1e-12 and abs(side[1]) < 1e-12, side
+    # cap face nearest (1 nm further up): the same magnitude along the cylinder's axis = the taxel's first shear axis (0, 0, -1)
+    assert abs(abs(cap[0]) - 0.1) < 1e-7 and abs(cap[2]) < 1e-12 and abs(cap[1]) < 1e-12, cap
+    assert np.linalg.norm(side - cap) > 0.14            # a jump of sqrt(2) kn d over 2 nm: no root of the residual lies on that surface

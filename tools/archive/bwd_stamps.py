@@ -1,7 +1,7 @@
 """Shader-clock stamps of the adjoint kernel's first sub-steps (wavefront 0), bench workload (GPU box)."""
 import os, sys, json, ctypes as C
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
 from tactilesimulation_amd.host import capi

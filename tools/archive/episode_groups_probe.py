@@ -4,7 +4,7 @@ evaluation rounds per wavefront, maximum 403), and the adjoint cannot start befo
 chains the adjoint of one group runs under the forward tail of another.  GPU box."""
 import os, sys, time, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
 from tactilesimulation_amd.workloads import push_workload, PUSHER_BLOB

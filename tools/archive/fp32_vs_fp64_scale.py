@@ -1,7 +1,7 @@
 """fp32 against fp64 kernels on the whole bench batch (4096 environments x 100 env-steps): how far do the trajectories drift?"""
 import os, sys, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
 from tactilesimulation_amd.workloads import push_workload

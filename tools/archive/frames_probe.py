@@ -3,7 +3,7 @@ Times tsim_rollout / tsim_backward_episode for several episode lengths and frame
 evaluation rounds (mean over environments, and per wavefront of 4 sub-step-synchronous slots)."""
 import os, sys, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
 from tactilesimulation_amd.workloads import push_workload, PUSHER_BLOB

@@ -2,7 +2,7 @@
 Loss along -g/|g| on FIXED episodes, per-environment gradient-norm spread (GPU box)."""
 import os, sys, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
 from tactilesimulation_amd.algorithms.batched_gd import Actor, rollout_loss
 from tactilesimulation_amd.workloads import PUSHER_BLOB

@@ -1,5 +1,5 @@
 """Long GD training run of the fused closed loop with per-epoch diagnostics: flagged (non-converged) environments, gradient norm before
-the clip, largest |u|, loss quantiles over the batch.  python tools/gd_divergence_probe.py [epochs] [lr]"""
+the clip, largest |u|, loss quantiles over the batch.  python tools/archive/gd_divergence_probe.py [epochs] [lr]"""
 import os, sys, json, math
 import numpy as np, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))

@@ -2,7 +2,7 @@
 dynamics?  fp64 kernels, the same batch twice: exact inputs, and inputs rounded to fp32 (a 6e-8 relative perturbation)."""
 import os, sys, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim
 from tactilesimulation_amd.workloads import push_workload

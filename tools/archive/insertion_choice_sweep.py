@@ -5,7 +5,7 @@ model on the reference's own episode (insertion_attempt_workload: settled grasp,
 import copy, json, os, sys, time
 import multiprocessing as mp
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model import compiler as mc
 from tactilesimulation_amd import workloads as W

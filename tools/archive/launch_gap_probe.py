@@ -1,6 +1,6 @@
 """Where the difference between the HIP-event time of an episode's forward segment and rocprof's kernel duration goes (GPU box): N back-to-back
 episode launches bracketed by ONE event pair against single launches bracketed each, with and without the tactile output (k_taxels_small) and the
-tape.  usage: python tools/launch_gap_probe.py"""
+tape.  usage: python tools/archive/launch_gap_probe.py"""
 import json
 import os
 import sys
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import bench
 from tactilesimulation_amd.host.batch import BatchSim
 

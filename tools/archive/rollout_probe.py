@@ -1,7 +1,7 @@
 """Throughput of the one-launch episode (tsim_rollout + tsim_backward_episode) vs per-step launches (GPU box)."""
 import os, sys, time, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim

@@ -1,7 +1,7 @@
 """Probe: does splitting the batch into G groups on G HIP streams hide the Newton stragglers? (GPU box)"""
 import os, sys, time, json
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tactilesimulation_amd.model.compiler import load_model
 from tactilesimulation_amd.host.batch import BatchSim

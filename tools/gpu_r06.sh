@@ -18,4 +18,7 @@ a)  # new bench line: the driver's command, then the kernel trace of the same ti
 t)  # full GPU suite only
   ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > ${O}_tests.log 2>&1
   ;;
+b)  # D'Claw / TactileInsertion: lanes per environment (= helper slots per wavefront) 64 / 32 / 16 on the straggler-bound collection legs
+  for l in 64 32 16; do TSIM_LPE=$l timeout 600 python tools/sub_record_ab.py dclaw insertion >> ${O}_lpe.jsonl 2>> ${O}_lpe.err; done
+  ;;
 esac

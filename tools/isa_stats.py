@@ -53,7 +53,7 @@ def main():
             print("  " + "  ".join("%s=%s" % (k, v.group(1)) for k, v in meta.items() if v), " agpr=" + blk.split()[0])
             dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--symbolize-operands", co], capture_output=True, text=True).stdout.splitlines()
             a = next(i for i, l in enumerate(dis) if l.endswith("<%s>:" % name))
-            b = next((i for i in range(a + 1, len(dis)) if re.match(r"^[0-9a-f]+ <[^L].*>:$", dis[i])), len(dis))
+            b = next((i for i in range(a + 1, len(dis)) if re.match(r"^[0-9a-f]+ <(?!L\d+>)", dis[i])), len(dis))
             body = dis[a:b]
             n, cls, pick = mix(body)
             print("  static instructions: %d  %s" % (n, cls))
@@ -61,12 +61,12 @@ def main():
             if "--loop" in sys.argv:
                 lab = {}
                 for i, l in enumerate(body):
-                    m = re.match(r"^<(L\d+)>:", l)
+                    m = re.match(r"^[0-9a-f]+ <(L\d+)>:", l)
                     if m:
                         lab[m.group(1)] = i
                 best = (0, 0, 0)
                 for i, l in enumerate(body):
-                    m = re.search(r"s_cbranch\w*\s+<?(L\d+)>?|s_branch\s+<?(L\d+)>?", l)
+                    m = re.search(r"s_cbranch\w*\s+(L\d+)\b|s_branch\s+(L\d+)\b", l)
                     if m:
                         t = lab.get(m.group(1) or m.group(2))
                         if t is not None and t < i and i - t > best[0]:
