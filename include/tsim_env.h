@@ -61,7 +61,9 @@ typedef struct tsim_push_policy {
 /* Forward: num_frames env-steps of num_steps sub-steps from the batch's current state; frame f acts with
  *   action_f = [tanh(policy(obs_f)), dist[f][env][0:2], 0],  obs_f = [goal in the gripper frame of the state before the frame, tactile frame before it]
  * (tac0 [B][390]: the tactile frame at the current state, tsim_readout).  Outputs per frame [T][B][.]: q, qd (may be NULL), var, tac (required with
- * the tactile observation, which it feeds; may be NULL otherwise, and the launch then skips the read-out), and the policy's records u (3, pre-tanh), gl (3, goal part of the observation), h1, h2 (64, ELU outputs). */
+ * the tactile observation, which it feeds; may be NULL otherwise, and the launch then skips the read-out), and the policy's records u (3, pre-tanh), gl (3, goal part of the observation), h1, h2 (64, ELU outputs).
+ * Batches with per-environment parameter tables (tsim_set_env_tables) and edited models (tsim_update_model) are accepted (round 6): an fp32 batch
+ * that keeps the TactilePush structure runs the structure-static closed-loop instantiation (tsim_kernel_variant "param:pusher"), any other the generic one. */
 int tsim_push_closed_rollout(tsim_batch* b, const tsim_push_policy* pol, const void* goal, const void* dist, const void* tac0,
                              int num_frames, int num_steps, void* q_out, void* qd_out, void* var_out, void* tac_out,
                              void* u_out, void* gl_out, void* h1_out, void* h2_out, int32_t* status, void* stream);

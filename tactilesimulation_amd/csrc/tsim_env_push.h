@@ -150,13 +150,13 @@ static int push_closed_check(const tsim_batch* b, const tsim_push_policy* pol, i
   if (pol->eps && !pol->logstd) return fail(std::string(who) + ": eps without logstd");
   if ((pol->obs_mean != nullptr) != (pol->obs_istd != nullptr)) return fail(std::string(who) + ": obs_mean and obs_istd come together");
   if (pol->obs_mean && b->record) return fail(std::string(who) + ": observation normalisation is for roll-out collection (reset with backward_flag = False); the adjoint launch does not undo it");
-  if (b->dFenv) return fail(std::string(who) + ": per-environment tables are not supported in the closed-loop launch");
   return 0;
 }
 #define TS_LAUNCH_POLICY(KERNEL, R, b, st, a) do {                                                                                   \
     const LaunchShape L = launch_shape(b);                                                                                           \
     if constexpr (sizeof(R) == 4) {      /* the statically specialised TactilePush instantiation (tsim_static_pusher.hip) */           \
       if (kernel_mode(b) == TS_KM_STATIC && L.lpe == 16) { ts_static_pusher_launch_policy(a, L.grid, L.lds, st); break; }               \
+      if (kernel_mode(b) == TS_KM_PARAM && L.lpe == 16) { ts_param_pusher_launch_policy(a, L.grid, L.lds, st); break; }                 \
     }                                                                                                                                 \
     if (L.lpe == 64) hipLaunchKernelGGL((KERNEL<R, 8, false, 64, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);                  \
     else if (L.lpe == 32) hipLaunchKernelGGL((KERNEL<R, 8, false, 32, true>), dim3(L.grid), dim3(TS_WAVE), L.lds, st, a);             \
@@ -168,7 +168,7 @@ static int push_closed_rollout_t(tsim_batch* b, const tsim_push_policy* pol, con
                                  void* q_out, void* qd_out, void* var_out, void* tac_out, void* u_out, void* gl_out, void* h1_out, void* h2_out, int32_t* status, hipStream_t st) {
   FwdArgs<R> a;
   memset(&a, 0, sizeof(a));
-  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = nullptr; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = nullptr;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.nsub = nsub; a.record = b->record; a.t0 = b->t_cur; a.nframes = nframes; a.tac_slot = nullptr;
   a.tape = (R*)b->tape; a.u = nullptr;
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
@@ -204,7 +204,7 @@ static int push_closed_backward_t(tsim_batch* b, const tsim_push_policy* pol, co
                                   void* dobs_tac, void* df_du, hipStream_t st) {
   BwdArgs<R> a;
   memset(&a, 0, sizeof(a));
-  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = nullptr; a.fstride = b->nfrec; a.B = b->B; a.n = nframes * nsub; a.t_end = b->t_cur; a.seed_stride = nsub; a.frames = 1; a.tac_slot = nullptr;
+  a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = nframes * nsub; a.t_end = b->t_cur; a.seed_stride = nsub; a.frames = 1; a.tac_slot = nullptr;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = nullptr;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = nullptr; a.cull = b->pair_cull;
   a.pol = make_push_policy<R>(pol);

@@ -739,6 +739,8 @@ void ts_static_pusher_launch(const FwdArgs<float>& a, int lpe, unsigned grid, si
 void ts_static_pusher_launch(const BwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);
 void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);      // ... with the policy between the frames
 void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
+void ts_param_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);       // ... on the structure-static kernels (tsim_param_pusher_policy.hip)
+void ts_param_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 void ts_static_pusher_launch_debug(const DbgArgs<float>& a, unsigned grid, size_t lds, hipStream_t st);
 // ... and of the structure-static ones (tsim_param_pusher.hip): the same kernels with the model's parameters read from the float records
 void ts_param_pusher_launch(const FwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st);

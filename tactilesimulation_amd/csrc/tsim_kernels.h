@@ -802,6 +802,17 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
       else output_vjp<LPE>(c, lane, (a.df_dvar && nvar3) ? a.df_dvar + so * nvar3 : nullptr, wtac_);
     }
     TS_STAMP(c);
+#ifdef TS_BWD_REEVAL      // A/B builds only (profiles/r06_tape_ab.md): what a tape WITHOUT the Newton matrix would cost — the matrix of the taped point is evaluated
+                          // again here (the forward kernel's evaluation with tangents) and the adjoint solve uses it instead of the taped one
+    if (lane < nr) {
+      c.qp[lane] = c.q0[lane] + c.h * c.qd0[lane]; c.qdp[lane] = c.qd0[lane];
+      c.dl[lane] = (R)(c.qD[lane] - (double)c.qp[lane]); c.qpD[lane] = c.qD[lane] - (double)c.dl[lane];
+    }
+    TS_SYNC();
+    evaluate<R, NRM, EXPJ, LPE, MS>(c, lane, R(1), c.cv, c.ca, true);
+    for (int e = lane; e < nr * nr; e += LPE) H2[e] = c.H[e];
+    TS_SYNC();
+#endif
     if (lane < nr) c.rhs[lane] = c.lamq[lane] + c.cv * c.lamv[lane];      // d qd1 / d q1 = cv
     TS_SYNC();
     solve_newton<R, NRM, LPE, double, ts_static_nr<MS>()>(H2, c.rhs, c.z, nr, true, lane);

@@ -62,7 +62,8 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-ve
 # kernels are 63 KB already; at -O2: D'Claw -5 %, TactileInsertion -2 %, fp64 -2 %).
 HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),
              ("tsim_param_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),      # the same kernels, parameters at run time (tsim_static.h ts_F)
-             ("tsim_static_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"])]      # (closed-loop instantiations: 76 KB at -O2, stay at -Os)
+             ("tsim_static_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"]),      # (closed-loop instantiations: 76 KB at -O2, stay at -Os)
+             ("tsim_param_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"])]       # ... of the structure-static kernels (round 6: closed loop with per-environment tables)
 
 
 def hip_build_commands(hipcc, out_so=None):

@@ -67,7 +67,7 @@ def test_kernel_table_names_the_instantiations_a_batch_launches():
     combos += [(k, dt, 9, True, 64, "generic", False) for k in ("k_forward", "k_backward") for dt in ("f32", "f64")]                      # rotation-vector joint
     combos += [(k, "f32", 7, False, l, v, False) for k in ("k_forward", "k_backward") for l in (16, 32, 64) for v in ("static:pusher", "param:pusher")]
     combos += [(k, "f64", 7, False, l, v, False) for k in ("k_forward", "k_backward") for l in (32, 64) for v in ("static:pusher", "param:pusher")]
-    combos += [(k, "f32", 7, False, 16, "static:pusher", True) for k in ("k_forward", "k_backward")]                                      # closed loop
+    combos += [(k, "f32", 7, False, 16, v, True) for k in ("k_forward", "k_backward") for v in ("static:pusher", "param:pusher")]         # closed loop
     for c in combos:
         mangled, readable = buildhash.kernel_name(*c)
         assert mangled in table, (readable, mangled)

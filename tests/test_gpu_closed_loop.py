@@ -31,9 +31,37 @@ def test_fused_episode_with_the_other_observation_types(pusher_model, dtype, tol
     test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes, observation_type)
 
 
+def _randomised_tables(sim, model, B, seed=4):
+    """One parameter table per environment, drawn the way the reference's reset-time randomisers draw (envs/tactile_insertion_env.py:238-281: contact /
+    tactile stiffness, friction, damping; envs/stable_grasp_env.py:122: density) — here on the TactilePush records."""
+    import tactilesimulation_amd.model.blob as BL
+    I = model.I
+    fp, fs, fd, fl = (int(I[k]) for k in (BL.TSIM_IH_FOFF_PAIR, BL.TSIM_IH_FOFF_SENSOR, BL.TSIM_IH_FOFF_DOF, BL.TSIM_IH_FOFF_LINK))
+    tab = sim.base_tables()
+    r = torch.rand(B, 6, generator=torch.Generator().manual_seed(seed), dtype=torch.float64).to(tab)
+    tab[:, fp + BL.TSIM_PF_SIZE + BL.TSIM_PF_KN] *= 0.7 + 0.6 * r[:, 0]
+    tab[:, fp + BL.TSIM_PF_SIZE + BL.TSIM_PF_MU] *= 0.5 + r[:, 1]
+    tab[:, fs + BL.TSIM_SF_KN] *= 0.7 + 0.6 * r[:, 2]
+    tab[:, fs + BL.TSIM_SF_KT] *= 0.7 + 0.6 * r[:, 3]
+    tab[:, fd + 6 * BL.TSIM_DF_SIZE + BL.TSIM_DF_DAMPING] = 0.01 + 0.1 * r[:, 4]
+    scale = 0.8 + 0.4 * r[:, 5]
+    for e in (BL.TSIM_LF_MASS, BL.TSIM_LF_INERTIA, BL.TSIM_LF_INERTIA + 1, BL.TSIM_LF_INERTIA + 2):
+        tab[:, fl + 3 * BL.TSIM_LF_SIZE + e] *= scale
+    return tab
+
+
+@pytest.mark.parametrize("lanes", [16, 64])
+@pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-5)])
+def test_fused_episode_with_per_environment_tables(pusher_model, dtype, tol_q, tol_g, lanes):
+    """the fused closed loop on a batch with one parameter table per environment (tsim_set_env_tables) — round 5 refused it.
+    Same check as below: loss, states, policy outputs and every policy parameter's gradient equal the per-step loop with torch autograd on the
+    same tables; the fp32 batch at four environments per wavefront runs the structure-static closed-loop kernels (param:pusher)."""
+    test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes, tables=True)
+
+
 @pytest.mark.parametrize("lanes", [16, 32, 64])
 @pytest.mark.parametrize("dtype,tol_q,tol_g", [(torch.float64, 1e-9, 1e-7), (torch.float32, 2e-5, 2e-5)])      # policy gradient, fused vs per-step autograd, per parameter: measured 5.3e-7 (fp32), 1.3e-15 (fp64)
-def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes, observation_type="tactile_flatten"):
+def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_g, lanes, observation_type="tactile_flatten", tables=False):
     from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
     from tactilesimulation_amd.envs.push_closed_loop import FusedPushEpisode
     from tactilesimulation_amd.algorithms.batched_gd import Actor, rollout_loss
@@ -48,6 +76,9 @@ def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_
     # ---- the per-step loop with autograd
     env = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T, observation_type=observation_type)
     env.sim.set_lanes_per_env(lanes)
+    if tables:
+        tab = _randomised_tables(env.sim, pusher_model, B)
+        env.sim.set_env_tables(tab)
     obs = env.reset(q0, goal)
     qs, us, total = [], [], obs.new_zeros(())
     for t in range(T):
@@ -60,9 +91,19 @@ def test_fused_episode_equals_the_per_step_loop(pusher_model, dtype, tol_q, tol_
     # ---- the fused episode
     env2 = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T, observation_type=observation_type)
     env2.sim.set_lanes_per_env(lanes)
+    if tables:
+        env2.sim.set_env_tables(tab)
+        assert env2.sim.kernel_variant() == ("param:pusher" if dtype == torch.float32 else "generic")
     ep = FusedPushEpisode(env2, actor, T)
     loss = ep.rollout(q0, goal, dist)
     assert int((ep.status != 0).sum()) == 0
+    if tables:      # ... and the tables matter: the XML's own parameters give another trajectory
+        env3 = BatchedTactilePushEnv(pusher_model, B, dtype=dtype, gradient=True, seed=0, tape_steps=T, observation_type=observation_type)
+        env3.sim.set_lanes_per_env(lanes)
+        ep3 = FusedPushEpisode(env3, actor, T)
+        ep3.rollout(q0, goal, dist)
+        assert float((ep3.q - ep.q).abs().max()) > 1e-5
+        ep3.backward()
     ep.backward()
     assert env2.sim.tape_len() == 0
     q_ref, u_ref = torch.stack(qs), torch.stack(us)

@@ -21,4 +21,22 @@ t)  # full GPU suite only
 b)  # D'Claw / TactileInsertion: lanes per environment (= helper slots per wavefront) 64 / 32 / 16 on the straggler-bound collection legs
   for l in 64 32 16; do TSIM_LPE=$l timeout 600 python tools/sub_record_ab.py dclaw insertion >> ${O}_lpe.jsonl 2>> ${O}_lpe.err; done
   ;;
+c)  # changed tests, then: the <= 256-register build (two wavefronts per SIMD; csrc/ab/libtsim_w2.so = -DTS_WAVES_PER_EU=2) against the shipped one,
+    # timed region only, interleaved, at the batch sizes where a SIMD gets 1 / 2 / 4 wavefronts of four environments (B = 4096 / 8192 / 16 384)
+    # and with two environments per wavefront (TSIM_LPE=32: twice the wavefronts)
+  ( timeout 1500 python -m pytest tests/test_gpu_param_model.py tests/test_gpu_static_model.py tests/test_gpu_exact_options.py tests/test_gpu_models.py tests/test_gpu_shim.py tests/test_gpu_dclaw.py tests/test_gpu_sharded.py -m gpu -q -x 2>&1 | tail -12 ) > ${O}_tests.log 2>&1
+  for B in 4096 8192 16384; do for L in 16 32; do for i in 1 2; do
+    TSIM_LPE=$L timeout 300 python bench.py --steps 20 --warmup 5 --batch $B --timed-only >> ${O}_shipped_B${B}_L${L}.jsonl 2>> ${O}_ab.err
+    TSIM_LPE=$L TSIM_HIP_LIB=$PWD/tactilesimulation_amd/csrc/ab/libtsim_w2.so timeout 300 python bench.py --steps 20 --warmup 5 --batch $B --timed-only >> ${O}_w2_B${B}_L${L}.jsonl 2>> ${O}_ab.err
+  done; done; done
+  ;;
+d)  # fused closed loop with per-environment tables (structure-static closed-loop kernels): parity, then the epoch with / without tables;
+    # the cost of a tape WITHOUT the Newton matrix (csrc/ab/libtsim_reeval.so = -DTS_BWD_REEVAL: k_backward evaluates it again), interleaved with the shipped library
+  ( timeout 1500 python -m pytest tests/test_gpu_closed_loop.py tests/test_gpu_exact_options.py tests/test_gpu_batched_env.py -m gpu -q -x 2>&1 | tail -12 ) > ${O}_tests.log 2>&1
+  for i in 1 2 3; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --timed-only >> ${O}_shipped.jsonl 2>> ${O}_ab.err
+    TSIM_HIP_LIB=$PWD/tactilesimulation_amd/csrc/ab/libtsim_reeval.so timeout 300 python bench.py --steps 20 --warmup 5 --timed-only >> ${O}_reeval.jsonl 2>> ${O}_ab.err
+  done
+  timeout 600 python tools/closed_loop_tables_bench.py > ${O}_closed_loop_tables.json 2> ${O}_closed_loop_tables.err
+  ;;
 esac
