@@ -409,26 +409,29 @@ def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench", pmc=Fals
 
 
 # ---------------------------------------------------------------------------------------------------- closed GD loop
-def _closed_loop_inputs(model, B, T, tdt, dev):
+CNN_CFG = {"actor_cnn": {"kernel_sizes": [3, 3], "layer_sizes": [8, 16], "stride_sizes": [1, 1], "hidden_size": 32, "activation": "elu"}, "actor_logstd_init": -1.0}
+
+
+def _closed_loop_inputs(model, B, T, tdt, dev, cnn=False):
     from tactilesimulation_amd.envs.tactile_push import BatchedTactilePushEnv
-    from tactilesimulation_amd.algorithms.batched_gd import Actor
-    env = BatchedTactilePushEnv(model, B, device=str(dev), dtype=tdt, gradient=True, seed=0, tape_steps=T)
+    from tactilesimulation_amd.algorithms.batched_gd import Actor, CNNActor
+    env = BatchedTactilePushEnv(model, B, device=str(dev), dtype=tdt, gradient=True, seed=0, tape_steps=T, observation_type="tactile_map" if cnn else "tactile_flatten")
     env.reset()
     q0, goal = env.q0.clone(), env.goal.clone()
     rng = np.random.default_rng(1)
     dist_ = torch.tensor(rng.uniform(-1, 1, size=(T, B, 2)) * (rng.uniform(size=(T, B, 1)) < 0.5), device=dev, dtype=tdt)
     torch.manual_seed(0)
-    actor = Actor(dtype=tdt).to(dev)
+    actor = (CNNActor((3, 13, 10), 3, CNN_CFG, state_dim=3, dtype=tdt) if cnn else Actor(dtype=tdt)).to(dev)
     opt = torch.optim.Adam(actor.parameters(), lr=5e-3, betas=(0.7, 0.95))          # cfg/gd_tactile.yaml
     return env, q0, goal, dist_, actor, opt
 
 
-def closed_loop_leg(model, B, T, tdt, dev, epochs=3):
+def closed_loop_leg(model, B, T, tdt, dev, epochs=3, cnn=False):
     """BASELINE config 3 as algorithms/gd.py:224-259 runs it — observation -> policy -> env-step, 100 env-steps, BPTT, one
     gradient all-reduce + clip + Adam per epoch — with every environment of the batch as one episode and the episode + its
     backward replayed from one HIP graph (algorithms/batched_gd.GraphedRollout: any torch policy)."""
     from tactilesimulation_amd.algorithms.batched_gd import GraphedRollout, train_epoch_graphed
-    env, q0, goal, dist_, actor, opt = _closed_loop_inputs(model, B, T, tdt, dev)
+    env, q0, goal, dist_, actor, opt = _closed_loop_inputs(model, B, T, tdt, dev, cnn=cnn)
     gr = GraphedRollout(env, actor, T, q0, goal, dist_, warmup=1)
     train_epoch_graphed(gr, opt, B)
     torch.cuda.synchronize()
@@ -437,8 +440,9 @@ def closed_loop_leg(model, B, T, tdt, dev, epochs=3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     res = {"value": B * T * epochs / dt, "unit": "env-steps/s", "s_per_epoch": dt / epochs, "epochs": epochs, "horizon": T, "batch": B,
-           "what": "closed GD epoch: policy MLP (29 574 parameters) between env-steps, per-env-step launches of the simulator, BPTT, "
-                   "gradient normalise + clip + Adam; one HIP graph replay per episode",
+           "what": "closed GD epoch: %s between env-steps, per-env-step launches of the simulator, BPTT, gradient normalise + clip + Adam; one HIP graph replay per episode"
+                   % ("the reference's CNN policy on its default tactile_map observation (utils/model.py:37-98; %d parameters, MIOpen convolutions)" % sum(p.numel() for p in actor.parameters())
+                      if cnn else "policy MLP (29 574 parameters)"),
            "loss_per_episode": [float(l) / B for l in losses]}
     del gr, env
     torch.cuda.empty_cache()
@@ -696,6 +700,7 @@ def run_leg(name, res, ctx):
             return
         res["closed_loop"] = closed_loop_fused_leg(model, B, T, tdt, dev)
         res["closed_loop_per_step_graph"] = closed_loop_leg(model, B, T, tdt, dev)
+        res["closed_loop_cnn_per_step_graph"] = closed_loop_leg(model, B, T, tdt, dev, epochs=2, cnn=True)
     elif name == "readout":
         res["readout"] = readout_legs(tdt, dev, args.dtype, pmc="pmc" in args.leg_list)
     elif name == "cpu":

@@ -130,6 +130,48 @@ class Actor(torch.nn.Module):
             self._armed = False
 
 
+class CNNActor(torch.nn.Module):
+    """The reference's CNN policy for the `tactile_map` observation — TactilePushEnv's DEFAULT observation_type (envs/tactile_push_env.py:21,37-40)
+    — utils/model.py:37-98 CNN + CNNActor: Conv2d(k, stride) + activation per layer, Flatten, Linear -> hidden, activation, Linear -> action_dim, and
+    the log-std vector.  Same constructor arguments and the same state_dict names (feature_net.body.N, mean_net, logstd), so a checkpoint of the
+    reference loads with load_state_dict (tests/test_policy_and_utils.py checks parameters -> outputs against vectors recorded from the reference's
+    class).  forward() returns the MEAN action (what DiagGaussian.mode() / act(deterministic=True) gives; the batched GD loop is deterministic).
+    Takes the tactile image [B, C, rows, cols] or BatchedTactilePushEnv's tactile_map observation tuple (image, goal-in-gripper-frame); the reference's
+    CNNActor looks at the image only, and so does this one unless state_dim > 0 (then the state part is concatenated to the CNN features in front
+    of mean_net — an extension, off by default).  Runs as plain torch modules (MIOpen convolutions): the closed loop with this policy is the
+    per-env-step graph (GraphedRollout), not the fused episode launch, whose in-kernel policy is the 393-64-64-3 MLP."""
+
+    _ACT = {"tanh": torch.nn.Tanh, "relu": torch.nn.ReLU, "elu": torch.nn.ELU, "identity": torch.nn.Identity}
+
+    def __init__(self, obs_shape, action_dim, cfg_network, state_dim=0, dtype=torch.float32):
+        super().__init__()
+        assert len(obs_shape) == 3                      # (feature_channels, rows, cols)
+        cfg = cfg_network["actor_cnn"]
+        act = self._ACT[cfg["activation"].lower()]
+        in_ch, rows, cols = obs_shape
+        mods = []
+        for k, n, st in zip(cfg["kernel_sizes"], cfg["layer_sizes"], cfg["stride_sizes"]):
+            mods += [torch.nn.Conv2d(in_ch, n, k, stride=st), act()]
+            if cfg.get("layernorm", False):
+                mods.append(torch.nn.LayerNorm(n))
+            in_ch, rows, cols = n, (rows - k) // st + 1, (cols - k) // st + 1
+        mods += [torch.nn.Flatten(), torch.nn.Linear(rows * cols * in_ch, cfg["hidden_size"]), act()]
+        self.feature_net = torch.nn.Module()
+        self.feature_net.body = torch.nn.Sequential(*mods)
+        self.feature_net.out_features = cfg["hidden_size"]
+        self.state_dim = int(state_dim)
+        self.mean_net = torch.nn.Linear(cfg["hidden_size"] + self.state_dim, action_dim)
+        self.logstd = torch.nn.Parameter(torch.ones(action_dim) * cfg_network.get("actor_logstd_init", -1.0))
+        self.to(dtype)
+
+    def forward(self, obs):
+        img, state = (obs if isinstance(obs, (tuple, list)) else (obs, None))
+        f = self.feature_net.body(img.contiguous())
+        if self.state_dim:
+            f = torch.cat([f, state], dim=1)
+        return self.mean_net(f)
+
+
 def rollout_loss(env, actor, horizon, q0=None, goal=None, disturbances=None):
     """-sum of rewards of all environments over one episode (un-normalised; see train_epoch)."""
     obs = env.reset(q0, goal)

@@ -39,4 +39,8 @@ d)  # fused closed loop with per-environment tables (structure-static closed-loo
   done
   timeout 600 python tools/closed_loop_tables_bench.py > ${O}_closed_loop_tables.json 2> ${O}_closed_loop_tables.err
   ;;
+e)  # CNN policy on the tactile_map observation: graphed == eager, then the bench with the closed-loop legs only
+  ( timeout 900 python -m pytest tests/test_gpu_batched_env.py -m gpu -q -x 2>&1 | tail -6 ) > ${O}_tests.log 2>&1
+  timeout 600 python bench.py --steps 20 --warmup 5 --legs closed_loop > ${O}_bench.json 2> ${O}_bench.err; cp bench_detail.json ${O}_bench_detail.json
+  ;;
 esac
