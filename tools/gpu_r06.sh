@@ -43,4 +43,15 @@ e)  # CNN policy on the tactile_map observation: graphed == eager, then the benc
   ( timeout 900 python -m pytest tests/test_gpu_batched_env.py -m gpu -q -x 2>&1 | tail -6 ) > ${O}_tests.log 2>&1
   timeout 600 python bench.py --steps 20 --warmup 5 --legs closed_loop > ${O}_bench.json 2> ${O}_bench.err; cp bench_detail.json ${O}_bench_detail.json
   ;;
+z)  # the round's evidence run: full GPU suite, the driver's bench command (with its in-run PMC passes), kernel traces of the timed regions of the
+    # headline and of the dclaw / insertion / fp64 legs, the 100-step line, the suite once more with the exact shortcuts OFF
+  ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -12 ) > ${O}_tests.log 2>&1
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --pmc-dump ${O}_pmc_f32.json > ${O}_bench.json 2> ${O}_bench.err; cp bench_detail.json ${O}_bench_detail.json
+  ktrace f32_steps20 --steps 20 --warmup 20
+  ktrace dclaw --workload dclaw --steps 50 --warmup 50 --repeats 2
+  ktrace insertion --workload insertion --steps 9 --warmup 9 --repeats 2
+  ktrace f64_steps20 --dtype f64 --steps 20 --warmup 20
+  timeout 600 python bench.py --steps 100 --warmup 10 --legs pmc > ${O}_bench_steps100.json 2> ${O}_bench_steps100.err
+  ( TSIM_NO_TRIAL_HELPERS=1 TSIM_NO_VALUE_FIRST=1 TSIM_VALUE_TRIALS=0 TSIM_NO_PAIR_CULL=1 timeout 2400 python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_exact_options.py 2>&1 | tail -6 ) > ${O}_tests_options_off.log 2>&1
+  ;;
 esac
