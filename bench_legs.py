@@ -121,7 +121,7 @@ def kernel_record(sim, dtype, forward_only=False, policy=False):
            "options": {"pair_cull": sim.get_option(sim.OPT_PAIR_CULL), "value_trials": sim.get_option(sim.OPT_VALUE_TRIALS),
                        "trial_helpers": sim.get_option(sim.OPT_TRIAL_HELPERS), "value_first": sim.get_option(sim.OPT_VALUE_FIRST)}}
     for k in ("k_forward",) + (() if forward_only else ("k_backward",)):
-        mangled, readable = buildhash.kernel_name(k, dtype, sim.ndof_r, has_exp, info["lanes_per_env"], variant, policy)
+        mangled, readable = buildhash.kernel_name(k, dtype, sim.ndof_r, has_exp, info["lanes_per_env"], variant, policy, default_opts=sim.get_option(sim.OPT_ALL_DEFAULT) == 1)
         rec[k] = dict({"instantiation": readable, "symbol": mangled}, **(table.get(mangled) or {"metadata": "not found in %s" % os.path.basename(buildhash.KERNELS_JSON)}))
     return rec
 

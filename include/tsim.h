@@ -216,7 +216,12 @@ const char* tsim_kernel_variant(const tsim_batch* b);
  *                       tsim_reset with backward_flag 0) never use the Newton matrix of a sub-step's FINAL iterate.  Where the previous sub-step
  *                       of an environment converged in one Newton step, the first trial of the next one evaluates the residual without its
  *                       tangents; it is taken as it is if it ends the sub-step, and evaluated again in full otherwise.  Exact, as above. */
-enum { TSIM_OPT_PAIR_CULL = 1, TSIM_OPT_VALUE_TRIALS = 2, TSIM_OPT_TRIAL_HELPERS = 3, TSIM_OPT_VALUE_FIRST = 4 };
+/* Read-only through tsim_get_option (set them with tsim_set_solver_options): TSIM_OPT_CROSS_KINKS, TSIM_OPT_EVAL_BUDGET; and TSIM_OPT_ALL_DEFAULT = 1 iff
+ * every solver / scheduling option of the batch is at its default (cross_kinks 1, eval_budget 0, value_trials 2, trial_helpers 1, value_first 1) — the
+ * forward launch of an fp32 batch on a compiled-in model at four environments per wavefront then runs an instantiation that has them as compile-time
+ * constants (same results bit for bit, ~2 % faster; environment variable TSIM_NO_DEFAULT_OPTS=1 at creation: never). */
+enum { TSIM_OPT_PAIR_CULL = 1, TSIM_OPT_VALUE_TRIALS = 2, TSIM_OPT_TRIAL_HELPERS = 3, TSIM_OPT_VALUE_FIRST = 4, TSIM_OPT_CROSS_KINKS = 5, TSIM_OPT_EVAL_BUDGET = 6,
+       TSIM_OPT_ALL_DEFAULT = 7 };
 int tsim_set_option(tsim_batch* b, int option, int value);
 int tsim_get_option(const tsim_batch* b, int option);
 

@@ -428,7 +428,7 @@ struct tsim_batch {
   int value_first = 1;           // launches without a tape: the first trial after a Newton step evaluates the residual only where the previous sub-step converged in one step (tsim_set_option TSIM_OPT_VALUE_FIRST; TSIM_NO_VALUE_FIRST=1 at creation: off)
   // A/B switches of the environment, read ONCE at creation (launches are on the host-bound path of the per-step collectors):
   // TSIM_NO_EPISODE_LPT, TSIM_INKERNEL_READOUT, TSIM_NO_FREE_RUN, TSIM_LOCKSTEP, TSIM_TAXELS_PER_RECORD, TSIM_NO_ENVTAB_CPT
-  bool ab_no_episode_lpt = false, ab_inkernel_readout = false, ab_no_free_run = false, ab_lockstep = false, ab_taxels_per_record = false, ab_no_envtab_cpt = false;
+  bool ab_no_episode_lpt = false, ab_inkernel_readout = false, ab_no_free_run = false, ab_lockstep = false, ab_taxels_per_record = false, ab_no_envtab_cpt = false, ab_no_default_opts = false;
   int pair_cull = 1;             // phase 2 skips contact pairs out of reach of their primitive (tsim_set_option TSIM_OPT_PAIR_CULL; TSIM_NO_PAIR_CULL=1 at creation: off)
   // Compiled-in models (csrc/tsim_static.h).  static_id: the model whose STRUCTURE the batch's blob has (ints + the structural floats: 1 TactilePush);
   // static_exact: every float record equals the compiled asset's bit for bit as well (the fully static instantiation); env_struct_ok: the
@@ -605,6 +605,11 @@ static int kernel_mode(const tsim_batch* b) {
   if (b->dtype == TSIM_F64 && b->lpe_forced == 16) return TS_KM_GENERIC;    // fp64: no compiled-in instantiation with four environments per wavefront (16 lanes only when forced: its LDS is over the automatic cap)
   if (b->dFenv) return b->env_struct_ok ? TS_KM_PARAM : TS_KM_GENERIC;      // (the table check is fp32 only: fp64 batches with per-environment tables stay generic)
   return b->static_exact ? TS_KM_STATIC : TS_KM_PARAM;
+}
+// every solver / scheduling option of the batch at its default: the forward launch of a compiled-in model may use the TsDefaultOpts<> instantiation
+// (tsim_static.h), which has them as constants.  (TSIM_NO_DEFAULT_OPTS=1 at creation keeps the run-time-option kernel: A/B.)
+static bool default_options(const tsim_batch* b) {
+  return b->cross_kinks == 1 && b->eval_budget == 0 && b->value_trials == 2 && b->trial_helpers == 1 && b->value_first == 1 && !b->ab_lockstep && !b->ab_no_default_opts;
 }
 static int upload_model(tsim_batch* b, hipStream_t st) {
   detect_static_model(b);
@@ -848,6 +853,7 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
   a.free_run = (defer || !tac_out || b->ntax == 0) && !b->ab_no_free_run;
   a.lockstep = b->ab_lockstep ? 1 : 0;
   if (a.lockstep) a.free_run = 0;
+  a.default_opts = default_options(b) ? 1 : 0;
   { KtScope kt_(b, TSIM_KT_FORWARD, st); TS_LAUNCH(k_forward, R, b, st, a); }
   HIPCHK(hipGetLastError());
   if (defer) { KtScope kt_(b, TSIM_KT_TAXELS, st); if (launch_taxels<R>(b, b->fposeR, b->fposeD, nframes, tac_slot, tac_out, st)) return 1; }
@@ -915,7 +921,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->no_static = getenv("TSIM_NO_STATIC") != nullptr;
   b->trial_helpers = getenv("TSIM_NO_TRIAL_HELPERS") ? 0 : 1;
   b->ab_no_episode_lpt = getenv("TSIM_NO_EPISODE_LPT") != nullptr; b->ab_inkernel_readout = getenv("TSIM_INKERNEL_READOUT") != nullptr;
-  b->ab_no_free_run = getenv("TSIM_NO_FREE_RUN") != nullptr; b->ab_lockstep = getenv("TSIM_LOCKSTEP") != nullptr;
+  b->ab_no_free_run = getenv("TSIM_NO_FREE_RUN") != nullptr; b->ab_lockstep = getenv("TSIM_LOCKSTEP") != nullptr; b->ab_no_default_opts = getenv("TSIM_NO_DEFAULT_OPTS") != nullptr;
   b->ab_taxels_per_record = getenv("TSIM_TAXELS_PER_RECORD") != nullptr; b->ab_no_envtab_cpt = getenv("TSIM_NO_ENVTAB_CPT") != nullptr;
   b->value_first = getenv("TSIM_NO_VALUE_FIRST") ? 0 : 1;
   if (const char* e = getenv("TSIM_VALUE_TRIALS")) b->value_trials = std::max(0, atoi(e));
@@ -1018,6 +1024,9 @@ int tsim_get_option(const tsim_batch* b, int option) {
   if (option == TSIM_OPT_VALUE_TRIALS) return b->value_trials;
   if (option == TSIM_OPT_TRIAL_HELPERS) return b->trial_helpers;
   if (option == TSIM_OPT_VALUE_FIRST) return b->value_first;
+  if (option == TSIM_OPT_CROSS_KINKS) return b->cross_kinks;
+  if (option == TSIM_OPT_EVAL_BUDGET) return b->eval_budget;
+  if (option == TSIM_OPT_ALL_DEFAULT) return default_options(b) ? 1 : 0;
   return -1;
 }
 int tsim_set_solver_options(tsim_batch* b, int cross_kinks, int eval_budget) {

@@ -9,6 +9,10 @@
 #include "tsim_eval.h"
 #include "tsim_policy_push.h"
 
+// the model's integrator (1 BDF1, 2 BDF2): read from the blob, or the compiled-in model's constant (the batch's int blob equals it: blob_has_structure)
+template <class MS, class C> __device__ __forceinline__ int ts_integrator(const C& c) {
+  if constexpr (std::is_void<MS>::value) return ts_u(c.I[TSIM_IH_INTEGRATOR]); else return MS::Iv(TSIM_IH_INTEGRATOR);
+}
 // number of dofs of a statically known model (0: generic kernels, the size is a run-time value)
 template <class MS> constexpr int ts_static_nr() { if constexpr (std::is_void<MS>::value) return 0; else return MS::Iv(TSIM_IH_NR); }
 
@@ -108,6 +112,8 @@ template <class R> struct FwdArgs {
   int vo_ls = 0;               // > 0: line-search trials after vo_ls rejected ones evaluate the residual only (k_forward, main loop; tsim_set_option TSIM_OPT_VALUE_TRIALS)
   int* helped = nullptr;        // [B] line-search trials of the launch that a helper slot evaluated for this environment (tsim_last_helper_trials)
   int vo_first = 0;            // forward-only launches: the first trial after a Newton step is evaluated without tangents where the previous sub-step converged in one step (k_forward; TSIM_OPT_VALUE_FIRST)
+  int default_opts = 0;        // every option above is at its default (cross_kinks 1, eval_budget 0, vo_ls 2, vo_first 1, helpers 1, lockstep 0): the launcher of a
+                               // compiled-in model may then pick the TsDefaultOpts<> instantiation, which has them as constants (tsim_static.h)
   int helpers = 0;             // slots that have finished their environment evaluate the NEXT line-search trials of a slot that is still in one (k_forward, main loop; TSIM_OPT_TRIAL_HELPERS)
 };
 
@@ -123,6 +129,9 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   constexpr int NS = TS_WAVE / LPE;
+  // a TsDefaultOpts<> instantiation (tsim_static.h): the options below are their defaults, as constants — the host launches it only then
+  constexpr bool kFixed = TsHasDefaultOpts<MS>::value && !POLICY;
+#define TS_OPT(field, fixed) (kFixed ? (fixed) : a.field)
   const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;       // lane: inside the slot
   // Stragglers set the kernel time (all environments wait for the one with the most Newton work), so environments that
   // were expensive in the previous env-step are dispatched first: slot s of block b runs environment order[b NS + s]
@@ -143,7 +152,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   int bad = 0; bool nonfinite = false;
   int evals = 0;
   R gmax = R(0);
-  const bool bdf2_model = ts_u(c.I[TSIM_IH_INTEGRATOR]) == 2;
+  const bool bdf2_model = ts_integrator<MS>(c) == 2;      // (a compile-time constant for a compiled-in model: its BDF2 branches fold away)
   // BDF2 history (the state before the previous sub-step).  While recording it is tape record t0 - 1 — so taped sub-step t is a BDF2
   // step exactly when t >= 2, which is what the adjoint kernel assumes (also after the tape was swapped by the backward cache);
   // without a tape it is the batch's `prev` buffer.
@@ -206,7 +215,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   // (reductions inside a slot are symmetric), so iterates, convergence flags, taped matrices and `evals` (trial points judged) are those of
   // the loop without helpers, bit for bit (tests/test_gpu_exact_options.py); a line search of n trials takes ceil(n / (1 + helpers)) rounds.
   // Not in launches that leave their final link records for tsim_readout (a helper's records are not its environment's).
-#define helpers_on (NS > 1 && !POLICY && a.helpers != 0 && !a.lockstep && a.poseR == nullptr)      /* (re-read from the kernel arguments where it is asked: no register held for it) */
+#define helpers_on (NS > 1 && !POLICY && TS_OPT(helpers, 1) != 0 && !TS_OPT(lockstep, 0) && a.poseR == nullptr)      /* (re-read from the kernel arguments where it is asked: no register held for it) */
   static_assert(NS <= 4, "helper slots: three result registers (gh0..gh2) and step factors 1/2, 1/4, 1/8 — at most three helpers per owner");
   if (helpers_on && !valid) { done = true; fs = false; ss = false; }      // an idle slot of the last wavefront helps from the start
   int helped = 0;
@@ -219,7 +228,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   // needs H from it, and free-running slots drift out of phase (one at its predictor while the other is at its trial: every round full); a slot
   // about to START a sub-step therefore waits ONE round — at most once per sub-step — when that makes the round value-only, which puts it in
   // phase with the others.  Same iterates, flags and evaluation counts as without the option (tests/test_gpu_exact_options.py).
-  const bool vfirst = a.vo_first != 0 && a.record == 0 && !POLICY && !a.lockstep;
+  const bool vfirst = TS_OPT(vo_first, 1) != 0 && a.record == 0 && !POLICY && !TS_OPT(lockstep, 0);
   // `kq`: the last measured contraction of a full Newton step of this slot, ||g_new|| / ||g||^2 (quadratic convergence: roughly a constant of
   // the problem) — the first trial after a step from residual gn is expected to end the sub-step if kq gn^2 is well below tol.
   R kq = R(1e30);
@@ -308,7 +317,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     //    TactileInsertion grasp (||g|| ~ 1e-3, steps of 0.02 - 0.5) that reached roots 0.15 rad away from the literal one.
     //  * eval_budget (default 0 = none): an upper bound on the evaluations of one sub-step for throughput-minded roll-out collection;
     //    a sub-step cut short is flagged non-converged in status.
-    const bool tang = (a.vo_ls <= 0 && !vfirst) || __any(!fin && !done && !held && !vo && !wait_);      // does any live slot need H from this round?
+    const bool tang = (TS_OPT(vo_ls, 2) <= 0 && !vfirst) || __any(!fin && !done && !held && !vo && !wait_);      // does any live slot need H from this round?
     // ---- helper slots: who evaluates whose next trials this round (wave-uniform masks over the slots; see above).  Nothing of this is live
     //      across the evaluation (the kernels hold one wavefront per SIMD on their register count): the helpers are set up here, the owners
     //      find theirs again afterwards, from the same masks
@@ -375,7 +384,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     auto judge = [&](const R gj, const int j, const int hj) -> bool {
       int action = 2;                        // the first evaluation of the sub-step, an accepted trial, or the step across a kink
       if (ls >= 0 && !forced && (!ts_finite(gj) || gj >= gn)) {              // a rejected trial (a non-finite one is rejected too)
-        if (a.cross_kinks && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) action = 0;
+        if (TS_OPT(cross_kinks, 1) && ls >= min(c.max_ls, TSIM_KINK_LS) && crossings < TSIM_KINK_MAX && gn < R(TSIM_KINK_FACTOR) * c.tol) action = 0;
         else if (ls < c.max_ls) action = 1;
       }                                      // (else: the literal loop takes the last trial anyway)
       if (action == 2) {
@@ -384,10 +393,10 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
         // there (its records, q and qd are the frame's), or without tangents, this slot evaluates the point again itself.
         // A launch that records no tape has no use for H of a point that ENDS the sub-step: this slot's own value-only evaluation of such a
         // point is taken as it is, a helper's is evaluated again by this slot (its link records are the frame's) — value-only.
-        const bool ends = !ts_finite(gj) || gj < c.tol || (ls >= 0 && iter + 1 >= c.max_iter) || (a.eval_budget > 0 && sub_evals + 1 >= a.eval_budget);
+        const bool ends = !ts_finite(gj) || gj < c.tol || (ls >= 0 && iter + 1 >= c.max_iter) || (TS_OPT(eval_budget, 0) > 0 && sub_evals + 1 >= TS_OPT(eval_budget, 0));
         const bool no_h = ends && a.record == 0;
         bool usable = j == 0 ? (tang || no_h) : (tang && !ends);
-        vo = !usable && no_h && (a.vo_ls > 0 || vfirst);
+        vo = !usable && no_h && (TS_OPT(vo_ls, 2) > 0 || vfirst);
         if (usable) {
           ++evals; ++sub_evals; take = true; gtake = gj;
           if (j > 0) {
@@ -405,7 +414,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
         return false;
       }
       alpha *= R(0.5); ++ls;                 // halve the step
-      vo = a.vo_ls > 0 && ls >= a.vo_ls;
+      vo = TS_OPT(vo_ls, 2) > 0 && ls >= TS_OPT(vo_ls, 2);
       if (lane < nr) c.dl[lane] = ts_trial_point(dlbase[lane], alpha, c.dq[lane]);
       return true;
     };
@@ -427,7 +436,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
         gn = gtake;
         if (!ts_finite(gn)) { nonfinite = true; fin = true; }
         else if (gn < c.tol) { conv = true; fin = true; }
-        else if (iter >= c.max_iter || (a.eval_budget > 0 && sub_evals >= a.eval_budget)) fin = true;
+        else if (iter >= c.max_iter || (TS_OPT(eval_budget, 0) > 0 && sub_evals >= TS_OPT(eval_budget, 0))) fin = true;
         else {
           solve = true;
           if (lane < nr) { c.rhs[lane] = -c.g[lane]; dlbase[lane] = c.dl[lane]; }
@@ -446,7 +455,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
     }
     // ---- commit the sub-steps that ended with this evaluation: c.q = q1, c.qd = (q1 - q0)/h, c.H = dg/dq1 at q1
     bool commit = fin && !done && !held;
-    if (a.lockstep && !__all(fin || done)) commit = false;      // the slots of a wavefront go through the sub-steps together (see FwdArgs)
+    if (TS_OPT(lockstep, 0) && !__all(fin || done)) commit = false;      // the slots of a wavefront go through the sub-steps together (see FwdArgs)
     if (!free_run) {                           // the last sub-step of a frame is committed by all slots together
       if (commit && s == a.nsub - 1) { held = true; commit = false; }
       if (__all(held || done)) { commit = held; held = false; }
@@ -546,6 +555,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   }
 }
 #undef helpers_on
+#undef TS_OPT
 
 
 // ================================================================================================ backward kernel
@@ -728,7 +738,7 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   // BDF2 models: taped sub-step t >= 2 is a BDF2 step (the first one after a reset is the BDF1 start-up, k_forward).  Its new state
   // depends on the TWO states before it, so next to the adjoint of the state one step back (lamq, lamv) the kernel carries what later
   // sub-steps already contributed to the state two steps back (lq1, lv1: one value per lane, in registers; second half of the buffers).
-  const bool bdf2_model = ts_u(c.I[TSIM_IH_INTEGRATOR]) == 2;
+  const bool bdf2_model = ts_integrator<MS>(c) == 2;      // (a compile-time constant for a compiled-in model: its BDF2 branches fold away)
   const size_t half = (size_t)a.B * nr;
   R lq1 = R(0), lv1 = R(0);
   if (bdf2_model && lane < nr) { lq1 = a.lamq[half + (size_t)env * nr + lane]; lv1 = a.lamv[half + (size_t)env * nr + lane]; }

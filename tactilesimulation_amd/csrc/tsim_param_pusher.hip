@@ -11,7 +11,8 @@
 using TsParamPusher = TsParam<TsStaticPusher>;
 
 void ts_param_pusher_launch(const FwdArgs<float>& a, int lpe, unsigned grid, size_t lds, hipStream_t st) {
-  if (lpe == 16) hipLaunchKernelGGL((k_forward<float, 8, false, 16, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+  if (lpe == 16 && a.default_opts) hipLaunchKernelGGL((k_forward<float, 8, false, 16, false, TsDefaultOpts<TsParamPusher>>), dim3(grid), dim3(TS_WAVE), lds, st, a);      // every option at its default: as constants
+  else if (lpe == 16) hipLaunchKernelGGL((k_forward<float, 8, false, 16, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
   else if (lpe == 32) hipLaunchKernelGGL((k_forward<float, 8, false, 32, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
   else hipLaunchKernelGGL((k_forward<float, 8, false, 64, false, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
 }

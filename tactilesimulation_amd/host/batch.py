@@ -284,7 +284,7 @@ class BatchSim:
         """Name of the kernel instantiation the next launch uses: "generic", "static:<model>", "param:<model>" (include/tsim.h)."""
         return capi.lib().tsim_kernel_variant(self._h).decode()
 
-    OPT_PAIR_CULL, OPT_VALUE_TRIALS, OPT_TRIAL_HELPERS, OPT_VALUE_FIRST = 1, 2, 3, 4
+    OPT_PAIR_CULL, OPT_VALUE_TRIALS, OPT_TRIAL_HELPERS, OPT_VALUE_FIRST, OPT_CROSS_KINKS, OPT_EVAL_BUDGET, OPT_ALL_DEFAULT = 1, 2, 3, 4, 5, 6, 7
 
     def set_option(self, option, value):
         """include/tsim.h tsim_set_option (TSIM_OPT_*)."""

@@ -136,12 +136,16 @@ def write_kernel_table(lib=None, out=None):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def kernel_name(kernel, dtype, nr, has_exp, lanes, variant, policy=False):
-    """Mangled name of the instantiation of k_forward / k_backward a batch launches (csrc/tsim_hip.hip TS_LAUNCH) and a readable form of it."""
+def kernel_name(kernel, dtype, nr, has_exp, lanes, variant, policy=False, default_opts=False):
+    """Mangled name of the instantiation of k_forward / k_backward a batch launches (csrc/tsim_hip.hip TS_LAUNCH) and a readable form of it.
+    default_opts: every solver / scheduling option of the batch is at its default (tsim_get_option TSIM_OPT_ALL_DEFAULT): the fp32 forward launch of a
+    compiled-in model at 16 lanes per environment then runs the TsDefaultOpts<> instantiation (csrc/tsim_static.h)."""
     nrm, expj, lpe = (16, True, 64) if has_exp else ((8 if nr <= 8 else 16), False, lanes)
     if variant != "generic":
         nrm = 8
     ms = {"generic": ("v", "void"), "static:pusher": ("14TsStaticPusher", "TsStaticPusher"), "param:pusher": ("7TsParamI14TsStaticPusherE", "TsParam<TsStaticPusher>")}[variant]
+    if default_opts and kernel == "k_forward" and variant != "generic" and dtype == "f32" and lpe == 16 and not policy:
+        ms = ("13TsDefaultOptsI%sE" % ms[0], "TsDefaultOpts<%s>" % ms[1])
     r = {"f32": ("f", "float"), "f64": ("d", "double")}[dtype]
     args = {"k_forward": "7FwdArgs", "k_backward": "7BwdArgs"}[kernel]
     mangled = "_Z%d%sI%sLi%dELb%dELi%dELb%dE%sEv%sIT_E" % (len(kernel), kernel, r[0], nrm, int(expj), lpe, int(policy), ms[0], args)

@@ -153,6 +153,54 @@ def test_helper_slots_with_per_environment_tables_on_the_generic_kernels():
     assert int(plain[6].sum()) == 0 and int(r[6].sum()) > 0
 
 
+@pytest.mark.parametrize("tables", [False, True])
+def test_the_default_options_instantiation_changes_no_number(pusher_model, tables, monkeypatch):
+    """Round 6: with every solver / scheduling option at its default the fp32 forward launch of a compiled-in model at four environments per wavefront
+    runs k_forward<..., TsDefaultOpts<MS>> — the options as compile-time constants (csrc/tsim_static.h; ~2 % faster) — and must give what the
+    run-time-option kernel gives (TSIM_NO_DEFAULT_OPTS=1 at creation), bit for bit: states, tactile frames, evaluation counts, helper trials, gradients.
+    Fully static and structure-static (per-environment tables)."""
+    import tactilesimulation_amd.model.blob as BL
+    B = 1024
+    q0, u, _ = push_workload(B, 12, seed=8)
+    T, S, dtype = u.shape[1], 5, torch.float32
+
+    def run(no_default):
+        if no_default:
+            monkeypatch.setenv("TSIM_NO_DEFAULT_OPTS", "1")
+        else:
+            monkeypatch.delenv("TSIM_NO_DEFAULT_OPTS", raising=False)
+        sim = BatchSim(pusher_model, B, dtype=dtype, tape_capacity=T * S)
+        sim.set_lanes_per_env(16)
+        assert sim.get_option(BatchSim.OPT_ALL_DEFAULT) == (0 if no_default else 1) and sim.get_option(BatchSim.OPT_CROSS_KINKS) == 1 and sim.get_option(BatchSim.OPT_EVAL_BUDGET) == 0
+        if tables:
+            tab = sim.base_tables()
+            fo = int(pusher_model.I[BL.TSIM_IH_FOFF_DOF])
+            tab[:, fo + BL.TSIM_DF_DAMPING] = (0.5 + torch.rand(B, generator=torch.Generator().manual_seed(4))).to(tab)
+            sim.set_env_tables(tab)
+        sim.reset(torch.tensor(q0, device=DEV, dtype=dtype), None, backward_flag=True)
+        ro = sim.rollout(torch.tensor(u, device=DEV, dtype=dtype).transpose(0, 1).contiguous(), S, want_qd=True)
+        ev = sim.last_evals().copy()
+        g = torch.Generator().manual_seed(9)
+        wq, wv, wt = (torch.randn(T, B, n, generator=g).to(DEV) for n in (7, 6, 390))
+        du = sim.backward_episode(T, S, wq, wv, wt)
+        lq, lv = sim.get_adjoint()
+        return ro, ev, du, lq, lv, sim.kernel_variant(), sim.last_helper_trials().copy()
+
+    a, b = run(False), run(True)
+    assert a[5] == b[5] == ("param:pusher" if tables else "static:pusher")
+    _same(a, b, ("static pusher", tables, "default-options instantiation"))
+    assert (a[6] == b[6]).all()
+    # a changed option takes the batch off it (and back)
+    sim = BatchSim(pusher_model, 64, dtype=dtype, tape_capacity=0)
+    assert sim.get_option(BatchSim.OPT_ALL_DEFAULT) == 1
+    sim.set_solver_options(cross_kinks=True, eval_budget=32)
+    assert sim.get_option(BatchSim.OPT_ALL_DEFAULT) == 0 and sim.get_option(BatchSim.OPT_EVAL_BUDGET) == 32
+    sim.set_solver_options(cross_kinks=True, eval_budget=0); sim.set_option(BatchSim.OPT_VALUE_TRIALS, 0)
+    assert sim.get_option(BatchSim.OPT_ALL_DEFAULT) == 0
+    sim.set_option(BatchSim.OPT_VALUE_TRIALS, 2)
+    assert sim.get_option(BatchSim.OPT_ALL_DEFAULT) == 1
+
+
 @pytest.mark.parametrize("lanes", [16, 32])
 @pytest.mark.parametrize("tables", [False, True])
 def test_helper_slots_change_no_number_on_the_compiled_in_kernels(pusher_model, lanes, tables):

@@ -54,4 +54,17 @@ z)  # the round's evidence run: full GPU suite, the driver's bench command (with
   timeout 600 python bench.py --steps 100 --warmup 10 --legs pmc > ${O}_bench_steps100.json 2> ${O}_bench_steps100.err
   ( TSIM_NO_TRIAL_HELPERS=1 TSIM_NO_VALUE_FIRST=1 TSIM_VALUE_TRIALS=0 TSIM_NO_PAIR_CULL=1 timeout 2400 python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_exact_options.py 2>&1 | tail -6 ) > ${O}_tests_options_off.log 2>&1
   ;;
+f)  # A/B of a library variant (csrc/ab/libtsim_$2.so) against the shipped one on the headline, interleaved, timed region only
+  for i in 1 2 3; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --timed-only >> ${O}_$2_shipped.jsonl 2>> ${O}_ab.err
+    TSIM_HIP_LIB=$PWD/tactilesimulation_amd/csrc/ab/libtsim_$2.so timeout 300 python bench.py --steps 20 --warmup 5 --timed-only >> ${O}_$2.jsonl 2>> ${O}_ab.err
+  done
+  ;;
+g)  # default-options instantiation: exactness + parity tests, then the headline with it / without it (TSIM_NO_DEFAULT_OPTS=1), interleaved
+  ( timeout 1500 python -m pytest tests/test_gpu_exact_options.py tests/test_gpu_static_model.py tests/test_gpu_param_model.py tests/test_gpu_configs.py tests/test_gpu_literal.py tests/test_gpu_edge_cases.py tests/test_gpu_bdf2_adjoint.py -m gpu -q -x 2>&1 | tail -8 ) > ${O}_tests.log 2>&1
+  for i in 1 2 3; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --timed-only >> ${O}_default_opts.jsonl 2>> ${O}_ab.err
+    TSIM_NO_DEFAULT_OPTS=1 timeout 300 python bench.py --steps 20 --warmup 5 --timed-only >> ${O}_runtime_opts.jsonl 2>> ${O}_ab.err
+  done
+  ;;
 esac
