@@ -173,6 +173,7 @@ static int push_closed_rollout_t(tsim_batch* b, const tsim_push_policy* pol, con
   a.q_out = (R*)q_out; a.qd_out = (R*)qd_out; a.var_out = (R*)var_out; a.tac_out = (R*)tac_out; a.status = status; a.evals = b->evals; a.order = nullptr;
   a.prev = (double*)b->prev; a.has_prev = b->has_prev; a.stage_cpt = b->stage_cpt;
   a.cross_kinks = b->cross_kinks; a.eval_budget = b->eval_budget; a.gnorm = b->gnorm; a.cull = b->pair_cull; a.vo_ls = b->value_trials;
+  a.default_opts = default_options(b) ? 1 : 0;      // (helpers / value-first trials are off in closed-loop launches whatever the options say: k_forward)
   a.pol = make_push_policy<R>(pol);
   a.pol.goal = (const R*)goal; a.pol.dist = (const R*)dist; a.pol.tac0 = (const R*)tac0;
   a.pol.u_out = (R*)u_out; a.pol.gl_out = (R*)gl_out; a.pol.h1_out = (R*)h1_out; a.pol.h2_out = (R*)h2_out;

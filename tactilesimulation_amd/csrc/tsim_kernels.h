@@ -130,7 +130,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   R* lds = reinterpret_cast<R*>(smem_raw);
   constexpr int NS = TS_WAVE / LPE;
   // a TsDefaultOpts<> instantiation (tsim_static.h): the options below are their defaults, as constants — the host launches it only then
-  constexpr bool kFixed = TsHasDefaultOpts<MS>::value && !POLICY;
+  constexpr bool kFixed = TsHasDefaultOpts<MS>::value;
 #define TS_OPT(field, fixed) (kFixed ? (fixed) : a.field)
   const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;       // lane: inside the slot
   // Stragglers set the kernel time (all environments wait for the one with the most Newton work), so environments that

@@ -12,7 +12,8 @@
 using TsParamPusher = TsParam<TsStaticPusher>;
 
 void ts_param_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((k_forward<float, 8, false, 16, true, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+  if (a.default_opts) hipLaunchKernelGGL((k_forward<float, 8, false, 16, true, TsDefaultOpts<TsParamPusher>>), dim3(grid), dim3(TS_WAVE), lds, st, a);      // every solver option at its default: as constants (tsim_static.h)
+  else hipLaunchKernelGGL((k_forward<float, 8, false, 16, true, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
 }
 void ts_param_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((k_backward<float, 8, false, 16, true, TsParamPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);

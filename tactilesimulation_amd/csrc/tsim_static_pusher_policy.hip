@@ -7,7 +7,8 @@
 #include "tsim_static_pusher.h"
 
 void ts_static_pusher_launch_policy(const FwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((k_forward<float, 8, false, 16, true, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
+  if (a.default_opts) hipLaunchKernelGGL((k_forward<float, 8, false, 16, true, TsDefaultOpts<TsStaticPusher>>), dim3(grid), dim3(TS_WAVE), lds, st, a);      // every solver option at its default: as constants (tsim_static.h)
+  else hipLaunchKernelGGL((k_forward<float, 8, false, 16, true, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);
 }
 void ts_static_pusher_launch_policy(const BwdArgs<float>& a, unsigned grid, size_t lds, hipStream_t st) {
   hipLaunchKernelGGL((k_backward<float, 8, false, 16, true, TsStaticPusher>), dim3(grid), dim3(TS_WAVE), lds, st, a);

@@ -144,7 +144,7 @@ def kernel_name(kernel, dtype, nr, has_exp, lanes, variant, policy=False, defaul
     if variant != "generic":
         nrm = 8
     ms = {"generic": ("v", "void"), "static:pusher": ("14TsStaticPusher", "TsStaticPusher"), "param:pusher": ("7TsParamI14TsStaticPusherE", "TsParam<TsStaticPusher>")}[variant]
-    if default_opts and kernel == "k_forward" and variant != "generic" and dtype == "f32" and lpe == 16 and not policy:
+    if default_opts and kernel == "k_forward" and variant != "generic" and dtype == "f32" and lpe == 16:
         ms = ("13TsDefaultOptsI%sE" % ms[0], "TsDefaultOpts<%s>" % ms[1])
     r = {"f32": ("f", "float"), "f64": ("d", "double")}[dtype]
     args = {"k_forward": "7FwdArgs", "k_backward": "7BwdArgs"}[kernel]

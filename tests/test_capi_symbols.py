@@ -68,7 +68,7 @@ def test_kernel_table_names_the_instantiations_a_batch_launches():
     combos += [(k, "f32", 7, False, l, v, False) for k in ("k_forward", "k_backward") for l in (16, 32, 64) for v in ("static:pusher", "param:pusher")]
     combos += [(k, "f64", 7, False, l, v, False) for k in ("k_forward", "k_backward") for l in (32, 64) for v in ("static:pusher", "param:pusher")]
     combos += [(k, "f32", 7, False, 16, v, True) for k in ("k_forward", "k_backward") for v in ("static:pusher", "param:pusher")]         # closed loop
-    combos += [("k_forward", "f32", 7, False, 16, v, False, True) for v in ("static:pusher", "param:pusher")]                              # every option at its default: TsDefaultOpts<>
+    combos += [("k_forward", "f32", 7, False, 16, v, pol, True) for v in ("static:pusher", "param:pusher") for pol in (False, True)]                              # every option at its default: TsDefaultOpts<>
     for c in combos:
         mangled, readable = buildhash.kernel_name(*c)
         assert mangled in table, (readable, mangled)

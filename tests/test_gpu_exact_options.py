@@ -191,6 +191,7 @@ def test_the_default_options_instantiation_changes_no_number(pusher_model, table
     _same(a, b, ("static pusher", tables, "default-options instantiation"))
     assert (a[6] == b[6]).all()
     # a changed option takes the batch off it (and back)
+    monkeypatch.delenv("TSIM_NO_DEFAULT_OPTS", raising=False)
     sim = BatchSim(pusher_model, 64, dtype=dtype, tape_capacity=0)
     assert sim.get_option(BatchSim.OPT_ALL_DEFAULT) == 1
     sim.set_solver_options(cross_kinks=True, eval_budget=32)

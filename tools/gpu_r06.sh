@@ -67,4 +67,11 @@ g)  # default-options instantiation: exactness + parity tests, then the headline
     TSIM_NO_DEFAULT_OPTS=1 timeout 300 python bench.py --steps 20 --warmup 5 --timed-only >> ${O}_runtime_opts.jsonl 2>> ${O}_ab.err
   done
   ;;
+h)  # default-options closed-loop instantiation: parity, then the closed-loop leg with / without it
+  ( timeout 1500 python -m pytest tests/test_gpu_closed_loop.py tests/test_gpu_exact_options.py -m gpu -q -x 2>&1 | tail -6 ) > ${O}_tests.log 2>&1
+  for i in 1 2; do
+    timeout 300 python tools/closed_loop_tables_bench.py >> ${O}_default_opts.json 2>> ${O}_ab.err
+    TSIM_NO_DEFAULT_OPTS=1 timeout 300 python tools/closed_loop_tables_bench.py >> ${O}_runtime_opts.json 2>> ${O}_ab.err
+  done
+  ;;
 esac
