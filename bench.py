@@ -105,7 +105,7 @@ def _sub_summary(rec):
 def compact_line(res):
     """The ONE stdout line, from the full result dict (which goes to bench_detail.json).  Pure function: tests/test_bench_line.py feeds it a
     canned result and asserts strict JSON and len < LINE_LIMIT."""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "host_gap_ms")
     line = {k: res.get(k) for k in keep}
     cfg = res.get("config") or {}
     line["config"] = {"workload": cfg.get("workload"), "global_batch": cfg.get("global_batch"), "parallelism": cfg.get("parallelism")}
@@ -440,6 +440,9 @@ def main():
             "ranks": {"world_size": world, "ranks_in_first_allreduce": ranks_seen, "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
                       "shared_gpu": share} if world > 1 else None,
             "roofline": rl,
+            # what a window spends outside its simulation kernels (host launch gaps, the reset / reduction launches, the all-reduce): wall clock of the
+            # median window minus the HIP-event kernel time of an average window — SURVEY §8e names this as the expected limiter of the multi-GPU curve
+            "host_gap_ms": dt * 1e3 - sum(ms for ms, _ in ktimes.values()) / max(n_win, 1),
             "nonconverged_warmup": bad_warm,
             "nonconverged_timed": {"substeps": bad_sub_timed, "envs": bad_env_timed, "of_substeps": B * args.steps * fps * S * len(eager_windows)},
             "per_rank": per_rank,

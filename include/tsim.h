@@ -173,7 +173,7 @@ int tsim_launch_info(const tsim_batch* b, int32_t* out);
  * kernels by this batch — k_forward, the tactile read-out kernel that follows it (k_taxels / k_taxels_small), k_backward — is bracketed by a
  * pair of HIP events recorded on the stream the kernel is launched on (never inside a stream capture).  tsim_kernel_times waits for the
  * recorded pairs, returns per kind the summed milliseconds and the number of launches since the previous call (HOST double[TSIM_KT_COUNT],
- * int32[TSIM_KT_COUNT]) and forgets them. */
+ * int32[TSIM_KT_COUNT]) and forgets them; at most 65 536 launches are kept between two calls (later ones are not timed). */
 enum { TSIM_KT_FORWARD = 0, TSIM_KT_TAXELS = 1, TSIM_KT_BACKWARD = 2, TSIM_KT_COUNT = 3 };
 int tsim_kernel_timing(tsim_batch* b, int enable);
 int tsim_kernel_times(tsim_batch* b, double* ms_sum, int32_t* launches);

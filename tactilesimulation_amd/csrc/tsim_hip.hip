@@ -455,7 +455,7 @@ struct tsim_batch {
 struct KtScope {
   tsim_batch* b; hipStream_t st; KtPair p; bool on = false;
   KtScope(tsim_batch* b_, int kind, hipStream_t st_) : b(b_), st(st_) {
-    if (!b->kt_on) return;
+    if (!b->kt_on || b->kt.size() >= (size_t)1 << 16) return;      // (a caller that never reads the times back does not grow the list without bound)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
     hipEvent_t e[2];
