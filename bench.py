@@ -145,7 +145,7 @@ def compact_line(res):
     if res.get("ranks"):
         line["ranks"] = res["ranks"]
     subs = {}
-    for kk in ("env_tables", "f64", "f64_library_default", "push_fwd", "dclaw", "insertion", "closed_loop", "closed_loop_per_step_graph", "closed_loop_cnn_per_step_graph", "readout"):
+    for kk in ("env_tables", "f32_bare_xml_loop", "f64", "f64_library_default", "push_fwd", "dclaw", "insertion", "closed_loop", "closed_loop_per_step_graph", "closed_loop_cnn_per_step_graph", "readout"):
         if kk in res:
             subs[kk] = _sub_summary(res[kk])
     if subs:

@@ -142,7 +142,10 @@ class Leg:
         # f64 legs: 2 of the 4096 TactilePush environments cycle between the two sides of a kink (the loop then runs ~1000 evaluations to
         # max_iter, non-converged either way): bounded.  The fp32 headline has no budget (its largest sub-step: 43 evaluations).
         self.eval_budget = eval_budget if eval_budget is not None else (F64_EVAL_BUDGET if (tdt == torch.float64 and solver != "library") else 0)
-        if solver != "library":
+        if solver == "bare":       # the XML-stated loop and nothing else, whatever the dtype (the reference has no other; fp32 batches run kink crossing by default)
+            sim.set_solver_options(cross_kinks=False, eval_budget=0)
+            self.solver = "the bare XML Newton loop (tol / max_iter / max_ls of the model), no kink crossing, no evaluation budget"
+        elif solver != "library":
             sim.set_solver_options(cross_kinks=True, eval_budget=self.eval_budget)
             self.solver = "XML Newton loop (tol / max_iter / max_ls of the model) + kink crossing near convergence" + (
                 "" if not self.eval_budget else ", at most %d evaluations per sub-step (flagged in status beyond)" % self.eval_budget)
@@ -682,6 +685,10 @@ def run_leg(name, res, ctx):
             lib_ = sub_record("push", "f64", dev, steps=20, warm=5, solver="library")
             res["f64_library_default"] = {k: lib_[k] for k in ("value", "ms_per_step", "solver", "batch", "dtype", "nonconverged_envs", "nonconverged_substeps", "substeps_timed",
                                                                "idle_share", "residual_evals_per_substep_last_launch", "roofline")}
+            if args.dtype == "f32":      # ... and the fp32 headline WITHOUT the one solver option it uses that the reference does not have
+                bare_ = sub_record("push", "f32", dev, steps=20, warm=5, solver="bare", env_tables=False)
+                res["f32_bare_xml_loop"] = {k: bare_[k] for k in ("value", "ms_per_step", "solver", "batch", "dtype", "nonconverged_envs", "nonconverged_substeps", "substeps_timed",
+                                                                  "idle_share", "residual_evals_per_substep_last_launch", "roofline")}
         elif name == "env_tables":      # the headline workload with one parameter table per environment: must stay on compiled-in kernels (round 4: fell to the generic ones)
             res[name] = sub_record("push", args.dtype, dev, steps=20, warm=20, env_tables=True)
         elif name == "dclaw":
