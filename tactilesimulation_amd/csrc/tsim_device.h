@@ -27,6 +27,7 @@
 // Replaces the per-sub-step C++ of the reference's absent DiffRedMax behind `sim.forward()` /
 // `sim.backward_steps()` (envs/redmax_torch_functions.py:132,167).  Formulation: DESIGN.md §1.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "../../include/tsim_blob.h"
 
@@ -505,10 +506,17 @@ __device__ __forceinline__ void ts_own_stores_visible() {
 
 // LDS layout of a block: [model float tables: one copy, or one per slot when the environments have their own tables]
 // [slot 0 state][slot 1 state]...   (ts_lds_env_reals each)
-template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, bool stage_cpt, const R* Fenv = nullptr) {
+// An int of the model blob's header for the context: read from the blob, or — for a kernel instantiated for a compiled-in model (MS: tsim_static.h), whose
+// batch carries that model's ints (tsim_hip.hip blob_has_structure; the taxel layout excepted) — the compiled-in constant: the sizes, offsets and LDS array
+// offsets of the context then fold, and the scalar registers that held them are free (round 6).
+template <class MS> __device__ __forceinline__ int ts_ctx_int(const int* I, int idx) {
+  if constexpr (std::is_void<MS>::value) return I[idx]; else return MS::Iv(idx);
+}
+template <class R, class MS = void> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int* I, const R* F, R* lds, int nslot, int slot, int lane, int lpe, bool stage_cpt, const R* Fenv = nullptr) {
+#define TS_IV(idx) ts_ctx_int<MS>(I, idx)
   // Stage the model's tables in LDS — the float records (link / dof / motor / pair / sensor), the sweep schedule and the whole
   // int blob: later reads are ds_read broadcasts instead of ~500-cycle global loads (a lone wavefront cannot hide those).
-  const int nfrec = I[TSIM_IH_FOFF_CPT];
+  const int nfrec = TS_IV(TSIM_IH_FOFF_CPT);
   {
     R* mf = lds;
     R* cpt_l = lds + nfrec;                      // shared tables: the contact points follow the records, as in the blob
@@ -516,19 +524,19 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
       mf += slot * (nfrec + 2);
       for (int i = lane; i < nfrec; i += lpe) mf[i] = Fenv[i];
       cpt_l = lds + nslot * (nfrec + 2);         // ... and ONE copy of the (shared) contact-point arrays behind them
-      const int nc = ts_cpt_staged(I[TSIM_IH_NCPT], true, stage_cpt);
+      const int nc = ts_cpt_staged(TS_IV(TSIM_IH_NCPT), true, stage_cpt);
       for (int i = threadIdx.x; i < nc; i += TS_WAVE) cpt_l[i] = F[nfrec + i];
     } else {
-      const int nst = nfrec + ts_cpt_staged(I[TSIM_IH_NCPT], false, stage_cpt);   // tables (+ contact points)
+      const int nst = nfrec + ts_cpt_staged(TS_IV(TSIM_IH_NCPT), false, stage_cpt);   // tables (+ contact points)
       for (int i = threadIdx.x; i < nst; i += TS_WAVE) mf[i] = F[i];
     }
-    lds += ts_tab_reals(nfrec, I[TSIM_IH_NCPT], nslot, Fenv != nullptr, stage_cpt);
+    lds += ts_tab_reals(nfrec, TS_IV(TSIM_IH_NCPT), nslot, Fenv != nullptr, stage_cpt);
     {                                            // sweep schedule + the whole int blob (one copy per block)
       // The int tables are wave-uniform, but loads through a plain global pointer are not scalar loads here (the kernel
       // also writes global memory, so the compiler issues global_load_dword + s_waitcnt vmcnt(0) + v_readfirstlane): ~400
       // cycles of exposed latency each for a lone wavefront, a dozen times per evaluation.  From LDS they cost a ds_read.
-      const int* S = I + I[TSIM_IH_NI];
-      const int ns = S[0], ni = I[TSIM_IH_NI];
+      const int* S = I + TS_IV(TSIM_IH_NI);
+      const int ns = S[0], ni = TS_IV(TSIM_IH_NI);
       int* li = reinterpret_cast<int*>(lds);
       for (int i = threadIdx.x; i < ns; i += TS_WAVE) li[i] = S[i];
       for (int i = threadIdx.x; i < ni; i += TS_WAVE) li[ns + i] = I[i];
@@ -538,23 +546,25 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
     }
     TS_SYNC();
     c.Fg = F; c.F = mf;
-    c.cpt_lds = ts_u(ts_cpt_staged(I[TSIM_IH_NCPT], Fenv != nullptr, stage_cpt)) != 0;
-    c.CPT = F + I[TSIM_IH_FOFF_CPT];
+    c.cpt_lds = ts_u(ts_cpt_staged(TS_IV(TSIM_IH_NCPT), Fenv != nullptr, stage_cpt)) != 0;
+    c.CPT = F + TS_IV(TSIM_IH_FOFF_CPT);
     c.CPTl = (__attribute__((address_space(3))) const R*)(c.cpt_lds ? cpt_l : mf);
     F = mf;
   }
   c.stamps = nullptr; c.nstamp = 0; c.cull = 0;
-  c.nl = I[TSIM_IH_NL]; c.nr = I[TSIM_IH_NR]; c.nu = I[TSIM_IH_NU]; c.nvar = I[TSIM_IH_NVAR];
-  c.npair = I[TSIM_IH_NPAIR]; c.ncpt = I[TSIM_IH_NCPT]; c.nsensor = I[TSIM_IH_NSENSOR]; c.ntax = I[TSIM_IH_NTAXEL];
+  c.nl = TS_IV(TSIM_IH_NL); c.nr = TS_IV(TSIM_IH_NR); c.nu = TS_IV(TSIM_IH_NU); c.nvar = TS_IV(TSIM_IH_NVAR);
+  c.npair = TS_IV(TSIM_IH_NPAIR); c.ncpt = TS_IV(TSIM_IH_NCPT); c.nsensor = TS_IV(TSIM_IH_NSENSOR); c.ntax = I[TSIM_IH_NTAXEL];
   c.nd = c.nr;
-  c.off_link = I[TSIM_IH_OFF_LINK]; c.off_dof = I[TSIM_IH_OFF_DOF]; c.off_motor = I[TSIM_IH_OFF_MOTOR];
-  c.off_var = I[TSIM_IH_OFF_VAR]; c.off_pair = I[TSIM_IH_OFF_PAIR]; c.off_sensor = I[TSIM_IH_OFF_SENSOR];
-  c.off_sprim = I[TSIM_IH_OFF_SPRIM];
-  c.foff_link = I[TSIM_IH_FOFF_LINK]; c.foff_dof = I[TSIM_IH_FOFF_DOF]; c.foff_motor = I[TSIM_IH_FOFF_MOTOR];
-  c.foff_var = I[TSIM_IH_FOFF_VAR]; c.foff_pair = I[TSIM_IH_FOFF_PAIR]; c.foff_sensor = I[TSIM_IH_FOFF_SENSOR];
-  c.foff_cpt = I[TSIM_IH_FOFF_CPT]; c.foff_tax = I[TSIM_IH_FOFF_TAXEL];
+  c.off_link = TS_IV(TSIM_IH_OFF_LINK); c.off_dof = TS_IV(TSIM_IH_OFF_DOF); c.off_motor = TS_IV(TSIM_IH_OFF_MOTOR);
+  c.off_var = TS_IV(TSIM_IH_OFF_VAR); c.off_pair = TS_IV(TSIM_IH_OFF_PAIR); c.off_sensor = TS_IV(TSIM_IH_OFF_SENSOR);
+  c.off_sprim = TS_IV(TSIM_IH_OFF_SPRIM);
+  c.foff_link = TS_IV(TSIM_IH_FOFF_LINK); c.foff_dof = TS_IV(TSIM_IH_FOFF_DOF); c.foff_motor = TS_IV(TSIM_IH_FOFF_MOTOR);
+  c.foff_var = TS_IV(TSIM_IH_FOFF_VAR); c.foff_pair = TS_IV(TSIM_IH_FOFF_PAIR); c.foff_sensor = TS_IV(TSIM_IH_FOFF_SENSOR);
+  c.foff_cpt = TS_IV(TSIM_IH_FOFF_CPT); c.foff_tax = TS_IV(TSIM_IH_FOFF_TAXEL);
   c.h = F[TSIM_FH_H]; c.gx = F[TSIM_FH_GX]; c.gy = F[TSIM_FH_GY]; c.gz = F[TSIM_FH_GZ]; c.tol = F[TSIM_FH_TOL];
-  c.max_iter = I[TSIM_IH_MAX_ITER]; c.max_ls = I[TSIM_IH_MAX_LS];
+  // (the header FLOATS stay run-time reads also for a fully static model: folding them made the forward kernel 3 % slower — scheduling noise
+  // of a 50 KB straight-line loop, measured in round 6)
+  c.max_iter = TS_IV(TSIM_IH_MAX_ITER); c.max_ls = TS_IV(TSIM_IH_MAX_LS);
   c.cv = R(1) / c.h; c.ca = R(1) / (c.h * c.h);
   int nr = c.nr, nl = c.nl, nd = c.nd;
   R* p = lds + slot * ts_lds_env_reals(nl, nr, c.nu, (int)sizeof(R));
@@ -578,6 +588,7 @@ template <class R> __device__ __forceinline__ void ctx_init(Ctx<R>& c, const int
   c.expw = p; p += 54;
   c.scr = p;
 }
+#undef TS_IV
 
 // world link: identity pose, zero velocity, gravity as base acceleration, zero wrench; all tangents zero.
 template <class R> __device__ __forceinline__ void init_world(const Ctx<R>& c, int lane, int lpe) {

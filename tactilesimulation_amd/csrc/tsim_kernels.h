@@ -122,7 +122,10 @@ template <class R> struct FwdArgs {
 #ifdef TS_WAVES_PER_EU
 #define TS_KLB __launch_bounds__(TS_WAVE, TS_WAVES_PER_EU)
 #else
-#define TS_KLB __launch_bounds__(TS_WAVE)
+// One wavefront per SIMD is what these kernels run at (their LDS footprint allows four blocks per CU): say so, or a kernel that happens to fit 256 registers
+// is scheduled FOR two wavefronts per SIMD — shorter live ranges, less overlap of its own loads and arithmetic — which costs a lone wavefront
+// (round 6: the adjoint kernel with the model's sizes folded fits 220 registers and ran 18 % slower than the 280-register one until this attribute)
+#define TS_KLB __launch_bounds__(TS_WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #endif
 template <class R, int NRM, bool EXPJ, int LPE, bool POLICY = false, class MS = void>
 __global__ void TS_KLB k_forward(FwdArgs<R> a) {
@@ -139,7 +142,7 @@ __global__ void TS_KLB k_forward(FwdArgs<R> a) {
   const int eidx = blockIdx.x * NS + slot;
   const bool valid = eidx < a.B;                                        // a batch that is no multiple of NS: idle slot
   const int env = a.order ? a.order[min(eidx, a.B - 1)] : min(eidx, a.B - 1);
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  Ctx<R> c; ctx_init<R, MS>(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   c.cull = a.cull;
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   init_world(c, lane, LPE);
@@ -727,7 +730,9 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
   const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
   const bool valid = (int)blockIdx.x * NS + slot < a.B;
   const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  // (the context's sizes stay run-time values HERE: with them folded the adjoint kernel is 10 % shorter and 18 % SLOWER — 0.82 -> 0.96 ms per 20-step
+  // launch, round 6; the forward kernel gains 5 % from the same fold)
+  Ctx<R> c; ctx_init<R, MS>(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   c.cull = a.cull;
   const int nr = c.nr, nu = c.nu, REC = ts_rec(nr, nu, (int)sizeof(R));
   const int nvar3 = 3 * c.nvar, ntac3 = 3 * c.ntax;
@@ -786,6 +791,10 @@ __global__ void TS_KLB k_backward(BwdArgs<R> a) {
 #pragma unroll
       for (int i = 0; i < NHL; ++i) { const int e = lane + i * LPE; pH[i] = e < nr * nr ? r1[oH + e] : R(0); }
     }
+    // (the loads above must be ISSUED here, a whole sub-step ahead of their use: with the model's sizes as compile-time constants the scheduler
+    // otherwise sinks them to the top of the next iteration and a lone wavefront waits ~2 us of HBM latency per sub-step — measured in round 6:
+    // k_backward 0.82 -> 0.96 ms per 20-step launch with 10 % FEWER instructions)
+    __builtin_amdgcn_sched_barrier(0);
     TS_SYNC();
     TS_STAMP(c);
     // A statically known model (tsim_static_eval.h): the evaluation at the taped state is one register-resident pass AFTER the adjoint solve
@@ -972,7 +981,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_debug_eval(DbgArgs<R> a) {
   const int slot = threadIdx.x / LPE, lane = threadIdx.x % LPE;
   const bool valid = (int)blockIdx.x * NS + slot < a.B;
   const int env = min((int)blockIdx.x * NS + slot, a.B - 1);
-  Ctx<R> c; ctx_init(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
+  Ctx<R> c; ctx_init<R, MS>(c, a.I, a.F, lds, NS, slot, lane, LPE, a.stage_cpt != 0, a.Fenv ? a.Fenv + (size_t)env * a.fstride : nullptr);
   c.cull = a.cull;
   const int nr = c.nr, nu = c.nu;
   init_world(c, lane, LPE);
