@@ -428,7 +428,7 @@ struct tsim_batch {
   int value_first = 1;           // launches without a tape: the first trial after a Newton step evaluates the residual only where the previous sub-step converged in one step (tsim_set_option TSIM_OPT_VALUE_FIRST; TSIM_NO_VALUE_FIRST=1 at creation: off)
   // A/B switches of the environment, read ONCE at creation (launches are on the host-bound path of the per-step collectors):
   // TSIM_NO_EPISODE_LPT, TSIM_INKERNEL_READOUT, TSIM_NO_FREE_RUN, TSIM_LOCKSTEP, TSIM_TAXELS_PER_RECORD, TSIM_NO_ENVTAB_CPT
-  bool ab_no_episode_lpt = false, ab_inkernel_readout = false, ab_no_free_run = false, ab_lockstep = false, ab_taxels_per_record = false, ab_no_envtab_cpt = false, ab_no_default_opts = false;
+  bool ab_no_episode_lpt = false, ab_inkernel_readout = false, ab_no_free_run = false, ab_lockstep = false, ab_taxels_per_record = false, ab_no_envtab_cpt = false, ab_no_default_opts = false; int ab_bwd_lpe = 0;
   int pair_cull = 1;             // phase 2 skips contact pairs out of reach of their primitive (tsim_set_option TSIM_OPT_PAIR_CULL; TSIM_NO_PAIR_CULL=1 at creation: off)
   // Compiled-in models (csrc/tsim_static.h).  static_id: the model whose STRUCTURE the batch's blob has (ints + the structural floats: 1 TactilePush);
   // static_exact: every float record equals the compiled asset's bit for bit as well (the fully static instantiation); env_struct_ok: the
@@ -879,7 +879,13 @@ static int launch_backward(tsim_batch* b, int n, int seed_stride, int frames, co
   a.I = b->dI; a.F = (const R*)b->dF; a.Fenv = (const R*)b->dFenv; a.fstride = b->nfrec; a.B = b->B; a.n = n; a.t_end = b->t_cur; a.seed_stride = seed_stride; a.frames = frames; a.tac_slot = tac_slot;
   a.tape = (const R*)b->tape; a.df_dq = (const R*)df_dq; a.df_dvar = (const R*)df_dvar; a.df_dtac = (const R*)df_dtac;
   a.lamq = (R*)b->lamq; a.lamv = (R*)b->lamv; a.df_du = (R*)df_du; a.stage_cpt = b->stage_cpt; a.cyc = b->bwd_stamps; a.cull = b->pair_cull;
-  { KtScope kt_(b, TSIM_KT_BACKWARD, st); TS_LAUNCH(k_backward, R, b, st, a); }
+  {
+    KtScope kt_(b, TSIM_KT_BACKWARD, st);
+    const int keep_ = b->lpe_forced;
+    if (b->ab_bwd_lpe) b->lpe_forced = b->ab_bwd_lpe;      // A/B (TSIM_BWD_LPE at creation): another launch shape for the adjoint kernel (the tape does not depend on it)
+    TS_LAUNCH(k_backward, R, b, st, a);
+    b->lpe_forced = keep_;
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -922,6 +928,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->trial_helpers = getenv("TSIM_NO_TRIAL_HELPERS") ? 0 : 1;
   b->ab_no_episode_lpt = getenv("TSIM_NO_EPISODE_LPT") != nullptr; b->ab_inkernel_readout = getenv("TSIM_INKERNEL_READOUT") != nullptr;
   b->ab_no_free_run = getenv("TSIM_NO_FREE_RUN") != nullptr; b->ab_lockstep = getenv("TSIM_LOCKSTEP") != nullptr; b->ab_no_default_opts = getenv("TSIM_NO_DEFAULT_OPTS") != nullptr;
+  if (const char* e = getenv("TSIM_BWD_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->ab_bwd_lpe = v; }
   b->ab_taxels_per_record = getenv("TSIM_TAXELS_PER_RECORD") != nullptr; b->ab_no_envtab_cpt = getenv("TSIM_NO_ENVTAB_CPT") != nullptr;
   b->value_first = getenv("TSIM_NO_VALUE_FIRST") ? 0 : 1;
   if (const char* e = getenv("TSIM_VALUE_TRIALS")) b->value_trials = std::max(0, atoi(e));

@@ -722,8 +722,13 @@ __device__ __forceinline__ void output_vjp(const Ctx<R>& c, int lane, const R* w
   TS_SYNC();
 }
 
+#ifdef TS_BWD_TWO_WAVES      // A/B builds only: the adjoint kernel may share a SIMD with a second wavefront (two-environment wavefronts, TSIM_BWD_LPE=32)
+#define TS_KLB_BWD __launch_bounds__(TS_WAVE)
+#else
+#define TS_KLB_BWD TS_KLB
+#endif
 template <class R, int NRM, bool EXPJ, int LPE, bool POLICY = false, class MS = void>
-__global__ void TS_KLB k_backward(BwdArgs<R> a) {
+__global__ void TS_KLB_BWD k_backward(BwdArgs<R> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   R* lds = reinterpret_cast<R*>(smem_raw);
   constexpr int NS = TS_WAVE / LPE;

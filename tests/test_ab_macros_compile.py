@@ -20,6 +20,7 @@ SURVIVING = {                      # switch -> what it is for
     "TS_REAL_BARRIERS": "__syncthreads() instead of the compiler-only barrier",
     "TS_LIBM_SINCOS": "libm sincos instead of the kernels' own",
     "TS_BWD_REEVAL": "k_backward evaluates the Newton matrix of the taped point again instead of reading it from the tape: the cost of a tape without it (profiles/r06_tape_ab.md)",
+    "TS_BWD_TWO_WAVES": "the adjoint kernel without the one-wavefront-per-SIMD attribute (with TSIM_BWD_LPE=32: two two-environment wavefronts per SIMD; profiles/r06_static_kernel_levers.md)",
     "TS_ISA_MARKS": "every stamp site as a unique s_sleep marker in the ISA (static analysis)",
 }
 
@@ -36,7 +37,7 @@ def test_every_switch_in_the_sources_is_a_known_one():
     assert found == set(SURVIVING), (sorted(found - set(SURVIVING)), sorted(set(SURVIVING) - found))
 
 
-@pytest.mark.parametrize("defs", [["-DTS_FINE_STAMPS", "-DTS_SOLVE_PIVOT_ONLY", "-DTS_ROUND_STATS", "-DTS_PP_TIME", "-DTS_WAVES_PER_EU=1", "-DTS_REAL_BARRIERS", "-DTS_LIBM_SINCOS", "-DTS_BWD_REEVAL"],
+@pytest.mark.parametrize("defs", [["-DTS_FINE_STAMPS", "-DTS_SOLVE_PIVOT_ONLY", "-DTS_ROUND_STATS", "-DTS_PP_TIME", "-DTS_WAVES_PER_EU=1", "-DTS_REAL_BARRIERS", "-DTS_LIBM_SINCOS", "-DTS_BWD_REEVAL", "-DTS_BWD_TWO_WAVES"],
                                   ["-DTS_ISA_MARKS"]])
 def test_the_surviving_switches_compile(defs):
     if not os.path.exists(_hipcc()):
