@@ -225,6 +225,47 @@ def plumbing_only(args, world, rank):
         dist.destroy_process_group()
 
 
+IN_PROCESS_LEGS = ("step_mode", "pmc")      # step_mode uses the headline's own batch; pmc fills the headline's roofline (and is child processes itself)
+
+
+def leg_child(args):
+    """`bench.py --leg-child NAME` (started by the parent's run_leg_in_child): ONE optional leg in a process of its own; prints the records it produced."""
+    from tactilesimulation_amd.model.compiler import load_model
+    from tactilesimulation_amd import workloads as W
+    name = args.leg_child
+    asset_, B_def, T_def, fwd_only_def, _ = BL.WORKLOADS[args.workload]
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    forward_only = args.forward_only or fwd_only_def
+    S = 1 if args.workload == "insertion" else args.frame_skip
+    ctx = {"args": args, "B": args.batch or B_def, "T": args.episode or T_def, "S": S, "fps": BL.FRAMES_PER_ENV_STEP[args.workload], "dev": dev, "tdt": tdt,
+           "esz": 4 if args.dtype == "f32" else 8, "forward_only": forward_only, "model": load_model(W.asset(asset_)), "leg": None, "progress": progress}
+    if os.environ.get("TSIM_BENCH_CRASH_LEG") == name:      # tests/test_gpu_bench_line.py: a leg that dies the hard way (as a segmentation fault would)
+        os.abort()
+    out = {}
+    BL.run_leg(name, out, ctx)
+    print(json.dumps(out, default=lambda o: float(o) if hasattr(o, "__float__") else str(o)), flush=True)
+
+
+def run_leg_in_child(name, res, args, timeout_s):
+    """One optional leg in a child process (same command line + --leg-child NAME): its records are merged into `res`; a crash, a hang or garbage on its
+    stdout becomes an {"error": ...} record of that leg and nothing else."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--leg-child", name]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        res[name if name != "cpu" else "cpu_baseline"] = {"error": "leg ran into its %d s limit (child process killed)" % timeout_s}
+        return False
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        tail = (r.stderr or "").strip().splitlines()[-3:]
+        res[name if name != "cpu" else "cpu_baseline"] = {"error": "child process exited with %d: %s" % (r.returncode, " | ".join(tail)[-300:])}
+        return False
+    res.update(json.loads(lines[-1]))
+    return True
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,6 +296,9 @@ def parse_args(argv=None):
     ap.add_argument("--timed-only", action="store_true", help="skip every leg after the timed region: profiler runs (and the in-run --pmc passes)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL over xGMI, the real multi-GPU path) or gloo (plumbing test: with TSIM_BENCH_SHARE_GPU=1 all ranks share cuda:0)")
+    ap.add_argument("--leg-child", default=None, help=argparse.SUPPRESS)      # internal: run ONE optional leg in this (child) process and print its records as JSON
+    ap.add_argument("--legs-in-process", action="store_true", help="run the optional legs in this process (default: each in a child process, so that a leg that "
+                    "crashes or hangs — a segmentation fault inside a graph capture, say — cannot take the headline with it)")
     ap.add_argument("--plumbing-only", action="store_true", help="set up the ranks of --gpus N, run one all-reduce of the policy-gradient payload, print n_gpus and exit")
     args = ap.parse_args(argv)
     legs = [] if args.legs == "none" else (list(ALL_LEGS) if args.legs == "all" else [l for l in args.legs.split(",") if l])
@@ -284,6 +328,8 @@ def main():
         return
     if args.forward_only and args.workload != "push":
         fatal("--forward-only is a TactilePush option; dclaw / insertion are forward-only already")
+    if args.leg_child:
+        return leg_child(args)
 
     # ---- ranks: under a launcher WORLD_SIZE is set; a bare `python bench.py --gpus N` starts its own N ranks
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -470,8 +516,12 @@ def main():
                 leg = sim = run_steps = None
                 torch.cuda.empty_cache()
             try:
-                BL.run_leg(name, res, ctx)
-                res["legs"]["done"].append(name)
+                if name in IN_PROCESS_LEGS or args.legs_in_process:
+                    BL.run_leg(name, res, ctx)
+                    ok = True
+                else:                       # a process of its own: a crash or a hang there costs that leg only
+                    ok = run_leg_in_child(name, res, args, timeout_s=max(30.0, min(180.0, args.budget_s + 60.0 - (time.perf_counter() - _T0))))
+                res["legs"]["done"].append(name if ok else name + " (error)")
             except Exception as e:      # the headline must not die with an optional leg
                 res[name] = {"error": repr(e)}
                 res["legs"]["done"].append(name + " (error)")

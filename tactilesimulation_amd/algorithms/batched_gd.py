@@ -164,9 +164,29 @@ class CNNActor(torch.nn.Module):
         self.logstd = torch.nn.Parameter(torch.ones(action_dim) * cfg_network.get("actor_logstd_init", -1.0))
         self.to(dtype)
 
+    # as_gemm = True runs each convolution as im2col (F.unfold) + ONE matmul — the same numbers up to the summation order (tests/test_policy_and_utils.py:
+    # outputs and gradients 1e-12 in fp64 against torch's Conv2d), the same parameters.  OFF by default: it is correct eagerly and in small captured graphs
+    # (tests/test_gpu_batched_env.py), but capturing the B = 4096 x 100-step closed loop with it ends in a segmentation fault inside
+    # torch.cuda.CUDAGraph.capture_end on this stack (ROCm 7.0.2 runtime, torch 2.10; round 6) — the per-step graph is the only fast path for this policy.
+    as_gemm = False
+
+    def _body(self, x):
+        if not self.as_gemm:
+            return self.feature_net.body(x)
+        for m in self.feature_net.body:
+            if isinstance(m, torch.nn.Conv2d):
+                B, _, H, Wd = x.shape
+                k, st = m.kernel_size, m.stride
+                cols = torch.nn.functional.unfold(x, k, stride=st)                                   # [B, Cin k k, positions]
+                x = torch.matmul(m.weight.reshape(m.out_channels, -1), cols) + m.bias.reshape(1, -1, 1)
+                x = x.reshape(B, m.out_channels, (H - k[0]) // st[0] + 1, (Wd - k[1]) // st[1] + 1)
+            else:
+                x = m(x)
+        return x
+
     def forward(self, obs):
         img, state = (obs if isinstance(obs, (tuple, list)) else (obs, None))
-        f = self.feature_net.body(img.contiguous())
+        f = self._body(img.contiguous())
         if self.state_dim:
             f = torch.cat([f, state], dim=1)
         return self.mean_net(f)
