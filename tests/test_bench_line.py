@@ -101,5 +101,5 @@ def test_legs_argument():
     a = bench.parse_args(["--legs", "pmc,cpu"])
     assert a.leg_list == ["pmc", "cpu"]
     a = bench.parse_args(["--no-pmc", "--no-sub-records"])
-    assert a.leg_list == ["step_mode", "closed_loop", "readout", "cpu"]
+    assert a.leg_list == ["step_mode", "cpu", "closed_loop", "readout"]
     assert bench.parse_args(["--legs", "none"]).leg_list == []

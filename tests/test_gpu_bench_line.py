@@ -30,7 +30,7 @@ def test_line_with_legs_in_child_processes_and_a_crashing_leg():
     rl = j["roofline"]
     assert rl["bound"] == "hbm" and rl["kernel"] == "k_forward" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-6
     assert set(rl["per_kernel"]) == {"k_forward", "k_taxels", "k_backward"} and all(v["ms"] > 0 for v in rl["per_kernel"].values())
-    assert rl["per_kernel"]["k_forward"]["algorithmic_bytes"] == 356 * 512 * 6            # its OWN bytes: u in, q / variables out, tape q / qd
+    assert abs(rl["per_kernel"]["k_forward"]["algorithmic_bytes"] - 356 * 512 * 6) < 1e-4 * 356 * 512 * 6      # its OWN bytes: u in, q / variables out, tape q / qd (the line rounds to 5 digits)
     assert "error" in j["sub"]["push_fwd"] and "push_fwd (error)" in j["legs"]["errors"]     # the leg that aborted ...
     assert j["sub"]["readout"]["GBps"] > 0 and j["launch"]["other_mode_value"] > 0          # ... cost nothing else
     assert os.path.exists(os.path.join(ROOT, "bench_detail.json"))
