@@ -15,8 +15,9 @@ Output: ONE compact JSON line on stdout (rank 0; < 6 KB, tests/test_bench_line.p
 charged ITS OWN algorithmic bytes, timed by HIP events the library records on the launching stream around that kernel alone; per-kernel table
 for k_forward / k_taxels / k_backward; `traffic` from in-run rocprofv3 --pmc passes), `cpu_baseline`, and a one-line summary of each optional
 leg.  Everything else (counter dumps, per-window lists, launch shapes, full sub-records) goes to bench_detail.json next to this file and to
-stderr.  The headline is measured FIRST; optional legs (bench_legs.py, chosen with --legs) run after it inside a wall-clock budget, and a
-watchdog prints the line with whatever is finished if a leg overruns — an optional leg can no longer cost the headline.
+stderr.  The headline is measured FIRST; the optional legs (bench_legs.py, chosen with --legs) run after it inside a wall-clock budget, each in a
+child process of its own (the contract's other fields first: the PMC passes, the CPU baseline), and a watchdog prints the line with whatever is finished
+if one overruns — a leg that crashes or hangs costs that leg only.
 """
 import argparse
 import json
