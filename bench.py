@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 import bench_legs as BL      # noqa: E402  (optional legs + shared helpers; imports nothing of the simulator at module level)
 from bench_legs import WORKLOADS, make_workload, sub_record, readout_leg, Leg, kernel_record      # noqa: E402,F401  (tools/*.py use them through this module)
 
-ALL_LEGS = ["step_mode", "pmc", "cpu", "env_tables", "f64", "push_fwd", "dclaw", "insertion", "closed_loop", "readout"]      # (the contract's fields first: roofline.traffic, cpu_baseline)
+ALL_LEGS = ["step_mode", "cpu", "pmc", "env_tables", "f64", "push_fwd", "dclaw", "insertion", "closed_loop", "readout"]      # (the contract's fields first: roofline.traffic, cpu_baseline)
 LINE_LIMIT = 6144            # bytes of the final stdout line (the driver keeps an 8.5 KB tail)
 
 _T0 = time.perf_counter()

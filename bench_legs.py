@@ -282,7 +282,7 @@ def pmc_passes(args, B, T, kernels=KERNELS):
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, BENCH,
                    "--steps", str(args.steps), "--warmup", str(args.steps), "--batch", str(B), "--dtype", args.dtype, "--workload", args.workload,
                    "--episode", str(T), "--frame-skip", str(args.frame_skip), "--launch", args.launch, "--timed-only", "--repeats", "1"] + (["--forward-only"] if args.forward_only else [])
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=60, check=True)      # (a pass takes ~3 s)
             per = {k: {} for k in kernels}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):

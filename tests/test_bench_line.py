@@ -99,7 +99,7 @@ def test_kernel_bytes_split_adds_up_to_the_survey_table():
 def test_legs_argument():
     import bench
     a = bench.parse_args(["--legs", "pmc,cpu"])
-    assert a.leg_list == ["pmc", "cpu"]
+    assert a.leg_list == ["pmc", "cpu"]      # (the order given)
     a = bench.parse_args(["--no-pmc", "--no-sub-records"])
     assert a.leg_list == ["step_mode", "cpu", "closed_loop", "readout"]
     assert bench.parse_args(["--legs", "none"]).leg_list == []
