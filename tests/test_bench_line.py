@@ -103,3 +103,23 @@ def test_legs_argument():
     a = bench.parse_args(["--no-pmc", "--no-sub-records"])
     assert a.leg_list == ["step_mode", "cpu", "closed_loop", "readout"]
     assert bench.parse_args(["--legs", "none"]).leg_list == []
+
+
+def test_a_leg_that_dies_in_its_child_process_becomes_an_error_record(monkeypatch):
+    """bench.run_leg_in_child: a crash (non-zero exit, nothing on stdout), a hang (timeout) and a normal end of the child process."""
+    import subprocess
+    import types
+    import bench
+    args = types.SimpleNamespace()
+    res = {}
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=-11, stdout="", stderr="Fatal Python error: Segmentation fault\n"))
+    assert bench.run_leg_in_child("closed_loop", res, args, 30) is False and "Segmentation fault" in res["closed_loop"]["error"] and "-11" in res["closed_loop"]["error"]
+
+    def hang(*a, **k):
+        raise subprocess.TimeoutExpired(cmd="bench.py", timeout=k.get("timeout"))
+    monkeypatch.setattr(subprocess, "run", hang)
+    assert bench.run_leg_in_child("cpu", res, args, 30) is False and "limit" in res["cpu_baseline"]["error"]
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout='noise\n{"f64": {"value": 1.0}, "f64_library_default": {"value": 2.0}}\n', stderr=""))
+    assert bench.run_leg_in_child("f64", res, args, 30) is True and res["f64"]["value"] == 1.0 and res["f64_library_default"]["value"] == 2.0
+    line = json.loads(bench.compact_line(dict(_canned(), **res, legs={"asked": [], "done": ["closed_loop (error)", "f64"], "skipped": ["readout"]})))
+    assert line["legs"]["errors"] == ["closed_loop (error)"] and line["legs"]["skipped"] == ["readout"] and "error" in line["sub"]["closed_loop"]
