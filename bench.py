@@ -178,11 +178,23 @@ class Emitter:
         self.detail_path = os.path.join(ROOT, "bench_detail.json")
 
     def emit(self, why=None):
+        import copy
         with self.lock:
             if self.done or self.res is None:
                 return
             self.done = True
-            res = self.res
+            # The watchdog calls this from its own thread while the main thread may be inside a leg that is adding records to the same dict: work on a
+            # snapshot (a few attempts: a copy can meet a dict that changes size under it), and whatever happens, print A line
+            res = None
+            for _ in range(5):
+                try:
+                    res = copy.deepcopy(self.res)
+                    break
+                except RuntimeError:
+                    time.sleep(0.05)
+            if res is None:
+                res = {k: self.res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                                                    "data", "config", "roofline", "cpu_baseline", "repeats", "kernel")}
             if why:
                 res.setdefault("legs", {})["watchdog"] = why
             res["detail_file"] = os.path.basename(self.detail_path)
@@ -191,7 +203,12 @@ class Emitter:
                     json.dump(res, fh, indent=1, default=lambda o: float(o) if hasattr(o, "__float__") else str(o))
             except Exception as e:      # a read-only checkout must not cost the line
                 res["detail_file"] = "not written: %r" % (e,)
-            print(compact_line(res), flush=True)
+            try:
+                line = compact_line(res)
+            except Exception as e:      # ... nor may a malformed optional record
+                line = compact_line({k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                                               "dtype", "data", "config", "roofline", "cpu_baseline", "repeats", "kernel")} | {"legs": {"watchdog": "line rebuilt without the optional records: %r" % (e,)}})
+            print(line, flush=True)
 
 
 def self_launch(args):
