@@ -97,7 +97,8 @@ def _sub_summary(rec):
             out["valu_frac"] = rl["valu"].get("frac")
             out["lanes"] = rl["valu"].get("active_lane_frac")
     for k_in, k_out in (("nonconverged_envs", "nonconv_envs"), ("batch", "B"), ("dtype", "dtype"), ("idle_share", "idle_share"), ("achieved", "GBps"),
-                        ("s_per_epoch", "s_per_epoch"), ("value_budgeted", "value_budgeted"), ("flagged_frac_budgeted", "flagged_frac_budgeted")):
+                        ("s_per_epoch", "s_per_epoch"), ("value_budgeted", "value_budgeted"), ("flagged_frac_budgeted", "flagged_frac_budgeted"),
+                        ("value_whole_config", "value_whole_config")):
         if rec.get(k_in) is not None:
             out[k_out] = rec[k_in]
     return out

@@ -48,6 +48,8 @@ WORKLOADS = {
 # TactileInsertion's episode is 45 frames of ONE sub-step (envs/tactile_insertion_env.py:53,359: frame_skip 1, a new joint target every
 # sub-step); to keep the unit of the metric (one env-step = 5 sub-steps) 5 of its frames count as one env-step
 FRAMES_PER_ENV_STEP = {"push": 1, "push_fwd": 1, "dclaw": 1, "insertion": 5}
+# BASELINE.json configs[3] / configs[4] are 8-GPU jobs (16 384 / 32 768 environments): the same jobs on ONE GPU, next to their per-GPU shares
+WHOLE_CONFIG_BATCH = {"dclaw": 16384, "insertion": 32768}
 
 
 def kernel_bytes(nr, nu, nvar, ntac, S, esz, tape=True, tac_frac=1.0, inkernel_readout=False):
@@ -353,10 +355,11 @@ def fill_roofline_counters(rl, pmc, src, B):
 
 
 # ---------------------------------------------------------------------------------------------------- sub-records
-def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench", pmc=False, env_tables=False, eval_budget=None):
+def sub_record(name, dtype, dev, steps=None, warm=None, solver="bench", pmc=False, env_tables=False, eval_budget=None, batch=None):
     """A short N = 1 leg of another BASELINE config (or of the headline workload in another dtype): value, per-kernel roofline.  `steps` in
-    env-steps (5 sub-steps)."""
+    env-steps (5 sub-steps).  batch: another number of environments on this GPU than the config's per-GPU share."""
     asset_, B, T, fwd_only, cfg = WORKLOADS[name]
+    B = batch or B
     tdt = torch.float32 if dtype == "f32" else torch.float64
     esz = 4 if dtype == "f32" else 8
     if name == "push" and env_tables:      # the HEADLINE's inputs (the first 20 env-steps of its 100-step table): this record is read against the headline
@@ -701,6 +704,14 @@ def run_leg(name, res, ctx):
                                      "substeps_timed": b_["substeps_timed"], "idle_share": b_["idle_share"], "kernel_ms": b_["roofline"]["kernel_ms"]}
         else:
             res[name] = sub_record(name, args.dtype, dev, pmc=pmc_on and name == "insertion")
+        if name in WHOLE_CONFIG_BATCH and "value" in res.get(name, {}):
+            # the BASELINE config's WHOLE batch on this one GPU (its 8-GPU job in 288 GB): a launch lasts its slowest environment's chain whatever
+            # the batch is, so the larger batch amortises that chain over more wavefronts taken in turn by each SIMD
+            w_ = sub_record(name, args.dtype, dev, batch=WHOLE_CONFIG_BATCH[name])
+            res[name]["value_whole_config"] = w_["value"]
+            res[name]["whole_config_on_one_gpu"] = {"batch": w_["batch"], "value": w_["value"], "ms_per_step": w_["ms_per_step"], "nonconverged_envs": w_["nonconverged_envs"],
+                                                    "nonconverged_substeps": w_["nonconverged_substeps"], "substeps_timed": w_["substeps_timed"], "idle_share": w_["idle_share"],
+                                                    "kernel_ms": w_["roofline"]["kernel_ms"], "launch_shape": w_["launch_shape"]}
     elif name == "closed_loop":
         if not push or ctx["forward_only"]:
             res[name] = {"skipped": "closed loop belongs to the push fwd+adjoint headline"}

@@ -30,7 +30,7 @@ def _canned():
     sub = {"workload": "w" * 400, "model": "dclaw_position_control", "batch": 2048, "dtype": "f32", "value": 2921234.5678, "unit": "env-steps/s", "solver": "s" * 200, "what": "z" * 200,
            "steps": 100, "ms_per_step": 0.7012345, "nonconverged_envs": 3, "nonconverged_substeps": 421, "substeps_timed": 1024000, "idle_share": 0.7312345,
            "residual_evals_per_substep_last_launch": {"mean": 2.5, "max_env_total": 2310, "mean_env_total": 626.1}, "launch_shape": {"lds_bytes": 1, "threads": 64, "blocks": 1024, "lanes_per_env": 32},
-           "kernel": kern, "roofline": dict(rl, instantiation="k_forward<float, NRM=16, EXPJ=false, LPE=32, POLICY=false, void>"), "value_budgeted": 5123456.7, "flagged_frac_budgeted": 0.0123456}
+           "kernel": kern, "roofline": dict(rl, instantiation="k_forward<float, NRM=16, EXPJ=false, LPE=32, POLICY=false, void>"), "value_budgeted": 5123456.7, "flagged_frac_budgeted": 0.0123456, "value_whole_config": 4101234.567}
     res = {"metric": "env-steps/sec (fwd+bwd) TactilePush batch=4096", "value": 20861234.5678, "unit": "env-steps/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.19641234,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "TactilePush (pusher.xml, 13x10 taxels, ndof_r 7) gd_tactile fwd+adjoint, frame_skip 5, batch 4096 envs/GPU; a timed window = 20 env-steps as episodes of 20 "
