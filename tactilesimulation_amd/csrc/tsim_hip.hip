@@ -384,6 +384,7 @@ __global__ void __launch_bounds__(TS_WAVE) k_signature(SigArgs<R> a) {
 // ================================================================================================ host side
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
+int tsim_fail_(const std::string& m) { return fail(m); }      // for the library's other translation units (tsim_model.cpp)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 // Every entry point runs on the batch's device and leaves the calling thread's current device as it found it (a process

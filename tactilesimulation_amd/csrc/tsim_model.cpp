@@ -1,0 +1,975 @@
+// tsim_model.cpp — include/tsim_model.h: redmax XML (+ OBJ / contact-point / taxel files) -> description -> flat blob (include/tsim_blob.h).
+// Host code only.  The native counterpart of tactilesimulation_amd/model/compiler.py + geometry.py: same description, same modelling
+// choices (the [CHOICE]s of DESIGN.md §Model), same record order; tests/test_native_model_loader.py holds the two against each other on
+// every model of the reference and on synthetic ones.  What the reference does with a model file is inside its absent DiffRedMax
+// dependency (call site: envs/redmax_torch_env.py:33); the XML vocabulary is the one its asset files use
+// (envs/assets/*/*.xml, assets/tactile_pad/tactile_pad.xml).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tsim_blob.h"
+#include "../../include/tsim_model.h"
+
+int tsim_fail_(const std::string& m);      // tsim_hip.hip: sets what tsim_last_error() returns, returns 1
+
+namespace {
+
+struct Err : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// ----------------------------------------------------------------------------------------------------------------- XML (the subset the assets use)
+struct XNode {
+  std::string tag;
+  std::vector<std::pair<std::string, std::string>> attrs;
+  std::vector<std::unique_ptr<XNode>> kids;
+  const char* get(const char* k) const {
+    for (auto& a : attrs) if (a.first == k) return a.second.c_str();
+    return nullptr;
+  }
+  const XNode* find(const char* t) const {
+    for (auto& c : kids) if (c->tag == t) return c.get();
+    return nullptr;
+  }
+};
+
+struct XParser {
+  const std::string& s; size_t i = 0;
+  explicit XParser(const std::string& s_) : s(s_) {}
+  [[noreturn]] void bad(const char* what) const { throw Err(std::string("XML: ") + what + " at byte " + std::to_string(i)); }
+  void ws() { while (i < s.size() && std::isspace((unsigned char)s[i])) ++i; }
+  bool starts(const char* t) const { return s.compare(i, std::strlen(t), t) == 0; }
+  void skip_to(const char* t) { const size_t j = s.find(t, i); if (j == std::string::npos) bad("unterminated construct"); i = j + std::strlen(t); }
+  void misc() {      // white space, comments, processing instructions, DOCTYPE
+    for (;;) {
+      ws();
+      if (starts("<!--")) skip_to("-->");
+      else if (starts("<?")) skip_to("?>");
+      else if (starts("<!")) skip_to(">");
+      else return;
+    }
+  }
+  std::string name() {
+    const size_t a = i;
+    while (i < s.size() && (std::isalnum((unsigned char)s[i]) || s[i] == '_' || s[i] == '-' || s[i] == ':' || s[i] == '.')) ++i;
+    if (i == a) bad("name expected");
+    return s.substr(a, i - a);
+  }
+  static std::string unescape(const std::string& v) {
+    if (v.find('&') == std::string::npos) return v;
+    std::string o;
+    for (size_t k = 0; k < v.size(); ++k) {
+      if (v[k] != '&') { o += v[k]; continue; }
+      static const char* ent[5][2] = {{"&lt;", "<"}, {"&gt;", ">"}, {"&amp;", "&"}, {"&quot;", "\""}, {"&apos;", "'"}};
+      bool hit = false;
+      for (auto& e : ent) if (v.compare(k, std::strlen(e[0]), e[0]) == 0) { o += e[1]; k += std::strlen(e[0]) - 1; hit = true; break; }
+      if (!hit) o += v[k];
+    }
+    return o;
+  }
+  std::unique_ptr<XNode> element() {
+    if (i >= s.size() || s[i] != '<') bad("'<' expected");
+    ++i;
+    auto n = std::make_unique<XNode>();
+    n->tag = name();
+    for (;;) {
+      ws();
+      if (i >= s.size()) bad("unterminated tag");
+      if (s[i] == '/') { if (i + 1 >= s.size() || s[i + 1] != '>') bad("'/>' expected"); i += 2; return n; }
+      if (s[i] == '>') { ++i; break; }
+      std::string k = name();
+      ws();
+      if (i >= s.size() || s[i] != '=') bad("'=' expected");
+      ++i; ws();
+      if (i >= s.size() || (s[i] != '"' && s[i] != '\'')) bad("quoted attribute value expected");
+      const char q = s[i++];
+      const size_t e = s.find(q, i);
+      if (e == std::string::npos) bad("unterminated attribute value");
+      n->attrs.emplace_back(std::move(k), unescape(s.substr(i, e - i)));
+      i = e + 1;
+    }
+    for (;;) {      // content: child elements; text is ignored (the format carries everything in attributes)
+      const size_t lt = s.find('<', i);
+      if (lt == std::string::npos) bad("unterminated element");
+      i = lt;
+      if (starts("<!--")) { skip_to("-->"); continue; }
+      if (starts("<![CDATA[")) { skip_to("]]>"); continue; }
+      if (starts("<?")) { skip_to("?>"); continue; }
+      if (starts("</")) {
+        i += 2;
+        if (name() != n->tag) bad("mismatched closing tag");
+        ws();
+        if (i >= s.size() || s[i] != '>') bad("'>' expected");
+        ++i;
+        return n;
+      }
+      n->kids.push_back(element());
+    }
+  }
+  std::unique_ptr<XNode> document() {
+    if (s.compare(0, 3, "\xEF\xBB\xBF") == 0) i = 3;
+    misc();
+    auto r = element();
+    return r;
+  }
+};
+
+std::string read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw Err("cannot open " + path);
+  std::ostringstream ss; ss << f.rdbuf();
+  return ss.str();
+}
+std::string dir_of(const std::string& path) {
+  const size_t k = path.find_last_of('/');
+  return k == std::string::npos ? std::string(".") : path.substr(0, k);
+}
+
+// ----------------------------------------------------------------------------------------------------------------- numbers
+std::vector<std::string> tokens(const std::string& s, bool commas) {
+  std::vector<std::string> out; std::string cur;
+  for (char c : s) {
+    if (std::isspace((unsigned char)c) || (commas && c == ',')) { if (!cur.empty()) { out.push_back(cur); cur.clear(); } }
+    else cur += c;
+  }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+double to_double(const std::string& t) {
+  char* e = nullptr;
+  const double v = std::strtod(t.c_str(), &e);
+  if (e == t.c_str() || *e) throw Err("not a number: '" + t + "'");
+  return v;
+}
+int to_int(const std::string& t) {
+  char* e = nullptr;
+  const long v = std::strtol(t.c_str(), &e, 10);
+  if (e == t.c_str() || *e) throw Err("not an integer: '" + t + "'");
+  return (int)v;
+}
+std::vector<double> floats(const char* s, int n = -1) {
+  if (!s) throw Err("missing numeric attribute");
+  std::vector<double> v;
+  for (auto& t : tokens(s, true)) v.push_back(to_double(t));
+  if (n >= 0 && (int)v.size() != n) throw Err("expected " + std::to_string(n) + " numbers, got '" + s + "'");
+  return v;
+}
+std::vector<double> floats_or(const XNode* e, const char* k, const char* dflt, int n) { const char* v = e->get(k); return floats(v ? v : dflt, n); }
+double attr_d(const XNode* e, const char* k, double dflt) {
+  const char* v = e->get(k);
+  if (!v) return dflt;
+  const auto t = tokens(v, false);      // (surrounding white space is not part of the number)
+  if (t.size() != 1) throw Err(std::string("attribute ") + k + ": one number expected, got '" + v + "'");
+  return to_double(t[0]);
+}
+std::string attr_s(const XNode* e, const char* k, const char* dflt = "") { const char* v = e->get(k); return v ? v : dflt; }
+
+// ----------------------------------------------------------------------------------------------------------------- SE(3), mass properties
+struct V3 { double v[3] = {0, 0, 0}; double& operator[](int k) { return v[k]; } double operator[](int k) const { return v[k]; } };
+struct M3 { double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; double& operator()(int r, int c) { return m[3 * r + c]; } double operator()(int r, int c) const { return m[3 * r + c]; } };
+V3 v3(const std::vector<double>& a) { V3 o; for (int k = 0; k < 3; ++k) o[k] = a[k]; return o; }
+V3 v3(double x, double y, double z) { V3 o; o[0] = x; o[1] = y; o[2] = z; return o; }
+double dot(const V3& a, const V3& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+V3 cross(const V3& a, const V3& b) { return v3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]); }
+double norm(const V3& a) { return std::sqrt(dot(a, a)); }
+V3 scaled(const V3& a, double s) { return v3(a[0] * s, a[1] * s, a[2] * s); }
+V3 unit(const V3& a) { const double n = norm(a); return v3(a[0] / n, a[1] / n, a[2] / n); }
+V3 add(const V3& a, const V3& b) { return v3(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
+V3 sub(const V3& a, const V3& b) { return v3(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+M3 zero3() { M3 z; for (double& x : z.m) x = 0; return z; }
+M3 mul(const M3& A, const M3& B) {
+  M3 C = zero3();
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double s = 0; for (int k = 0; k < 3; ++k) s += A(r, k) * B(k, c); C(r, c) = s; }
+  return C;
+}
+M3 transpose(const M3& A) { M3 T; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T(r, c) = A(c, r); return T; }
+// (sums start from +0 as in mul(M3, M3): a row of exact zeros times a negative component gives +0, not -0)
+V3 mul(const M3& A, const V3& x) { V3 o; for (int r = 0; r < 3; ++r) o[r] = 0.0 + A(r, 0) * x[0] + A(r, 1) * x[1] + A(r, 2) * x[2]; return o; }
+
+// (w, x, y, z), normalised first: the XMLs carry 3-digit values such as 0.707
+M3 quat_to_R(const double* q4) {
+  const double n = std::sqrt(q4[0] * q4[0] + q4[1] * q4[1] + q4[2] * q4[2] + q4[3] * q4[3]);
+  const double w = q4[0] / n, x = q4[1] / n, y = q4[2] / n, z = q4[3] / n;
+  M3 R;
+  R(0, 0) = 1 - 2 * (y * y + z * z); R(0, 1) = 2 * (x * y - z * w);     R(0, 2) = 2 * (x * z + y * w);
+  R(1, 0) = 2 * (x * y + z * w);     R(1, 1) = 1 - 2 * (x * x + z * z); R(1, 2) = 2 * (y * z - x * w);
+  R(2, 0) = 2 * (x * z - y * w);     R(2, 1) = 2 * (y * z + x * w);     R(2, 2) = 1 - 2 * (x * x + y * y);
+  return R;
+}
+struct Pose {      // x_parent = R x_child + p
+  M3 R; V3 p;
+  Pose operator*(const Pose& o) const { Pose r; r.R = mul(R, o.R); r.p = add(mul(R, o.p), p); return r; }
+  Pose inv() const { Pose r; r.R = transpose(R); const V3 t = mul(r.R, p); r.p = v3(-t[0], -t[1], -t[2]); return r; }
+  V3 apply(const V3& x) const { return add(mul(R, x), p); }
+  V3 rotate(const V3& x) const { return mul(R, x); }
+};
+Pose pose_of(const V3& pos, const double* quat) { Pose T; T.R = quat_to_R(quat); T.p = pos; return T; }
+
+struct MassProps {      // mass, centre of mass, rotational inertia about it — one frame
+  double m = 0; V3 c; M3 Ic = zero3();
+  MassProps transformed(const Pose& T) const { MassProps o; o.m = m; o.c = T.apply(c); o.Ic = mul(mul(T.R, Ic), transpose(T.R)); return o; }
+  MassProps scaled_by(double s) const { MassProps o = *this; o.m = m * s; for (double& x : o.Ic.m) x *= s; return o; }
+};
+M3 shifted(const MassProps& mp, const V3& c) {      // inertia of mp about the point c
+  const V3 d = sub(mp.c, c);
+  const double dd = dot(d, d);
+  M3 o = mp.Ic;
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) o(r, k) += mp.m * ((r == k ? dd : 0.0) - d[r] * d[k]);
+  return o;
+}
+MassProps operator+(const MassProps& a, const MassProps& b) {
+  MassProps o;
+  o.m = a.m + b.m;
+  if (o.m == 0.0) return MassProps();
+  for (int k = 0; k < 3; ++k) o.c[k] = (a.m * a.c[k] + b.m * b.c[k]) / o.m;
+  const M3 A = shifted(a, o.c), B = shifted(b, o.c);
+  for (int k = 0; k < 9; ++k) o.Ic.m[k] = A.m[k] + B.m[k];
+  return o;
+}
+M3 diag(double a, double b, double c) { M3 D = zero3(); D(0, 0) = a; D(1, 1) = b; D(2, 2) = c; return D; }
+const double kPi = 3.14159265358979323846;
+
+// Unit-density mass properties of a closed triangle mesh: signed tetrahedra against the origin (divergence theorem)
+MassProps mesh_props(const std::vector<V3>& V, const std::vector<int>& Fc) {
+  double det_sum = 0; V3 cs; M3 S = zero3();
+  const size_t nf = Fc.size() / 3;
+  for (size_t f = 0; f < nf; ++f) {
+    const V3 &a = V[Fc[3 * f]], &b = V[Fc[3 * f + 1]], &c = V[Fc[3 * f + 2]];
+    const double det = dot(a, cross(b, c));      // 6 x signed tetrahedron volume
+    det_sum += det;
+    for (int k = 0; k < 3; ++k) cs[k] += (a[k] + b[k] + c[k]) * det;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+      S(i, j) += det * (2.0 * (a[i] * a[j] + b[i] * b[j] + c[i] * c[j]) + a[i] * b[j] + b[i] * a[j] + a[i] * c[j] + c[i] * a[j] + b[i] * c[j] + c[i] * b[j]);
+  }
+  double vol = det_sum / 6.0;
+  if (vol == 0.0) throw Err("mesh has zero volume");
+  MassProps o;
+  for (int k = 0; k < 3; ++k) o.c[k] = cs[k] / (24.0 * vol);
+  for (double& x : S.m) x /= 120.0;
+  const double tr = S(0, 0) + S(1, 1) + S(2, 2), cc = dot(o.c, o.c);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j)
+    o.Ic(i, j) = ((i == j ? tr : 0.0) - S(i, j)) - vol * ((i == j ? cc : 0.0) - o.c[i] * o.c[j]);
+  if (vol < 0) { vol = -vol; for (double& x : o.Ic.m) x = -x; }      // inward-facing winding
+  o.m = vol;
+  return o;
+}
+void load_obj(const std::string& path, std::vector<V3>& V, std::vector<int>& Fc) {      // vertices + fan-triangulated faces
+  std::ifstream f(path);
+  if (!f) throw Err("cannot open mesh " + path);
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.compare(0, 2, "v ") == 0) {
+      auto t = tokens(line, false);
+      if (t.size() < 4) throw Err("bad vertex line in " + path);
+      V.push_back(v3(to_double(t[1]), to_double(t[2]), to_double(t[3])));
+    } else if (line.compare(0, 2, "f ") == 0) {
+      auto t = tokens(line, false);
+      std::vector<int> idx;
+      for (size_t k = 1; k < t.size(); ++k) {
+        const int i = to_int(t[k].substr(0, t[k].find('/')));
+        idx.push_back(i > 0 ? i - 1 : (int)V.size() + i);
+      }
+      for (size_t k = 1; k + 1 < idx.size(); ++k) { Fc.push_back(idx[0]); Fc.push_back(idx[k]); Fc.push_back(idx[k + 1]); }
+    }
+  }
+  for (int i : Fc) if (i < 0 || i >= (int)V.size()) throw Err("face index out of range in " + path);
+}
+std::vector<V3> read_points(const std::string& path) {      // count, then x y z per line
+  std::ifstream f(path);
+  if (!f) throw Err("cannot open " + path);
+  std::string line;
+  std::getline(f, line);
+  auto h = tokens(line, false);
+  if (h.empty()) throw Err("bad point file " + path);
+  const int n = to_int(h[0]);
+  std::vector<V3> out;
+  for (int k = 0; k < n; ++k) {
+    if (!std::getline(f, line)) throw Err("point file too short: " + path);
+    auto t = tokens(line, false);
+    if (t.size() < 3) throw Err("bad point line in " + path);
+    out.push_back(v3(to_double(t[0]), to_double(t[1]), to_double(t[2])));
+  }
+  return out;
+}
+
+// ----------------------------------------------------------------------------------------------------------------- description
+struct Taxel { V3 pos, normal, axis0, axis1; int img[2]; };
+struct Body {
+  std::string name, type;
+  V3 pos; double quat[4] = {1, 0, 0, 0};
+  double density = 1.0;      // [CHOICE] bodies that state no density (pusher.xml:24,27)
+  V3 size; int cres[3] = {2, 2, 2};
+  double radius = 0, length = 0; int cyl_res[2] = {8, 2};
+  MassProps mesh_unit;      // mesh: unit density, joint frame
+  double mass = 0; V3 inertia;
+  bool has_contacts = false; std::vector<V3> contacts;      // abstract: joint frame
+};
+struct Joint {
+  std::string name, type; int parent = -1;
+  V3 pos; double quat[4] = {1, 0, 0, 0};
+  double damping = 0, lim_stiffness = 0; bool has_lim = false; double lim[2] = {0, 0};
+  std::vector<V3> axes;
+  Body body;
+};
+struct Contact { bool ground = false; std::string a, b; double k[4]; };      // ground: a = body; else a = general body, b = primitive body
+struct Motor { std::string joint; int ctrl = 0; double range[2] = {-1, 1}, P = 0, D = 0; };
+struct Sensor {
+  std::string body, name, type; double k[4];
+  V3 rect_pos0, rect_pos1, axis0, axis1; int res[2] = {0, 0};
+  V3 pos; double quat[4] = {1, 0, 0, 0}; std::vector<Taxel> taxels;
+};
+struct EndEff { std::string joint, name; V3 pos; };
+struct Spec {
+  std::string integrator = "BDF1"; double h = 1e-2, gravity[3] = {0, 0, -9.8}, tol = 1e-9; int max_iter = 50, max_ls = 20;
+  bool has_ground = false; V3 ground_pos, ground_normal;
+  std::vector<Joint> joints; std::vector<Contact> contacts; std::vector<Motor> motors; std::vector<Sensor> sensors; std::vector<EndEff> endeffectors;
+  std::map<std::string, std::vector<double>> virtuals;
+};
+
+int joint_ndof(const std::string& t) {
+  if (t == "fixed") return 0;
+  if (t == "revolute" || t == "prismatic") return 1;
+  if (t == "planar") return 2;
+  if (t == "translational") return 3;
+  if (t == "free3d-euler" || t == "free3d-exp") return 6;
+  return -1;
+}
+int joint_code(const std::string& t) {
+  if (t == "revolute") return TSIM_J_REVOLUTE;
+  if (t == "prismatic") return TSIM_J_PRISMATIC;
+  if (t == "planar") return TSIM_J_PLANAR;
+  if (t == "translational") return TSIM_J_TRANSLATIONAL;
+  if (t == "spherical-exp") return TSIM_J_SPHERICAL_EXP;
+  throw Err("joint type '" + t + "' has no record");
+}
+void quat4(const XNode* e, const char* k, double* q) { auto v = floats_or(e, k, "1 0 0 0", 4); for (int i = 0; i < 4; ++i) q[i] = v[i]; }
+
+std::vector<Taxel> read_taxel_spec(const std::string& path) {      // count, then per line five quoted fields: "pos" "img_r img_c" "normal" "axis0" "axis1"
+  std::ifstream f(path);
+  if (!f) throw Err("cannot open " + path);
+  std::string line;
+  std::getline(f, line);
+  auto h = tokens(line, false);
+  if (h.empty()) throw Err("bad taxel file " + path);
+  const int n = to_int(h[0]);
+  std::vector<Taxel> out;
+  for (int k = 0; k < n; ++k) {
+    if (!std::getline(f, line)) throw Err("taxel file too short: " + path);
+    std::vector<std::vector<double>> fields;
+    size_t p = 0;
+    while (fields.size() < 5) {
+      const size_t a = line.find('"', p);
+      if (a == std::string::npos) break;
+      const size_t b = line.find('"', a + 1);
+      if (b == std::string::npos) break;
+      std::vector<double> v;
+      for (auto& t : tokens(line.substr(a + 1, b - a - 1), false)) v.push_back(to_double(t));
+      if (!v.empty()) fields.push_back(v);
+      p = b + 1;
+    }
+    if (fields.size() < 5 || fields[0].size() < 3 || fields[1].size() < 2 || fields[2].size() < 3 || fields[3].size() < 3 || fields[4].size() < 3) throw Err("bad taxel line in " + path);
+    Taxel t;
+    t.pos = v3(fields[0]); t.img[0] = (int)fields[1][0]; t.img[1] = (int)fields[1][1]; t.normal = v3(fields[2]); t.axis0 = v3(fields[3]); t.axis1 = v3(fields[4]);
+    out.push_back(t);
+  }
+  return out;
+}
+
+struct Defaults { double joint_lim_stiffness = 0, joint_damping = 0; double gpc[4] = {1e3, 1.0, 1.0, 0.0}, gc[4] = {1e3, 1.0, 1.0, 0.0}, tac[4] = {1e2, 1.0, 1.0, 0.0};
+                  double mP = 0, mD = 0, mrange[2] = {-1, 1}; std::string mctrl = "force"; };
+const char* kK4[4] = {"kn", "kt", "mu", "damping"};
+
+Pose world_pose_of(const Spec& S, int j) {      // at q = 0 every joint motion is the identity
+  std::vector<int> chain;
+  while (j >= 0) { chain.push_back(j); j = S.joints[j].parent; }
+  Pose T;
+  for (auto it = chain.rbegin(); it != chain.rend(); ++it) T = T * pose_of(S.joints[*it].pos, S.joints[*it].quat);
+  return T;
+}
+
+Body parse_body(const XNode* be, Spec& S, int jidx, const std::string& base) {
+  Body B;
+  B.name = attr_s(be, "name"); B.type = attr_s(be, "type");
+  B.pos = v3(floats_or(be, "pos", "0 0 0", 3)); quat4(be, "quat", B.quat);
+  B.density = attr_d(be, "density", 1.0);
+  if (B.type == "cuboid") {
+    B.size = v3(floats(be->get("size"), 3));
+    if (const char* r = be->get("general_contact_resolution")) { auto t = tokens(r, false); if (t.size() != 3) throw Err("general_contact_resolution needs 3 integers"); for (int k = 0; k < 3; ++k) B.cres[k] = to_int(t[k]); }
+  } else if (B.type == "sphere") {
+    if (!be->get("radius")) throw Err("sphere without radius");
+    B.radius = attr_d(be, "radius", 0);
+  } else if (B.type == "cylinder") {
+    if (!be->get("radius") || !be->get("length")) throw Err("cylinder without radius / length");
+    B.radius = attr_d(be, "radius", 0); B.length = attr_d(be, "length", 0);
+    B.cyl_res[0] = to_int(attr_s(be, "general_contact_angle_resolution", "8")); B.cyl_res[1] = to_int(attr_s(be, "general_contact_radius_resolution", "2"));
+  } else if (B.type == "mesh") {
+    if (!be->get("filename")) throw Err("mesh body without filename");
+    std::vector<V3> V; std::vector<int> Fc;
+    load_obj(base + "/" + attr_s(be, "filename"), V, Fc);
+    Pose T = pose_of(B.pos, B.quat);
+    const std::string tt = attr_s(be, "transform_type", "OBJ_TO_JOINT");
+    if (tt == "OBJ_TO_WORLD") T = world_pose_of(S, jidx).inv() * T;      // vertices are placed in the world at q = 0
+    else if (tt != "OBJ_TO_JOINT") throw Err("transform_type '" + tt + "'");
+    for (auto& x : V) x = T.apply(x);
+    B.mesh_unit = mesh_props(V, Fc);
+  } else if (B.type == "abstract") {
+    if (!be->get("mass") || !be->get("inertia")) throw Err("abstract body without mass / inertia");
+    B.mass = attr_d(be, "mass", 0); B.inertia = v3(floats(be->get("inertia"), 3));
+    const XNode* ce = be->find("collision");
+    if (ce && ce->get("contacts") && *ce->get("contacts")) {
+      // <collision pos quat> places the point file's frame in the BODY frame; stored in the JOINT frame
+      double cq[4]; quat4(ce, "quat", cq);
+      const Pose Tc = pose_of(B.pos, B.quat) * pose_of(v3(floats_or(ce, "pos", "0 0 0", 3)), cq);
+      B.contacts = read_points(base + "/" + attr_s(ce, "contacts"));
+      for (auto& x : B.contacts) x = Tc.apply(x);
+      B.has_contacts = true;
+    }
+  } else throw Err("body type '" + B.type + "'");
+  return B;
+}
+
+void parse_link(const XNode* link, int parent, Spec& S, const Defaults& D, const std::string& base) {
+  const XNode *je = link->find("joint"), *be = link->find("body");
+  if (!je || !be) throw Err("link '" + attr_s(link, "name") + "' needs one <joint> and one <body>");
+  Joint J;
+  J.name = attr_s(je, "name"); J.type = attr_s(je, "type"); J.parent = parent;
+  if (joint_ndof(J.type) < 0) throw Err("joint type '" + J.type + "'");
+  J.pos = v3(floats_or(je, "pos", "0 0 0", 3)); quat4(je, "quat", J.quat);
+  J.damping = attr_d(je, "damping", D.joint_damping); J.lim_stiffness = attr_d(je, "lim_stiffness", D.joint_lim_stiffness);
+  const bool one = J.type == "revolute" || J.type == "prismatic";
+  if (je->get("lim") && one) { auto l = floats(je->get("lim"), 2); J.has_lim = true; J.lim[0] = l[0]; J.lim[1] = l[1]; }
+  if (one) J.axes.push_back(v3(floats_or(je, "axis", "0 0 1", 3)));
+  else if (J.type == "planar") { J.axes.push_back(v3(floats_or(je, "axis0", "1 0 0", 3))); J.axes.push_back(v3(floats_or(je, "axis1", "0 1 0", 3))); }
+  const int jidx = (int)S.joints.size();
+  S.joints.push_back(J);
+  Body B = parse_body(be, S, jidx, base);
+  S.joints[jidx].body = B;
+  for (auto& c : link->kids) if (c->tag == "link") parse_link(c.get(), jidx, S, D, base);
+}
+
+Spec parse_xml(const std::string& path) {
+  const std::string base = dir_of(path);
+  const std::string text = read_file(path);
+  XParser P(text);
+  auto root = P.document();
+  if (root->tag != "redmax") throw Err("not a redmax model: " + path);
+  Spec S;
+  const XNode* opt = root->find("option");
+  if (opt) {
+    if (attr_s(opt, "unit", "m-kg") != "m-kg") throw Err("only unit='m-kg' models are supported");
+    S.integrator = attr_s(opt, "integrator", "BDF1"); S.h = attr_d(opt, "timestep", 1e-2);
+    auto g = floats_or(opt, "gravity", "0 0 -9.8", 3); for (int k = 0; k < 3; ++k) S.gravity[k] = g[k];
+  }
+  if (const XNode* sol = root->find("solver_option")) { S.tol = attr_d(sol, "tol", 1e-9); S.max_iter = to_int(attr_s(sol, "max_iter", "50")); S.max_ls = to_int(attr_s(sol, "max_ls", "20")); }
+  if (const XNode* g = root->find("ground")) { S.has_ground = true; S.ground_pos = v3(floats_or(g, "pos", "0 0 0", 3)); S.ground_normal = v3(floats_or(g, "normal", "0 0 1", 3)); }
+  Defaults D;
+  if (const XNode* d = root->find("default")) {
+    if (const XNode* e = d->find("joint")) { D.joint_lim_stiffness = attr_d(e, "lim_stiffness", D.joint_lim_stiffness); D.joint_damping = attr_d(e, "damping", D.joint_damping); }
+    const std::pair<const char*, double*> tabs[3] = {{"general_primitive_contact", D.gpc}, {"ground_contact", D.gc}, {"tactile", D.tac}};
+    for (auto& t : tabs) if (const XNode* e = d->find(t.first)) for (int k = 0; k < 4; ++k) t.second[k] = attr_d(e, kK4[k], t.second[k]);
+    if (const XNode* e = d->find("motor")) {
+      D.mP = attr_d(e, "P", D.mP); D.mD = attr_d(e, "D", D.mD);
+      if (e->get("ctrl_range")) { auto r = floats(e->get("ctrl_range"), 2); D.mrange[0] = r[0]; D.mrange[1] = r[1]; }
+      if (e->get("ctrl")) D.mctrl = e->get("ctrl");
+    }
+  }
+  for (auto& robot : root->kids) if (robot->tag == "robot") for (auto& link : robot->kids) if (link->tag == "link") parse_link(link.get(), -1, S, D, base);
+  if (const XNode* ce = root->find("contact")) for (auto& e : ce->kids) {
+    Contact c; const double* src;
+    if (e->tag == "ground_contact") { c.ground = true; c.a = attr_s(e.get(), "body"); src = D.gc; }
+    else if (e->tag == "general_primitive_contact") { c.a = attr_s(e.get(), "general_body"); c.b = attr_s(e.get(), "primitive_body"); src = D.gpc; }
+    else throw Err("contact type '" + e->tag + "'");
+    for (int k = 0; k < 4; ++k) c.k[k] = attr_d(e.get(), kK4[k], src[k]);
+    S.contacts.push_back(c);
+  }
+  if (const XNode* ae = root->find("actuator")) for (auto& e : ae->kids) if (e->tag == "motor") {
+    Motor m; m.joint = attr_s(e.get(), "joint");
+    const std::string ctrl = attr_s(e.get(), "ctrl", D.mctrl.c_str());
+    m.ctrl = ctrl == "force" ? 0 : 1;
+    const char* cr = e->get("ctrl_range");
+    if (cr && *cr) { auto r = floats(cr, 2); m.range[0] = r[0]; m.range[1] = r[1]; } else { m.range[0] = D.mrange[0]; m.range[1] = D.mrange[1]; }
+    m.P = attr_d(e.get(), "P", D.mP); m.D = attr_d(e.get(), "D", D.mD);
+    S.motors.push_back(m);
+  }
+  if (const XNode* se = root->find("sensor")) for (auto& e : se->kids) if (e->tag == "tactile") {
+    Sensor s; s.body = attr_s(e.get(), "body"); s.name = attr_s(e.get(), "name"); s.type = attr_s(e.get(), "type");
+    for (int k = 0; k < 4; ++k) s.k[k] = attr_d(e.get(), kK4[k], D.tac[k]);
+    if (s.type == "rect_array") {
+      s.rect_pos0 = v3(floats(e->get("rect_pos0"), 3)); s.rect_pos1 = v3(floats(e->get("rect_pos1"), 3));
+      s.axis0 = v3(floats(e->get("axis0"), 3)); s.axis1 = v3(floats(e->get("axis1"), 3));
+      auto t = tokens(attr_s(e.get(), "resolution"), false);
+      if (t.size() != 2) throw Err("tactile resolution needs 2 integers");
+      s.res[0] = to_int(t[0]); s.res[1] = to_int(t[1]);
+    } else if (s.type == "abstract") {
+      s.pos = v3(floats_or(e.get(), "pos", "0 0 0", 3)); quat4(e.get(), "quat", s.quat);
+      s.taxels = read_taxel_spec(base + "/" + attr_s(e.get(), "spec"));
+    } else throw Err("tactile type '" + s.type + "'");
+    S.sensors.push_back(s);
+  }
+  if (const XNode* ve = root->find("variable")) { int i = 0; for (auto& e : ve->kids) if (e->tag == "endeffector") {
+    EndEff ee; ee.joint = attr_s(e.get(), "joint"); ee.pos = v3(floats_or(e.get(), "pos", "0 0 0", 3));
+    ee.name = attr_s(e.get(), "name", ("endeffector_" + std::to_string(i)).c_str());
+    S.endeffectors.push_back(ee); ++i;
+  } }
+  if (const XNode* vv = root->find("virtual")) for (auto& e : vv->kids) {
+    auto p = floats_or(e.get(), "pos", "0 0 0", 3); auto q = floats_or(e.get(), "quat", "1 0 0 0", 4);
+    p.insert(p.end(), q.begin(), q.end());
+    S.virtuals[attr_s(e.get(), "name")] = p;
+  }
+  return S;
+}
+
+// ----------------------------------------------------------------------------------------------------------------- description -> blob
+struct Link { int parent = -1, joint = -1, dof0 = 0, ndof = 0, ancmask = 0; std::string jtype; Pose E; std::vector<V3> axes; MassProps mp;
+              double damping = 0, lim_stiffness = 0; bool has_lim = false; double lim[2] = {0, 0}; };
+struct Pair { int la, lb, prim, pt0, npt, flags; Pose T; double shape[4], k[4]; std::string key0, key1; };
+struct SensorRec { int link, tax0, ntax, sprim0, nsprim, rows, cols; double k[4]; std::string name; std::vector<int32_t> img; };
+
+struct Compiled {
+  std::vector<int32_t> I; std::vector<double> F;
+  std::vector<std::pair<std::string, std::string>> pair_keys;
+  std::vector<SensorRec> sensors;
+  std::map<std::string, std::pair<int, int>> dof_of_joint;
+};
+
+MassProps body_props(const Body& B) {      // in the body's JOINT frame
+  if (B.type == "mesh") return B.mesh_unit.scaled_by(B.density);
+  const Pose Tb = pose_of(B.pos, B.quat);
+  MassProps mp;
+  if (B.type == "cuboid") {
+    const double sx = B.size[0], sy = B.size[1], sz = B.size[2], m = B.density * sx * sy * sz;
+    mp.m = m; mp.Ic = diag(m / 12 * (sy * sy + sz * sz), m / 12 * (sx * sx + sz * sz), m / 12 * (sx * sx + sy * sy));
+  } else if (B.type == "sphere") {
+    const double r = B.radius, m = B.density * 4.0 / 3.0 * kPi * std::pow(r, 3.0);
+    mp.m = m; const double i = 0.4 * m * r * r; mp.Ic = diag(i, i, i);
+  } else if (B.type == "cylinder") {      // solid, axis = local z
+    const double r = B.radius, l = B.length, m = B.density * kPi * r * r * l, ixy = m * (3 * r * r + l * l) / 12.0;
+    mp.m = m; mp.Ic = diag(ixy, ixy, 0.5 * m * r * r);
+  } else if (B.type == "abstract") {
+    mp.m = B.mass; mp.Ic = diag(B.inertia[0], B.inertia[1], B.inertia[2]);
+  } else throw Err("body type '" + B.type + "'");
+  return mp.transformed(Tb);
+}
+std::vector<double> linspace(double a, double b, int n) {      // numpy.linspace: a + k * step, last point exactly b
+  std::vector<double> o(n);
+  const double step = (b - a) / (n - 1);
+  for (int k = 0; k < n; ++k) o[k] = a + k * step;
+  o[n - 1] = b;
+  return o;
+}
+bool body_contact_points(const Body& B, std::vector<V3>& out) {      // sampled surface points of a general contact body, JOINT frame; false: sphere (none)
+  const Pose Tb = pose_of(B.pos, B.quat);
+  if (B.type == "cuboid") {      // lattice of res points per axis spanning the cuboid, surface points only: (2,2,2) = the 8 corners
+    int res[3]; std::vector<double> ax[3];
+    for (int k = 0; k < 3; ++k) { res[k] = std::max(B.cres[k], 2); ax[k] = linspace(-0.5 * B.size[k], 0.5 * B.size[k], res[k]); }
+    for (int i = 0; i < res[0]; ++i) for (int j = 0; j < res[1]; ++j) for (int k = 0; k < res[2]; ++k)
+      if (i == 0 || i == res[0] - 1 || j == 0 || j == res[1] - 1 || k == 0 || k == res[2] - 1) out.push_back(Tb.apply(v3(ax[0][i], ax[1][j], ax[2][k])));
+    return true;
+  }
+  if (B.type == "cylinder") {      // both end caps: centre + n_radius rings of n_angle points
+    const int na = B.cyl_res[0], nrad = B.cyl_res[1];
+    for (double z : {0.5 * B.length, -0.5 * B.length}) {
+      out.push_back(Tb.apply(v3(0.0, 0.0, z)));
+      for (int ir = 1; ir <= nrad; ++ir) {
+        const double r = B.radius * ir / nrad;
+        for (int ia = 0; ia < na; ++ia) { const double th = 2.0 * kPi * ia / na; out.push_back(Tb.apply(v3(r * std::cos(th), r * std::sin(th), z))); }
+      }
+    }
+    return true;
+  }
+  if (B.type == "abstract" && B.has_contacts) { out = B.contacts; return true; }
+  if (B.type == "sphere") return false;
+  throw Err("contact points for body type '" + B.type + "' (" + B.name + ")");
+}
+
+Compiled compile_spec(const Spec& S) {
+  const int nj = (int)S.joints.size();
+  std::vector<int> link_of_joint(nj, 0);
+  std::vector<Pose> T_link_joint(nj);
+  std::vector<Link> links(1);      // link 0 = world
+  int dof0 = 0;
+  for (int j = 0; j < nj; ++j) {
+    const Joint& J = S.joints[j];
+    const int par = J.parent;
+    const Pose E_pj0 = pose_of(J.pos, J.quat);
+    int plink = par >= 0 ? link_of_joint[par] : 0;
+    const Pose T_pl = (par >= 0 ? T_link_joint[par] : Pose()) * E_pj0;      // joint-0 frame in the parent LINK frame
+    const int nd = joint_ndof(J.type);
+    auto mk = [&](int parent, const std::string& jt, std::vector<V3> axes, int n, const Pose& E) {
+      Link L; L.parent = parent; L.joint = j; L.E = E; L.dof0 = dof0; L.ndof = n; L.jtype = jt; L.axes = std::move(axes);
+      L.damping = J.damping; L.lim_stiffness = J.lim_stiffness; L.has_lim = J.has_lim; L.lim[0] = J.lim[0]; L.lim[1] = J.lim[1];
+      links.push_back(L); dof0 += n; return (int)links.size() - 1;
+    };
+    if (nd == 0) { link_of_joint[j] = plink; T_link_joint[j] = T_pl; }
+    else if (J.type == "free3d-euler") {      // [CHOICE] translation + intrinsic X-Y-Z revolutes with massless intermediate links
+      plink = mk(plink, "translational", {}, 3, T_pl);
+      plink = mk(plink, "revolute", {v3(1, 0, 0)}, 1, Pose());
+      plink = mk(plink, "revolute", {v3(0, 1, 0)}, 1, Pose());
+      plink = mk(plink, "revolute", {v3(0, 0, 1)}, 1, Pose());
+      link_of_joint[j] = plink; T_link_joint[j] = Pose();
+    } else if (J.type == "free3d-exp") {      // translation + rotation-vector spherical joint, massless link in between
+      plink = mk(plink, "translational", {}, 3, T_pl);
+      plink = mk(plink, "spherical-exp", {}, 3, Pose());
+      link_of_joint[j] = plink; T_link_joint[j] = Pose();
+    } else { link_of_joint[j] = mk(plink, J.type, J.axes, nd, T_pl); T_link_joint[j] = Pose(); }
+    Link& L = links[link_of_joint[j]];
+    L.mp = L.mp + body_props(J.body).transformed(T_link_joint[j]);
+  }
+  const int nl = (int)links.size() - 1, nr = dof0;
+  if (nr > 30) throw Err("more than 30 reduced dofs");
+  for (int i = 1; i <= nl; ++i) {
+    Link& L = links[i];
+    L.ancmask = (((1 << L.ndof) - 1) << L.dof0) | (L.parent > 0 ? links[L.parent].ancmask : 0);
+  }
+  std::map<std::string, int> jidx_by_name, body_joint;
+  for (int j = 0; j < nj; ++j) { jidx_by_name[S.joints[j].name] = j; body_joint[S.joints[j].body.name] = j; }
+  auto joint_of_body = [&](const std::string& n) { auto it = body_joint.find(n); if (it == body_joint.end()) throw Err("unknown body '" + n + "'"); return it->second; };
+  auto body_pose_in_link = [&](int j) { const Body& B = S.joints[j].body; return T_link_joint[j] * pose_of(B.pos, B.quat); };
+
+  // ---- contact pairs + points
+  std::vector<Pair> pairs; std::vector<V3> cpt;
+  auto add_points = [&](const std::vector<V3>& P, const Pose* T, int& p0, int& npt) { p0 = (int)cpt.size(); npt = (int)P.size(); for (auto& x : P) cpt.push_back(T ? T->apply(x) : x); };
+  for (const Contact& c : S.contacts) {
+    Pair p; for (int k = 0; k < 4; ++k) { p.k[k] = c.k[k]; p.shape[k] = 0; }
+    if (c.ground) {
+      if (!S.has_ground) throw Err("ground_contact without <ground>");
+      const int j = joint_of_body(c.a); const Body& B = S.joints[j].body;
+      const V3 n = unit(S.ground_normal);
+      const V3 t0 = unit(std::fabs(n[0]) < 0.9 ? cross(n, v3(1, 0, 0)) : cross(n, v3(0, 1, 0)));
+      const V3 t1 = cross(n, t0);
+      for (int r = 0; r < 3; ++r) { p.T.R(r, 0) = t0[r]; p.T.R(r, 1) = t1[r]; p.T.R(r, 2) = n[r]; }      // columns: tangent, tangent, normal
+      p.T.p = S.ground_pos;
+      if (B.type == "sphere") {      // [CHOICE] moving contact point = lowest point of the sphere: the stored point is its centre, the radius a shape parameter
+        add_points({body_pose_in_link(j).p}, nullptr, p.pt0, p.npt); p.shape[0] = B.radius; p.flags = 1 | 2;
+      } else {
+        std::vector<V3> P; body_contact_points(B, P);
+        add_points(P, &T_link_joint[j], p.pt0, p.npt); p.flags = 1;
+      }
+      p.la = link_of_joint[j]; p.lb = 0; p.prim = TSIM_P_PLANE; p.key0 = "ground"; p.key1 = c.a;
+    } else {
+      const int ja = joint_of_body(c.a), jb = joint_of_body(c.b);
+      const Body& Bp = S.joints[jb].body;
+      if (Bp.type == "cuboid") { p.prim = TSIM_P_CUBOID; for (int k = 0; k < 3; ++k) p.shape[k] = 0.5 * Bp.size[k]; }
+      else if (Bp.type == "sphere") { p.prim = TSIM_P_SPHERE; p.shape[0] = Bp.radius; }
+      else if (Bp.type == "cylinder") { p.prim = TSIM_P_CYLINDER; p.shape[0] = Bp.radius; p.shape[1] = 0.5 * Bp.length; }
+      else throw Err("body type '" + Bp.type + "' cannot be a contact primitive (" + Bp.name + ")");
+      std::vector<V3> P;
+      if (!body_contact_points(S.joints[ja].body, P)) throw Err("a sphere cannot be the general body of a general_primitive_contact (" + c.a + ")");
+      add_points(P, &T_link_joint[ja], p.pt0, p.npt);
+      p.la = link_of_joint[ja]; p.lb = link_of_joint[jb]; p.T = body_pose_in_link(jb); p.flags = 1; p.key0 = c.a; p.key1 = c.b;
+    }
+    pairs.push_back(p);
+  }
+
+  // ---- tactile sensors
+  std::vector<SensorRec> sensors; std::vector<int> sprims; std::vector<std::vector<double>> tax;      // tax[i] = 12 values
+  for (const Sensor& s : S.sensors) {
+    const int j = joint_of_body(s.body);
+    const Pose Tbody = body_pose_in_link(j);
+    SensorRec R; R.link = link_of_joint[j]; R.tax0 = (int)tax.size(); R.name = s.name; for (int k = 0; k < 4; ++k) R.k[k] = s.k[k];
+    auto emit = [&](const Pose& T, const V3& pos, const V3& a0, const V3& a1, const V3& nrm, int r, int c) {
+      const V3 P = T.apply(pos), A0 = T.rotate(a0), A1 = T.rotate(a1), N = T.rotate(nrm);
+      tax.push_back({P[0], P[1], P[2], A0[0], A0[1], A0[2], A1[0], A1[1], A1[2], N[0], N[1], N[2]});
+      R.img.push_back(r); R.img.push_back(c);
+    };
+    if (s.type == "rect_array") {
+      const V3 a0 = unit(s.axis0), a1 = unit(s.axis1), nrm = cross(a1, a0);      // [CHOICE] matches the explicit normals of the abstract spec file
+      const V3 d = sub(s.rect_pos1, s.rect_pos0);
+      const double e0 = dot(d, a0), e1 = dot(d, a1);
+      const int Rn = s.res[0], Cn = s.res[1];
+      for (int i = 0; i < Rn; ++i) for (int jx = 0; jx < Cn; ++jx) {
+        const double f0 = e0 * i / std::max(Rn - 1, 1), f1 = e1 * jx / std::max(Cn - 1, 1);
+        emit(Tbody, add(add(s.rect_pos0, scaled(a0, f0)), scaled(a1, f1)), a0, a1, nrm, i, jx);
+      }
+      R.rows = Rn; R.cols = Cn;
+    } else {
+      const Pose Ts = Tbody * pose_of(s.pos, s.quat);      // sensor pos / quat are relative to the body frame
+      R.rows = R.cols = 0;
+      for (const Taxel& t : s.taxels) { emit(Ts, t.pos, t.axis0, t.axis1, t.normal, t.img[0], t.img[1]); R.rows = std::max(R.rows, t.img[0] + 1); R.cols = std::max(R.cols, t.img[1] + 1); }
+      if (s.taxels.empty()) throw Err("tactile sensor '" + s.name + "' has no taxels");
+    }
+    R.ntax = (int)tax.size() - R.tax0;
+    // [CHOICE] a sensor's taxels are tested against the primitive of every general_primitive pair whose general body is the sensor's body
+    R.sprim0 = (int)sprims.size();
+    for (size_t pi = 0; pi < pairs.size(); ++pi) if (pairs[pi].key0 == s.body && pairs[pi].key0 != "ground") sprims.push_back((int)pi);
+    R.nsprim = (int)sprims.size() - R.sprim0;
+    sensors.push_back(R);
+  }
+
+  // ---- motors -> one record per entry of u
+  struct MotorRec { int dof, ctrl; double f[4]; };
+  std::vector<MotorRec> motors;
+  for (const Motor& m : S.motors) {
+    auto it = jidx_by_name.find(m.joint);
+    if (it == jidx_by_name.end()) throw Err("motor on unknown joint '" + m.joint + "'");
+    if (joint_ndof(S.joints[it->second].type) == 0) throw Err("motor on fixed joint '" + m.joint + "'");
+    for (int i = 1; i <= nl; ++i) if (links[i].joint == it->second)
+      for (int k = 0; k < links[i].ndof; ++k) motors.push_back({links[i].dof0 + k, m.ctrl, {m.range[0], m.range[1], m.P, m.D}});
+  }
+  // ---- variables
+  struct VarRec { int link; V3 pos; };
+  std::vector<VarRec> vars;
+  for (const EndEff& e : S.endeffectors) {
+    auto it = jidx_by_name.find(e.joint);
+    if (it == jidx_by_name.end()) throw Err("endeffector on unknown joint '" + e.joint + "'");
+    vars.push_back({link_of_joint[it->second], T_link_joint[it->second].apply(e.pos)});
+  }
+
+  // ---- emit
+  Compiled C;
+  std::vector<int32_t>& I = C.I; std::vector<double>& F = C.F;
+  I.assign(TSIM_IH_SIZE, 0); F.assign(TSIM_FH_SIZE, 0.0);
+  auto section = [&](int ioff_slot, int foff_slot, size_t nrec_i, int isz, size_t nrec_f, int fsz) {
+    if (ioff_slot >= 0) I[ioff_slot] = (int32_t)I.size();
+    if (foff_slot >= 0) I[foff_slot] = (int32_t)F.size();
+    const size_t i0 = I.size(), f0 = F.size();
+    I.resize(i0 + nrec_i * isz, 0); F.resize(f0 + nrec_f * fsz, 0.0);
+    return std::make_pair(i0, f0);
+  };
+  {
+    auto o = section(TSIM_IH_OFF_LINK, TSIM_IH_FOFF_LINK, nl, TSIM_LI_SIZE, nl, TSIM_LF_SIZE);
+    for (int i = 1; i <= nl; ++i) {
+      const Link& L = links[i];
+      int32_t* li = &I[o.first + (size_t)(i - 1) * TSIM_LI_SIZE]; double* lf = &F[o.second + (size_t)(i - 1) * TSIM_LF_SIZE];
+      li[TSIM_LI_PARENT] = L.parent; li[TSIM_LI_JTYPE] = joint_code(L.jtype); li[TSIM_LI_DOF0] = L.dof0; li[TSIM_LI_NDOF] = L.ndof; li[TSIM_LI_ANCMASK] = L.ancmask;
+      for (int k = 0; k < 9; ++k) lf[TSIM_LF_R + k] = L.E.R.m[k];
+      for (int k = 0; k < 3; ++k) lf[TSIM_LF_P + k] = L.E.p[k];
+      for (size_t a = 0; a < L.axes.size(); ++a) { const V3 u = unit(L.axes[a]); for (int k = 0; k < 3; ++k) lf[TSIM_LF_AXES + 3 * a + k] = u[k]; }
+      lf[TSIM_LF_MASS] = L.mp.m;
+      for (int k = 0; k < 3; ++k) lf[TSIM_LF_COM + k] = L.mp.c[k];
+      const M3& Ic = L.mp.Ic;
+      const double in6[6] = {Ic(0, 0), Ic(1, 1), Ic(2, 2), Ic(0, 1), Ic(0, 2), Ic(1, 2)};
+      for (int k = 0; k < 6; ++k) lf[TSIM_LF_INERTIA + k] = in6[k];
+    }
+  }
+  {
+    auto o = section(TSIM_IH_OFF_DOF, TSIM_IH_FOFF_DOF, nr, TSIM_DI_SIZE, nr, TSIM_DF_SIZE);
+    int d = 0;
+    for (int i = 1; i <= nl; ++i) for (int k = 0; k < links[i].ndof; ++k, ++d) {
+      const Link& L = links[i];
+      I[o.first + (size_t)d * TSIM_DI_SIZE + TSIM_DI_LINK] = i;
+      double* df = &F[o.second + (size_t)d * TSIM_DF_SIZE];
+      df[TSIM_DF_DAMPING] = L.damping;
+      if (L.has_lim && L.lim_stiffness > 0) { df[TSIM_DF_LIM_LO] = L.lim[0]; df[TSIM_DF_LIM_HI] = L.lim[1]; df[TSIM_DF_LIM_K] = L.lim_stiffness; }
+    }
+  }
+  {
+    auto o = section(TSIM_IH_OFF_MOTOR, TSIM_IH_FOFF_MOTOR, motors.size(), TSIM_MI_SIZE, motors.size(), TSIM_MF_SIZE);
+    for (size_t n = 0; n < motors.size(); ++n) {
+      I[o.first + n * TSIM_MI_SIZE + TSIM_MI_DOF] = motors[n].dof; I[o.first + n * TSIM_MI_SIZE + TSIM_MI_CTRL] = motors[n].ctrl;
+      for (int k = 0; k < 4; ++k) F[o.second + n * TSIM_MF_SIZE + k] = motors[n].f[k];
+    }
+  }
+  {
+    auto o = section(TSIM_IH_OFF_VAR, TSIM_IH_FOFF_VAR, vars.size(), TSIM_VI_SIZE, vars.size(), TSIM_VF_SIZE);
+    for (size_t n = 0; n < vars.size(); ++n) { I[o.first + n * TSIM_VI_SIZE + TSIM_VI_LINK] = vars[n].link; for (int k = 0; k < 3; ++k) F[o.second + n * TSIM_VF_SIZE + TSIM_VF_POS + k] = vars[n].pos[k]; }
+  }
+  {
+    auto o = section(TSIM_IH_OFF_PAIR, TSIM_IH_FOFF_PAIR, pairs.size(), TSIM_PI_SIZE, pairs.size(), TSIM_PF_SIZE);
+    for (size_t n = 0; n < pairs.size(); ++n) {
+      const Pair& p = pairs[n];
+      int32_t* pi = &I[o.first + n * TSIM_PI_SIZE]; double* pf = &F[o.second + n * TSIM_PF_SIZE];
+      pi[TSIM_PI_LINKA] = p.la; pi[TSIM_PI_LINKB] = p.lb; pi[TSIM_PI_PRIM] = p.prim; pi[TSIM_PI_PT0] = p.pt0; pi[TSIM_PI_NPT] = p.npt; pi[TSIM_PI_FLAGS] = p.flags;
+      for (int k = 0; k < 9; ++k) pf[TSIM_PF_R + k] = p.T.R.m[k];
+      for (int k = 0; k < 3; ++k) pf[TSIM_PF_P + k] = p.T.p[k];
+      for (int k = 0; k < 4; ++k) { pf[TSIM_PF_SHAPE + k] = p.shape[k]; pf[TSIM_PF_KN + k] = p.k[k]; }
+      C.pair_keys.emplace_back(p.key0, p.key1);
+    }
+  }
+  {
+    auto o = section(TSIM_IH_OFF_SENSOR, TSIM_IH_FOFF_SENSOR, sensors.size(), TSIM_SI_SIZE, sensors.size(), TSIM_SF_SIZE);
+    for (size_t n = 0; n < sensors.size(); ++n) {
+      const SensorRec& s = sensors[n];
+      int32_t* si = &I[o.first + n * TSIM_SI_SIZE];
+      si[TSIM_SI_LINK] = s.link; si[TSIM_SI_TAX0] = s.tax0; si[TSIM_SI_NTAX] = s.ntax; si[TSIM_SI_SPRIM0] = s.sprim0; si[TSIM_SI_NSPRIM] = s.nsprim; si[TSIM_SI_ROWS] = s.rows; si[TSIM_SI_COLS] = s.cols;
+      for (int k = 0; k < 4; ++k) F[o.second + n * TSIM_SF_SIZE + k] = s.k[k];
+    }
+  }
+  {
+    auto o = section(TSIM_IH_OFF_SPRIM, -1, sprims.size(), 1, 0, 1);
+    for (size_t n = 0; n < sprims.size(); ++n) I[o.first + n] = sprims[n];
+  }
+  const int ncpt = (int)cpt.size(), ntax = (int)tax.size();
+  I[TSIM_IH_FOFF_CPT] = (int32_t)F.size();
+  for (int c = 0; c < 3; ++c) for (int i = 0; i < ncpt; ++i) F.push_back(cpt[i][c]);
+  I[TSIM_IH_FOFF_TAXEL] = (int32_t)F.size();
+  for (int c = 0; c < 12; ++c) for (int i = 0; i < ntax; ++i) F.push_back(tax[i][c]);
+
+  int integ = S.integrator == "BDF1" ? 1 : S.integrator == "BDF2" ? 2 : 0;
+  if (!integ) throw Err("integrator '" + S.integrator + "'");
+  I[TSIM_IH_MAGIC] = TSIM_MAGIC; I[TSIM_IH_VERSION] = TSIM_VERSION;
+  I[TSIM_IH_NL] = nl; I[TSIM_IH_NR] = nr; I[TSIM_IH_NU] = (int)motors.size(); I[TSIM_IH_NVAR] = (int)vars.size();
+  I[TSIM_IH_NPAIR] = (int)pairs.size(); I[TSIM_IH_NCPT] = ncpt; I[TSIM_IH_NSENSOR] = (int)sensors.size();
+  I[TSIM_IH_NTAXEL] = ntax; I[TSIM_IH_NSPRIM] = (int)sprims.size();
+  I[TSIM_IH_INTEGRATOR] = integ; I[TSIM_IH_MAX_ITER] = S.max_iter; I[TSIM_IH_MAX_LS] = S.max_ls;
+  I[TSIM_IH_NDOF_TACTILE] = 3 * ntax;
+  F[TSIM_FH_H] = S.h; for (int k = 0; k < 3; ++k) F[TSIM_FH_GX + k] = S.gravity[k]; F[TSIM_FH_TOL] = S.tol;
+  I[TSIM_IH_NI] = (int32_t)I.size(); I[TSIM_IH_NF] = (int32_t)F.size();
+
+  for (int j = 0; j < nj; ++j) {
+    const int nd = joint_ndof(S.joints[j].type);
+    if (nd <= 0) continue;
+    int d0 = 1 << 30;
+    for (int i = 1; i <= nl; ++i) if (links[i].joint == j) d0 = std::min(d0, links[i].dof0);
+    C.dof_of_joint[S.joints[j].name] = {d0, nd};
+  }
+  C.sensors = std::move(sensors);
+  return C;
+}
+
+Body& find_body(Spec& S, const std::string& n) { for (auto& J : S.joints) if (J.body.name == n) return J.body; throw Err("unknown body '" + n + "'"); }
+Joint& find_joint(Spec& S, const std::string& n) { for (auto& J : S.joints) if (J.name == n) return J; throw Err("unknown joint '" + n + "'"); }
+
+}  // namespace
+
+struct tsim_model { bool has_spec = false; Spec spec; Compiled c; };
+
+namespace {
+template <class Fn> int guarded(Fn&& fn) {
+  try { fn(); return 0; }
+  catch (const std::exception& e) { return tsim_fail_(e.what()); }
+}
+}  // namespace
+
+extern "C" {
+
+int tsim_model_load(const char* xml_path, tsim_model** out) {
+  if (!xml_path || !out) return tsim_fail_("tsim_model_load: null argument");
+  *out = nullptr;
+  return guarded([&] {
+    auto m = std::make_unique<tsim_model>();
+    m->spec = parse_xml(xml_path); m->has_spec = true;
+    m->c = compile_spec(m->spec);
+    *out = m.release();
+  });
+}
+void tsim_model_free(tsim_model* m) { delete m; }
+
+int tsim_model_blob(const tsim_model* m, const int32_t** I, int* nI, const double** F, int* nF) {
+  if (!m) return tsim_fail_("tsim_model_blob: null model");
+  if (I) *I = m->c.I.data();
+  if (nI) *nI = (int)m->c.I.size();
+  if (F) *F = m->c.F.data();
+  if (nF) *nF = (int)m->c.F.size();
+  return 0;
+}
+
+int tsim_model_save_blob(const tsim_model* m, const char* path) {
+  if (!m || !path) return tsim_fail_("tsim_model_save_blob: null argument");
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return tsim_fail_(std::string("cannot write ") + path);
+  const uint32_t head[2] = {(uint32_t)TSIM_MAGIC, (uint32_t)TSIM_VERSION};
+  const int32_t n[2] = {(int32_t)m->c.I.size(), (int32_t)m->c.F.size()};
+  bool ok = std::fwrite(head, 4, 2, f) == 2 && std::fwrite(n, 4, 2, f) == 2 && std::fwrite(m->c.I.data(), 4, m->c.I.size(), f) == m->c.I.size() &&
+            std::fwrite(m->c.F.data(), 8, m->c.F.size(), f) == m->c.F.size();
+  ok = std::fclose(f) == 0 && ok;
+  return ok ? 0 : tsim_fail_(std::string("short write to ") + path);
+}
+int tsim_model_load_blob(const char* path, tsim_model** out) {
+  if (!path || !out) return tsim_fail_("tsim_model_load_blob: null argument");
+  *out = nullptr;
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return tsim_fail_(std::string("cannot open ") + path);
+  uint32_t head[2]; int32_t n[2];
+  auto m = std::make_unique<tsim_model>();
+  bool ok = std::fread(head, 4, 2, f) == 2 && std::fread(n, 4, 2, f) == 2;
+  if (ok && (head[0] != (uint32_t)TSIM_MAGIC || head[1] != (uint32_t)TSIM_VERSION)) { std::fclose(f); return tsim_fail_("model blob file: bad magic/version"); }
+  if (ok && (n[0] < TSIM_IH_SIZE || n[1] < TSIM_FH_SIZE || n[0] > (1 << 26) || n[1] > (1 << 28))) { std::fclose(f); return tsim_fail_("model blob file: bad sizes"); }
+  if (ok) { m->c.I.resize(n[0]); m->c.F.resize(n[1]); ok = std::fread(m->c.I.data(), 4, n[0], f) == (size_t)n[0] && std::fread(m->c.F.data(), 8, n[1], f) == (size_t)n[1]; }
+  std::fclose(f);
+  if (!ok) return tsim_fail_(std::string("model blob file truncated: ") + path);
+  if (m->c.I[TSIM_IH_MAGIC] != TSIM_MAGIC || m->c.I[TSIM_IH_VERSION] != TSIM_VERSION || m->c.I[TSIM_IH_NI] != n[0] || m->c.I[TSIM_IH_NF] != n[1])
+    return tsim_fail_("model blob file: header and contents disagree");
+  *out = m.release();
+  return 0;
+}
+
+int tsim_batch_create_from_model(const tsim_model* m, int B, int tape_capacity, int dtype, int device, tsim_batch** out) {
+  if (!m) return tsim_fail_("tsim_batch_create_from_model: null model");
+  return tsim_batch_create(m->c.I.data(), m->c.F.data(), B, tape_capacity, dtype, device, out);
+}
+
+int tsim_model_image_pos(const tsim_model* m, const char* sensor_name, int32_t* rc_out, int capacity) {
+  if (!m || !sensor_name) { tsim_fail_("tsim_model_image_pos: null argument"); return -1; }
+  if (!m->has_spec) { tsim_fail_("tsim_model_image_pos: the model was loaded from a blob file and has no description"); return -1; }
+  for (const SensorRec& s : m->c.sensors) if (s.name == sensor_name) {
+    const int n = std::min(s.ntax, std::max(capacity, 0));
+    if (rc_out) for (int k = 0; k < 2 * n; ++k) rc_out[k] = s.img[k];
+    return s.ntax;
+  }
+  tsim_fail_(std::string("unknown tactile sensor '") + sensor_name + "'");
+  return -1;
+}
+
+int tsim_model_update(tsim_model* m, int what, const char* name, const char* name2, const double* v, int n) {
+  if (!m || !name || (!v && n > 0)) return tsim_fail_("tsim_model_update: null argument");
+  if (!m->has_spec) return tsim_fail_("tsim_model_update: the model was loaded from a blob file and has no description");
+  return guarded([&] {
+    Spec S = m->spec;
+    auto need = [&](int k) { if (n < k) throw Err("tsim_model_update: " + std::to_string(k) + " values expected"); };
+    auto k4 = [&](double* dst) { need(4); for (int k = 0; k < 4; ++k) if (!std::isnan(v[k])) dst[k] = v[k]; };
+    switch (what) {
+      case TSIM_UPD_JOINT_DAMPING: need(1); find_joint(S, name).damping = v[0]; break;
+      case TSIM_UPD_JOINT_LOCATION: need(3); find_joint(S, name).pos = v3(v[0], v[1], v[2]); break;
+      case TSIM_UPD_BODY_DENSITY: need(1); find_body(S, name).density = v[0]; break;
+      case TSIM_UPD_BODY_SIZE: {
+        Body& B = find_body(S, name);
+        if (B.type == "cuboid") { need(3); B.size = v3(v[0], v[1], v[2]); }
+        else if (B.type == "sphere") { need(1); B.radius = v[0]; }
+        else if (B.type == "cylinder") { need(2); B.length = v[0]; B.radius = v[1]; }      // (length, radius) as envs/dclaw_rotate_env.py:175 passes them
+        else throw Err("update_body_size on a " + B.type + " body");
+        break;
+      }
+      case TSIM_UPD_ENDEFFECTOR_POSITION: {
+        need(3); bool hit = false;
+        for (auto& e : S.endeffectors) if (e.name == name) { e.pos = v3(v[0], v[1], v[2]); hit = true; break; }
+        if (!hit) throw Err(std::string("unknown endeffector '") + name + "'");
+        break;
+      }
+      case TSIM_UPD_CONTACT_PARAMETERS: {
+        if (!name2) throw Err("tsim_model_update: contact parameters need both body names");
+        bool hit = false;
+        for (auto& c : S.contacts) if (!c.ground && c.a == name && c.b == name2) { k4(c.k); hit = true; }
+        if (!hit) throw Err(std::string("no general_primitive_contact ") + name + " -> " + name2);
+        break;
+      }
+      case TSIM_UPD_TACTILE_PARAMETERS: {
+        bool hit = false;
+        for (auto& s : S.sensors) if (s.body == name || s.name == name) { k4(s.k); hit = true; }
+        if (!hit) throw Err(std::string("no tactile sensor on '") + name + "'");
+        break;
+      }
+      case TSIM_UPD_VIRTUAL_OBJECT: need(7); S.virtuals[name] = std::vector<double>(v, v + 7); break;
+      default: throw Err("tsim_model_update: unknown kind " + std::to_string(what));
+    }
+    Compiled c = compile_spec(S);
+    m->spec = std::move(S); m->c = std::move(c);
+  });
+}
+
+int tsim_model_table_offset(const tsim_model* m, int kind, const char* key0, const char* key1, int field) {
+  if (!m || !key0) { tsim_fail_("tsim_model_table_offset: null argument"); return -1; }
+  if (!m->has_spec) { tsim_fail_("tsim_model_table_offset: the model was loaded from a blob file and has no description"); return -1; }
+  const std::vector<int32_t>& I = m->c.I;
+  if (kind == TSIM_TAB_PAIR && key1 && field >= 0 && field < 8) {
+    for (size_t n = 0; n < m->c.pair_keys.size(); ++n) if (m->c.pair_keys[n].first == key0 && m->c.pair_keys[n].second == key1)
+      return I[TSIM_IH_FOFF_PAIR] + (int)n * TSIM_PF_SIZE + (field < 4 ? TSIM_PF_KN + field : TSIM_PF_SHAPE + field - 4);
+  } else if (kind == TSIM_TAB_SENSOR && field >= 0 && field < 4) {
+    for (size_t n = 0; n < m->c.sensors.size(); ++n) if (m->c.sensors[n].name == key0) return I[TSIM_IH_FOFF_SENSOR] + (int)n * TSIM_SF_SIZE + TSIM_SF_KN + field;
+  } else if (kind == TSIM_TAB_DOF) {
+    auto it = m->c.dof_of_joint.find(key0);
+    if (it != m->c.dof_of_joint.end() && field >= 0 && field < it->second.second) return I[TSIM_IH_FOFF_DOF] + (it->second.first + field) * TSIM_DF_SIZE + TSIM_DF_DAMPING;
+  }
+  tsim_fail_("tsim_model_table_offset: no such record");
+  return -1;
+}
+
+}  // extern "C"

@@ -63,7 +63,9 @@ HIP_FLAGS = ["--offload-arch=gfx950", "-Os", "-std=c++17", "-fPIC", "-fno-slp-ve
 HIP_UNITS = [("tsim_hip.hip", []), ("tsim_static_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),
              ("tsim_param_pusher.hip", ["-ffinite-math-only", "-fno-signed-zeros", "-O2"]),      # the same kernels, parameters at run time (tsim_static.h ts_F)
              ("tsim_static_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"]),      # (closed-loop instantiations: 76 KB at -O2, stay at -Os)
-             ("tsim_param_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"])]       # ... of the structure-static kernels (round 6: closed loop with per-environment tables)
+             ("tsim_param_pusher_policy.hip", ["-ffinite-math-only", "-fno-signed-zeros"]),       # ... of the structure-static kernels (round 6: closed loop with per-environment tables)
+             ("tsim_model.cpp", ["-ffp-contract=off"])]                                           # host only: the model loader (include/tsim_model.h); plain double arithmetic, no contraction
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC"]      # units that are not .hip: no device code
 
 
 def hip_build_commands(hipcc, out_so=None):
@@ -73,7 +75,7 @@ def hip_build_commands(hipcc, out_so=None):
     cmds, objs = [], []
     for src, extra in HIP_UNITS:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
-        cmds.append(([hipcc] + HIP_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj], CSRC))
+        cmds.append(([hipcc] + (HIP_FLAGS if src.endswith(".hip") else HOST_FLAGS) + extra + ["-c", os.path.join(CSRC, src), "-o", obj], CSRC))
         objs.append(obj)
     cmds.append(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_so] + objs, CSRC))
     return bdir, cmds
@@ -81,12 +83,12 @@ def hip_build_commands(hipcc, out_so=None):
 
 def hip_sources():
     """Every source next to the library (a new header cannot be forgotten) + the three public headers."""
-    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    return [os.path.join(CSRC, f) for f in srcs] + [os.path.join(INCLUDE, f) for f in ("tsim.h", "tsim_blob.h", "tsim_env.h")]
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    return [os.path.join(CSRC, f) for f in srcs] + [os.path.join(INCLUDE, f) for f in ("tsim.h", "tsim_blob.h", "tsim_env.h", "tsim_model.h")]
 
 
 def hip_digest():
-    return digest(hip_sources(), HIP_FLAGS + [u + ":" + " ".join(f) for u, f in HIP_UNITS])
+    return digest(hip_sources(), HIP_FLAGS + HOST_FLAGS + [u + ":" + " ".join(f) for u, f in HIP_UNITS])
 
 
 # ---------------------------------------------------------------------------------------------------- what the built kernels use

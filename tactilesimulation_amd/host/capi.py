@@ -45,6 +45,14 @@ _SIGS = {
     "tsim_set_solver_options": (C.c_int, [_vp, C.c_int, C.c_int]),
     "tsim_last_gnorm": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "tsim_last_error": (C.c_char_p, []),
+    # include/tsim_model.h — the model loader (host code)
+    "tsim_model_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]), "tsim_model_free": (None, [_vp]),
+    "tsim_model_blob": (C.c_int, [_vp, C.POINTER(_ip), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_int)]),
+    "tsim_model_save_blob": (C.c_int, [_vp, C.c_char_p]), "tsim_model_load_blob": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "tsim_batch_create_from_model": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "tsim_model_image_pos": (C.c_int, [_vp, C.c_char_p, _ip, C.c_int]),
+    "tsim_model_update": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_int]),
+    "tsim_model_table_offset": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
     # include/tsim_env.h — TactilePush per-step formulas
     "tsim_push_action": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "tsim_push_action_backward": (C.c_int, [C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

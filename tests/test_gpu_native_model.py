@@ -1,0 +1,81 @@
+"""A batch created through the model loader of the C ABI (include/tsim_model.h: tsim_model_load + tsim_batch_create_from_model — what a C host
+calls in place of redmax_py.Simulation(model_path), envs/redmax_torch_env.py:33) simulates what the batch of the Python-compiled model does:
+the same bits where the two blobs are the same bits (the repository's own small models), and the fp64 oracle's trajectory."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tactilesimulation_amd.model.compiler import load_model
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = {"slider_push": (np.zeros(4), lambda r: np.array([r.uniform(0.2, 1.0)])),
+         "pad_press": (np.array([0.0, 0.0, -1e-3, 0.0, 0.0, 0.0]), lambda r: np.zeros(0)),
+         "joint_laws": (np.array([0.02, 0.0, 0.3]), lambda r: np.array([r.uniform(-1, 1), r.uniform(-1, 1), r.uniform(-1.5, 1.5)])),
+         "sphere_rest": (np.array([0.0, 0.0, -1.3e-4]), lambda r: np.array([r.uniform(-0.2, 0.9), r.uniform(-0.4, 0.4), r.uniform(-0.3, 0.5)]))}
+
+
+def _native_batch(nm, py, B_, dtype, tape):
+    """a BatchSim whose handle comes from tsim_batch_create_from_model"""
+    from tactilesimulation_amd.host import capi
+    from tactilesimulation_amd.host.batch import BatchSim
+    sim = BatchSim(py, B_, dtype=dtype, tape_capacity=tape)
+    capi.lib().tsim_batch_destroy(sim._h)
+    sim._h = nm.create_batch_handle(B_, tape, capi.TSIM_F32 if dtype == torch.float32 else capi.TSIM_F64, torch.cuda.current_device())
+    L = capi.lib()
+    assert (L.tsim_ndof_r(sim._h), L.tsim_ndof_u(sim._h), L.tsim_ndof_var(sim._h), L.tsim_ndof_tactile(sim._h)) == (py.ndof_r, py.ndof_u, py.ndof_var, py.ndof_tactile)
+    assert L.tsim_timestep(sim._h) == py.h
+    return sim
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_natively_loaded_model_simulates_like_the_python_compiled_one(name, dtype):
+    from tactilesimulation_amd.host.batch import BatchSim
+    from tactilesimulation_amd.host.native_model import NativeModel
+    path = os.path.join(HERE, "models", name + ".xml")
+    nm, py = NativeModel(path), load_model(path)
+    I, F = nm.blob()
+    assert np.array_equal(I, py.I) and F.tobytes() == py.F.tobytes()      # (no meshes, axis-aligned frames: the two compilers agree to the bit)
+    q0c, us = CASES[name]
+    B_, T, S = 8, 8, 4
+    rng = np.random.default_rng(3)
+    q0 = torch.tensor(np.tile(q0c, (B_, 1)) + 1e-3 * rng.normal(size=(B_, q0c.size)), device="cuda", dtype=dtype)
+    u = torch.tensor(np.stack([[us(rng) for _ in range(T)] for _ in range(B_)]).reshape(B_, T, py.ndof_u), device="cuda", dtype=dtype)
+    a, b = BatchSim(py, B_, dtype=dtype, tape_capacity=T * S), _native_batch(nm, py, B_, dtype, T * S)
+    wq = torch.tensor(rng.normal(size=(B_, py.ndof_r)), device="cuda", dtype=dtype)
+    for sim in (a, b):
+        sim.reset(q0, None, backward_flag=True)
+    for t in range(T):
+        oa, ob = a.step(u[:, t], S, want_qd=True), b.step(u[:, t], S, want_qd=True)
+        for k in oa:
+            assert torch.equal(oa[k], ob[k]), (name, t, k)
+    ga, gb = a.backward_steps(T * S, df_dq=wq), b.backward_steps(T * S, df_dq=wq)      # (seed on the last sub-step, as StepSimFunction.backward)
+    assert torch.equal(ga, gb) and torch.isfinite(ga).all()
+    assert py.ndof_u == 0 or ga.abs().max() > 0
+
+
+def test_natively_loaded_model_follows_the_oracle():
+    """... and the oracle (fp64, one environment at a time) on the blob the native loader made"""
+    import copy
+    from oracle.oracle import OracleSim
+    from tactilesimulation_amd.host.native_model import NativeModel
+    path = os.path.join(HERE, "models", "slider_push.xml")
+    nm, py = NativeModel(path), load_model(path)
+    m = copy.copy(py)
+    m.I, m.F = nm.blob()
+    B_, T, S = 4, 10, 4
+    rng = np.random.default_rng(5)
+    q0 = 1e-3 * rng.normal(size=(B_, py.ndof_r))
+    u = rng.uniform(0.2, 1.0, size=(B_, T, py.ndof_u))
+    sim = _native_batch(nm, py, B_, torch.float64, T * S)
+    sim.reset(torch.tensor(q0, device="cuda"), None, backward_flag=False)
+    o = OracleSim(m)
+    traj = [sim.step(torch.tensor(u[:, t], device="cuda"), S)["q"].cpu().numpy() for t in range(T)]
+    for e in range(B_):
+        o.reset(q0[e])
+        for t in range(T):
+            assert o.forward(u[e, t], S) == 0
+            assert np.allclose(traj[t][e], o.state()[0], rtol=0, atol=1e-9), (e, t)

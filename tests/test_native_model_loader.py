@@ -1,0 +1,333 @@
+"""The model loader behind the C ABI (include/tsim_model.h, csrc/tsim_model.cpp) against the Python model compiler (model/compiler.py).
+
+What a C / C++ host calls in place of `redmax_py.Simulation(model_path)` (envs/redmax_torch_env.py:33) and the update_* family.
+The two compilers must produce the same ints and the same reals to round-off of the host's double arithmetic (the Python one goes through
+numpy / BLAS products, the native one through plain double arithmetic: last-bit differences, bounded here at 1e-12 relative / 1e-15 absolute).
+No GPU: the loader is host code.  The models of the reference are read where /root/reference exists (this container); the synthetic
+models written here cover every body / joint / contact / sensor kind of the format everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+REF_XMLS = ["envs/assets/pusher/pusher.xml", "envs/assets/tactile_insertion/tactile_insertion.xml", "envs/assets/stable_grasp/stable_grasp.xml",
+            "envs/assets/dclaw_rotate/dclaw_position_control.xml", "envs/assets/dclaw_rotate/dclaw_torque_control.xml", "assets/tactile_pad/tactile_pad.xml"]
+
+
+def _native(path):
+    from tactilesimulation_amd.host.native_model import NativeModel
+    return NativeModel(path)
+
+
+def _python(path):
+    from tactilesimulation_amd.model.compiler import parse_xml, compile_spec
+    return compile_spec(parse_xml(path))
+
+
+def _same_blob(I, F, py):
+    assert I.dtype == np.int32 and F.dtype == np.float64
+    assert np.array_equal(I, py.I), np.nonzero(I != py.I)[0][:10]
+    assert F.shape == py.F.shape
+    bad = np.nonzero(~np.isclose(F, py.F, rtol=1e-12, atol=1e-15))[0]
+    assert len(bad) == 0, (bad[:10], F[bad[:10]], py.F[bad[:10]])
+
+
+def _same_lookups(nm, py):
+    from tactilesimulation_amd.host.native_model import PAIR_FIELDS
+    for s in py.meta["sensor_names"]:
+        assert nm.image_pos(s) == [tuple(t) for t in py.meta["image_pos"][s]]
+        for f in ("kn", "kt", "mu", "damping"):
+            assert nm.table_offset("sensor", s, field=f) == py.table_offset("sensor", s, f)
+    for k0, k1 in py.meta["pair_keys"]:
+        for f in PAIR_FIELDS:
+            assert nm.table_offset("pair", k0, k1, f) == py.table_offset("pair", (k0, k1), f)
+    for j, (d0, nd) in py.meta["dof_of_joint"].items():
+        for k in range(nd):
+            assert nm.table_offset("dof", j, field=k) == py.table_offset("dof", (j, k), "damping")
+
+
+@pytest.mark.parametrize("rel", REF_XMLS)
+def test_reference_models_compile_to_the_same_blob(rel):
+    path = os.path.join(REF, rel)
+    if not os.path.exists(path):
+        pytest.skip("reference assets not on this machine")
+    nm, py = _native(path), _python(path)
+    I, F = nm.blob()
+    _same_blob(I, F, py)
+    _same_lookups(nm, py)
+
+
+def test_reference_models_match_the_committed_assets():
+    """... and therefore the blobs every other test of this repository simulates (tactilesimulation_amd/assets/*.npz, compiled by the Python compiler)"""
+    from tactilesimulation_amd import workloads as W
+    from tactilesimulation_amd.model.compiler import load_model
+    n = 0
+    for rel in REF_XMLS:
+        name = os.path.splitext(os.path.basename(rel))[0]
+        path = os.path.join(REF, rel)
+        if not os.path.exists(path) or not os.path.exists(W.asset(name)):
+            continue
+        I, F = _native(path).blob()
+        _same_blob(I, F, load_model(W.asset(name)))
+        n += 1
+    if n == 0:
+        pytest.skip("reference assets not on this machine")
+    assert n >= 5
+
+
+def test_the_repositorys_own_small_models_compile_to_the_same_bits():
+    """tests/models/*.xml (no meshes, axis-aligned frames): not one bit between the two compilers — the GPU test of the loader
+    (tests/test_gpu_native_model.py) relies on it to compare trajectories bit for bit"""
+    import glob
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "*.xml")))
+    assert len(paths) >= 8
+    for path in paths:
+        nm, py = _native(path), _python(path)
+        I, F = nm.blob()
+        assert np.array_equal(I, py.I) and F.tobytes() == py.F.tobytes(), path
+        _same_lookups(nm, py)
+
+
+# --------------------------------------------------------------------------------------------------------------- synthetic models
+CUBE_OBJ = """\
+# unit-ish box 0.04 x 0.02 x 0.06 with quads, one face given by negative indices, texture / normal references
+v -0.02 -0.01 -0.03
+v  0.02 -0.01 -0.03
+v  0.02  0.01 -0.03
+v -0.02  0.01 -0.03
+v -0.02 -0.01  0.03
+v  0.02 -0.01  0.03
+v  0.02  0.01  0.03
+v -0.02  0.01  0.03
+vn 0 0 1
+f 4/1/1 3/1/1 2/1/1 1/1/1
+f 5 6 7 8
+f 1//1 2//1 6//1 5//1
+f 2 3 7 6
+f 3 4 8 7
+f -5 -8 -4 -1
+"""
+
+PAD_POINTS = "5 points\n" + "\n".join("%g %g %g" % p for p in [(0.0, 0.0, 0.002), (0.004, 0.004, 0.002), (-0.004, 0.004, 0.002), (0.004, -0.004, 0.002), (-0.004, -0.004, 0.002)]) + "\n"
+
+TAXELS = "4\n" + "\n".join('"%g %g 0.002" "%d %d" "0 0 1" "1 0 0" "0 1 0"' % (x, y, r, c) for (x, y, r, c) in
+                           [(-0.003, -0.003, 0, 0), (0.003, -0.003, 0, 1), (-0.003, 0.003, 1, 0), (0.003, 0.003, 2, 1)]) + "\n"
+
+MODEL_A = """\
+<?xml version="1.0" encoding="utf-8"?>
+<!-- a pad on a planar + revolute carriage pushing a puck and a ball; every primitive kind, a mesh, fixed-joint merging -->
+<redmax model='synthetic &amp; small'>
+    <option integrator="BDF1" timestep="4e-3" unit="m-kg" gravity="0. 0. -9.8"/>
+    <solver_option tol="1e-9" max_iter="60" max_ls="12"/>
+    <ground pos="0 0 0" normal="0 0.01 1"/>
+    <default>
+        <joint lim_stiffness="25" damping="1.5"/>
+        <general_primitive_contact kn="4e3" kt="4." mu="1.2" damping="50"/>
+        <ground_contact kn="2e3" kt="2" mu="0.7" damping="0.4"/>
+        <tactile kn="90" kt="7." mu="0.9" damping="9"/>
+        <motor P="8." D="0.2" ctrl_range="-2 2" ctrl="force"/>
+    </default>
+    <robot>
+        <link name="carriage">
+            <joint name = "carriage_xy" type = "planar" axis0="1 0 0" axis1="0 2 0" pos = "0.01 0 0.1" quat = "1 0 0 0"/>
+            <body name = "carriage_body" type = "mesh" filename="box.obj" pos = "0 0 0.01" quat = "0.924 0 0 0.383" density = "800" transform_type="OBJ_TO_JOINT"/>
+            <link name="yaw">
+                <joint name="yaw" type="revolute" axis="0 0 3" pos="0 0 -0.02" quat="1 0 0 0" lim="-1.2 1.2" damping="0.5"/>
+                <body name="yaw_body" type="cuboid" size="0.01 0.012 0.014" pos="0 0.001 0" quat="1 0 0 0" density="50"/>
+                <link name="bracket">
+                    <joint name="bracket_fixed" type="fixed" pos="0 0 -0.03" quat="0.707 0 0.707 0"/>
+                    <body name="bracket_body" type="mesh" filename="box.obj" pos="0.01 0 0.05" quat="1 0 0 0" transform_type="OBJ_TO_WORLD"/>
+                    <link name="pad">
+                        <joint name="pad_fixed" type="fixed" pos="0.002 0 0.01" quat="1 0 0 0"/>
+                        <body name="pad" type="cylinder" density="2" radius="0.015" length="0.004" pos="0 0 0" quat="1 0 0 0" general_contact_angle_resolution="6" general_contact_radius_resolution="3"/>
+                    </link>
+                    <link name="slider">
+                        <joint name="slider" type="prismatic" axis="1 0 0" pos="0 0.02 0" quat="1 0 0 0" lim="-0.01 0.02" lim_stiffness="40"/>
+                        <body name="slider_body" type="abstract" mass="0.02" inertia="1e-6 2e-6 3e-6" pos="0 0 0.001" quat="0.966 0.259 0 0">
+                            <collision contacts="pad_points.txt" pos="0 0 0.001" quat="1 0 0 0"/>
+                        </body>
+                    </link>
+                </link>
+            </link>
+        </link>
+    </robot>
+    <robot>
+        <link name="puck">
+            <joint name="puck" type="free3d-euler" pos="0.06 0 0.0251" quat="1 0 0 0" damping="0.01"/>
+            <body name="puck" type="cuboid" size="0.05 0.04 0.05" pos="0 0 0" quat="1 0 0 0" density="500" general_contact_resolution="3 2 3"/>
+        </link>
+        <link name="ball">
+            <joint name="ball" type="free3d-exp" pos="-0.05 0.03 0.0152" quat="1 0 0 0"/>
+            <body name="ball" type="sphere" radius="0.015" pos="0 0 0" quat="1 0 0 0" density="300"/>
+        </link>
+        <link name="post">
+            <joint name="post" type="translational" pos="0.1 0.1 0.03" quat="1 0 0 0" damping="3"/>
+            <body name="post" type="cylinder" radius="0.01" length="0.06" pos="0 0 0" quat="1 0 0 0" density="700"/>
+        </link>
+    </robot>
+    <contact>
+        <ground_contact body="puck"/>
+        <ground_contact body="ball" kn="3e3" mu="0.5"/>
+        <ground_contact body="post" damping="0.2"/>
+        <general_primitive_contact general_body="pad" primitive_body="puck" kn="1e2" kt="8." mu="1." damping="10"/>
+        <general_primitive_contact general_body="pad" primitive_body="ball"/>
+        <general_primitive_contact general_body="slider_body" primitive_body="post" mu="0.3"/>
+    </contact>
+    <actuator>
+        <motor joint="carriage_xy" ctrl="force" ctrl_range="-1 1"/>
+        <motor joint="yaw"/>
+        <motor joint="slider" ctrl="position" P="20" D="0.5" ctrl_range="-0.01 0.02"/>
+        <motor joint="puck" ctrl="force" ctrl_range="-0.1 0.1"/>
+    </actuator>
+    <sensor>
+        <tactile body="pad" name="pad_array" type="rect_array" rect_pos0="0.006 0.005 0.002" rect_pos1="-0.006 -0.005 0.002" axis0="-1 0 0" axis1="0 -2 0" resolution="5 4" kn="120"/>
+        <tactile body="slider_body" name="slider_skin" type="abstract" spec="skin_taxels.txt" pos="0 0 0.0005" quat="1 0 0 0" mu="1.1"/>
+    </sensor>
+    <variable>
+        <endeffector joint="pad_fixed" pos="-0.005 0 0"/>
+        <endeffector joint="puck" pos="-0.025 0 0" name="puck_face"/>
+    </variable>
+    <virtual>
+        <cuboid name="goal" pos="1 0 0.025" quat="1 0 0 0" size="0.05 0.05 0.05"/>
+    </virtual>
+</redmax>
+"""
+
+MODEL_B = """\
+<redmax model="bare">
+    <robot>
+        <link name="a">
+            <joint name="a" type="revolute" axis="0 1 0" pos="0 0 0.2"/>
+            <body name="a" type="cuboid" size="0.02 0.02 0.1" pos="0 0 -0.05"/>
+            <link name="b">
+                <joint name="b" type="revolute" axis="0 1 0" pos="0 0 -0.1" quat="0.9 0.1 0 0"/>
+                <body name="b" type="sphere" radius="0.02" pos="0 0 -0.05" density="10"/>
+            </link>
+        </link>
+    </robot>
+</redmax>
+"""
+
+
+@pytest.fixture()
+def model_dir(tmp_path):
+    for name, text in (("a.xml", MODEL_A), ("b.xml", MODEL_B), ("box.obj", CUBE_OBJ), ("pad_points.txt", PAD_POINTS), ("skin_taxels.txt", TAXELS)):
+        (tmp_path / name).write_text(text)
+    return tmp_path
+
+
+def test_synthetic_models_compile_to_the_same_blob(model_dir):
+    from tactilesimulation_amd.model import blob as B
+    for name in ("a.xml", "b.xml"):
+        path = str(model_dir / name)
+        nm, py = _native(path), _python(path)
+        I, F = nm.blob()
+        _same_blob(I, F, py)
+        _same_lookups(nm, py)
+    py = _python(str(model_dir / "a.xml"))
+    # the model is what it was written to be: 2 + 1 + 1 + (3 + 1 + 1 + 1) + (3 + 3) + 3 dofs, fixed joints merged, both sensor kinds
+    assert py.ndof_r == 19 and py.ndof_u == 2 + 1 + 1 + 6 and py.I[B.TSIM_IH_NSENSOR] == 2 and py.I[B.TSIM_IH_NPAIR] == 6 and py.ndof_var == 6
+    assert py.meta["sensor_taxels"][1][2:] == (3, 2)      # abstract sensor: rows / cols from the largest image position
+
+
+def test_mesh_mass_properties_known_answer(model_dir):
+    """the OBJ is a 0.04 x 0.02 x 0.06 box: volume, centre and inertia of the first link (density 800, rotated 45 degrees about z, lifted 0.01) by hand"""
+    from tactilesimulation_amd.model import blob as B
+    I, F = _native(str(model_dir / "a.xml")).blob()
+    lf = F[I[B.TSIM_IH_FOFF_LINK]:][:B.TSIM_LF_SIZE]
+    m = 800 * 0.04 * 0.02 * 0.06
+    assert abs(lf[B.TSIM_LF_MASS] - m) < 1e-15
+    assert np.allclose(lf[B.TSIM_LF_COM:B.TSIM_LF_COM + 3], [0, 0, 0.01], atol=1e-15)
+    ixx, iyy, izz = m / 12 * (0.02 ** 2 + 0.06 ** 2), m / 12 * (0.04 ** 2 + 0.06 ** 2), m / 12 * (0.04 ** 2 + 0.02 ** 2)
+    q = np.array([0.924, 0, 0, 0.383]); q /= np.linalg.norm(q)
+    c, s = 1 - 2 * q[3] ** 2, 2 * q[0] * q[3]
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+    Ic = R @ np.diag([ixx, iyy, izz]) @ R.T
+    got = lf[B.TSIM_LF_INERTIA:B.TSIM_LF_INERTIA + 6]
+    assert np.allclose(got, [Ic[0, 0], Ic[1, 1], Ic[2, 2], Ic[0, 1], Ic[0, 2], Ic[1, 2]], rtol=1e-12, atol=1e-18)
+
+
+UPDATES = [("joint_damping", "yaw", [0.75], None), ("joint_location", "slider", [0.001, 0.021, -0.002], None), ("body_density", "puck", [650.0], None),
+           ("body_size", "puck", [0.045, 0.05, 0.04], None), ("body_size", "ball", [0.012], None), ("body_size", "post", [0.05, 0.008], None),
+           ("endeffector_position", "puck_face", [-0.02, 0.001, 0.0], None), ("contact_parameters", "pad", [150.0, float("nan"), 0.8, float("nan")], "puck"),
+           ("tactile_parameters", "pad", [float("nan"), 6.0, float("nan"), 12.0], None), ("tactile_parameters", "slider_skin", [70.0, 5.0, 1.0, 8.0], None),
+           ("virtual_object", "goal", [0.5, 0.1, 0.025, 1, 0, 0, 0], None)]
+
+
+def test_updates_recompile_like_the_python_spec_edits(model_dir):
+    """the update_* family (envs/dclaw_rotate_env.py:173-178, envs/stable_grasp_env.py:122, envs/tactile_insertion_env.py:254-279): edits accumulate"""
+    from tactilesimulation_amd.model.compiler import parse_xml, compile_spec, edit_spec
+    path = str(model_dir / "a.xml")
+    nm, spec = _native(path), parse_xml(path)
+    before = nm.blob()
+    for what, name, vals, name2 in UPDATES:
+        nm.update(what, name, vals, name2)
+        if what in ("contact_parameters", "tactile_parameters"):
+            kw = {k: (None if np.isnan(v) else v) for k, v in zip(("kn", "kt", "mu", "damping"), vals)}
+            edit_spec(spec, what, (name, name2) if name2 else name, **kw)
+        else:
+            edit_spec(spec, what, name, vals[0] if what in ("joint_damping", "body_density") else vals)
+        I, F = nm.blob()
+        _same_blob(I, F, compile_spec(spec))
+    assert not np.array_equal(before[1], nm.blob()[1])
+
+
+def test_a_failed_update_leaves_the_model_unchanged(model_dir):
+    nm = _native(str(model_dir / "a.xml"))
+    I0, F0 = nm.blob()
+    for what, name, vals, name2, msg in (("joint_damping", "no_such_joint", [1.0], None, "unknown joint"), ("body_size", "slider_body", [1.0], None, "abstract"),
+                                         ("contact_parameters", "pad", [1, 1, 1, 1], "post", "no general_primitive_contact"), ("body_size", "puck", [1.0], None, "3 values"),
+                                         ("endeffector_position", "nowhere", [0, 0, 0], None, "unknown endeffector"), ("tactile_parameters", "puck", [1, 1, 1, 1], None, "no tactile sensor")):
+        with pytest.raises(RuntimeError, match=msg):
+            nm.update(what, name, vals, name2)
+    I1, F1 = nm.blob()
+    assert np.array_equal(I0, I1) and np.array_equal(F0, F1)
+    with pytest.raises(KeyError):
+        nm.table_offset("pair", "pad", "post", "kn")
+    with pytest.raises(RuntimeError, match="unknown tactile sensor"):
+        nm.image_pos("nope")
+
+
+def test_blob_file_round_trip(model_dir, tmp_path):
+    nm = _native(str(model_dir / "a.xml"))
+    out = str(tmp_path / "a.tsimblob")
+    nm.save_blob(out)
+    again = _native(out)
+    I0, F0 = nm.blob()
+    I1, F1 = again.blob()
+    assert np.array_equal(I0, I1) and F0.tobytes() == F1.tobytes()
+    assert os.path.getsize(out) == 16 + 4 * len(I0) + 8 * len(F0)
+    with pytest.raises(RuntimeError, match="no description"):
+        again.update("joint_damping", "yaw", [1.0])
+    raw = open(out, "rb").read()
+    (tmp_path / "short.tsimblob").write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(RuntimeError, match="truncated"):
+        _native(str(tmp_path / "short.tsimblob"))
+    (tmp_path / "magic.tsimblob").write_bytes(b"\0\0\0\0" + raw[4:])
+    with pytest.raises(RuntimeError, match="magic"):
+        _native(str(tmp_path / "magic.tsimblob"))
+
+
+@pytest.mark.parametrize("text,msg", [
+    ("<mujoco/>", "not a redmax model"),
+    ("<redmax><robot><link name='l'><joint name='j' type='revolute'/></link></robot></redmax>", "needs one <joint> and one <body>"),
+    ("<redmax><robot><link name='l'><joint name='j' type='hinge'/><body name='b' type='sphere' radius='1'/></link></robot></redmax>", "joint type 'hinge'"),
+    ("<redmax><robot><link name='l'><joint name='j' type='revolute'/><body name='b' type='capsule'/></link></robot></redmax>", "body type 'capsule'"),
+    ("<redmax><robot><link name='l'><joint name='j' type='revolute' pos='0 0'/><body name='b' type='sphere' radius='1'/></link></robot></redmax>", "expected 3 numbers"),
+    ("<redmax><option unit='cm-g'/></redmax>", "m-kg"),
+    ("<redmax><robot><link name='l'><joint name='j' type='revolute'/><body name='b' type='sphere' radius='1'/></link></robot><contact><ground_contact body='b'/></contact></redmax>", "without <ground>"),
+    ("<redmax><robot><link name='l'><joint name='j' type='revolute'/><body name='b' type='mesh' filename='missing.obj'/></link></robot></redmax>", "cannot open mesh"),
+    ("<redmax><robot><link name='l'>", "XML"),
+    ("<redmax><option integrator='RK4'/></redmax>", "integrator 'RK4'"),
+])
+def test_bad_models_fail_with_a_reason(tmp_path, text, msg):
+    p = tmp_path / "bad.xml"
+    p.write_text(text)
+    with pytest.raises(RuntimeError, match=msg):
+        _native(str(p))
+
+
+def test_missing_file():
+    with pytest.raises(RuntimeError, match="cannot open"):
+        _native("/nonexistent/model.xml")
