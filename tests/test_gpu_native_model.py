@@ -79,3 +79,40 @@ def test_natively_loaded_model_follows_the_oracle():
         for t in range(T):
             assert o.forward(u[e, t], S) == 0
             assert np.allclose(traj[t][e], o.state()[0], rtol=0, atol=1e-9), (e, t)
+
+
+def test_plain_c_host_runs_the_same_trajectory(tmp_path):
+    """examples/c_host/step_from_xml.c — a C program with nothing but include/tsim.h, include/tsim_model.h and the HIP runtime (no Python,
+    no torch in the process) — loads the XML, steps B environments and differentiates; its printed fp64 numbers are the Python host's, digit for digit."""
+    import shutil
+    import subprocess
+    from tactilesimulation_amd.host import capi
+    from tactilesimulation_amd.host.batch import BatchSim
+    root = os.path.dirname(HERE)
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no C compiler / HIP headers on this machine")
+    exe = str(tmp_path / "step_from_xml")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_host", "step_from_xml.c"), "-o", exe, "-L" + libdir, "-ltsim_hip", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, text=True)
+    xml = os.path.join(HERE, "models", "slider_push.xml")
+    B_, T, S, uval = 8, 6, 5, 0.6
+    r = subprocess.run([exe, xml, str(B_), str(T), str(uval)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    py = load_model(xml)
+    assert lines[0].startswith("model ") and "ndof_r %d ndof_u %d ndof_var %d ndof_tactile %d" % (py.ndof_r, py.ndof_u, py.ndof_var, py.ndof_tactile) in lines[0] and "generic" in lines[0]
+    sim = BatchSim(py, B_, dtype=torch.float64, tape_capacity=T * S)
+    sim.reset(torch.zeros(B_, py.ndof_r, device="cuda", dtype=torch.float64), None, backward_flag=True)
+    u = torch.tensor([[uval * (1.0 + 0.1 * e)] * py.ndof_u for e in range(B_)], device="cuda", dtype=torch.float64)
+    for t in range(T):
+        q = sim.step(u, S)["q"].cpu().numpy()
+        a, b = lines[1 + t].split(" | ")
+        assert a.split()[:3] == ["step", str(t), "q[0]"] and b.split()[0] == "q[%d]" % (B_ - 1)
+        assert [float(x) for x in a.split()[3:]] == q[0].tolist() and [float(x) for x in b.split()[1:]] == q[-1].tolist(), t
+    assert lines[1 + T] == "non-converged environments in the last step: 0"
+    du = sim.backward_steps(T * S, df_dq=torch.ones(B_, py.ndof_r, device="cuda", dtype=torch.float64)).cpu().numpy()
+    got = [float(x) for x in lines[2 + T].split()[1:]]
+    assert got == du[0].reshape(-1).tolist() and max(abs(g) for g in got) > 0
