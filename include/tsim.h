@@ -184,7 +184,8 @@ int tsim_set_lanes_per_env(tsim_batch* b, int lanes);   /* host-side only: takes
  * whose compiled blob it was built with (csrc/tsim_static.h; round 4: TactilePush, envs/assets/pusher/pusher.xml): tree, joint types, joint
  * frames and axes, contact pairs, dof records are compile-time constants there and the whole residual evaluation is one register-resident
  * pass (csrc/tsim_static_eval.h).  They are used when the
- * batch's blob equals the compiled-in one bit for bit (checked at tsim_batch_create / tsim_update_model), the batch is fp32 and has no
+ * batch's blob equals the compiled-in one (checked at tsim_batch_create / tsim_update_model: ints and float records bit for bit — for an fp32
+ * batch the records AS FLOATS, which is all its kernels ever see of them; round 5 added fp64 instantiations) and the batch has no
  * per-environment tables; results equal the generic kernels' to fp32 rounding (tests/test_gpu_static_model.py).
  * tsim_static_model returns the id of the instantiation the NEXT launch will use (0: generic, 1: TactilePush); tsim_set_static(b, 0)
  * keeps a batch on the generic kernels (also: environment variable TSIM_NO_STATIC at creation), tsim_set_static(b, 1) allows them again. */

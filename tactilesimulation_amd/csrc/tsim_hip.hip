@@ -579,7 +579,13 @@ template <class MS> static bool blob_equals_static(const tsim_batch* b) {
     return false;
   };
   for (int i = 0; i < MS::NI; ++i) if (b->I[i] != MS::Iv(i) && !taxel_layout(i)) return false;
-  for (int i = 0; i < MS::NFREC; ++i) if (std::memcmp(&b->F[i], (const double[]){MS::Fv(i)}, sizeof(double)) != 0) return false;
+  // fp64 batches: the doubles, bit for bit.  fp32 batches: the FLOATS, bit for bit — the fp32 kernels see a model's reals only after their conversion to
+  // float (upload_model; ts_F casts the compiled-in constant the same way), so a blob that differs from the asset below float resolution (another host's
+  // BLAS in the Python compiler, the native loader of tsim_model.cpp: last bits of mesh-derived mass properties) IS the compiled-in model to them.
+  for (int i = 0; i < MS::NFREC; ++i) {
+    if (b->dtype == TSIM_F32) { const float x = (float)b->F[i], y = (float)MS::Fv(i); if (std::memcmp(&x, &y, sizeof(float)) != 0) return false; }
+    else if (std::memcmp(&b->F[i], (const double[]){MS::Fv(i)}, sizeof(double)) != 0) return false;
+  }
   return true;
 }
 // ... or in its STRUCTURE only: all ints (but the taxel layout) and the structural floats of the compiled asset (TsParam::Fk: exact 0, 1, -1)

@@ -204,3 +204,30 @@ def test_fp64_static_kernels_against_the_generic_fp64_ones(pusher_model, edited)
         x, y = (t.transpose(0, 1).reshape(B, -1) if t.dim() == 3 else t for t in (x, y))
         e = ((x - y).abs().max(1).values / y.abs().max(1).values.clamp_min(1e-30)).cpu().numpy()
         assert np.median(e) < 1e-10 and (e < 1e-7).mean() > 0.995, (name, float(np.median(e)), float((e < 1e-7).mean()), float(e.max()))
+
+
+def test_a_blob_that_differs_below_float_resolution_is_the_compiled_in_model_to_an_fp32_batch(pusher_model):
+    """Last-bit differences of the doubles (another host's BLAS in the Python compiler; the native loader, include/tsim_model.h, on the mesh-derived
+    mass properties of pusher.xml) do not reach an fp32 kernel: the batch stays on the fully static instantiation and not one output bit moves.
+    An fp64 batch sees them and takes the structure-static kernels."""
+    import copy
+    m = copy.deepcopy(pusher_model)
+    fl = int(m.I[BL.TSIM_IH_FOFF_LINK])
+    for k in (BL.TSIM_LF_MASS, BL.TSIM_LF_COM, BL.TSIM_LF_INERTIA, BL.TSIM_LF_INERTIA + 3):
+        i = fl + BL.TSIM_LF_SIZE + k
+        m.F[i] = np.nextafter(m.F[i], np.inf)
+    assert (m.F != pusher_model.F).sum() == 4 and np.array_equal(m.F.astype(np.float32), pusher_model.F.astype(np.float32))
+    B, T, S = 256, 6, 5
+    q0, u, _ = push_workload(B, T, seed=3)
+    outs = []
+    for mod in (pusher_model, m):
+        sim = BatchSim(mod, B, dtype=torch.float32, tape_capacity=T * S)
+        assert sim.kernel_variant() == "static:pusher"
+        sim.reset(torch.tensor(q0, device=DEV, dtype=torch.float32), None, backward_flag=True)
+        o = sim.rollout(torch.tensor(u, device=DEV, dtype=torch.float32).transpose(0, 1).contiguous(), S)
+        g = sim.backward_episode(T, S, df_dq=torch.ones(T, B, 7, device=DEV))
+        outs.append((o["q"], o["tactile"], g[0] if isinstance(g, (tuple, list)) else g))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert BatchSim(m, 8, dtype=torch.float64, tape_capacity=8).kernel_variant() == "param:pusher"
+    assert BatchSim(pusher_model, 8, dtype=torch.float64, tape_capacity=8).kernel_variant() == "static:pusher"

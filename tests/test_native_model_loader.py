@@ -76,6 +76,24 @@ def test_reference_models_match_the_committed_assets():
     assert n >= 5
 
 
+def test_native_pusher_is_the_compiled_in_asset_at_float_resolution():
+    """pusher.xml loaded natively differs from assets/pusher.npz (what the fully static kernels were generated from) in the last bits of a few
+    mesh-derived doubles; as floats — all an fp32 kernel sees of a model — the float records are the same bits, which is the host's criterion for
+    keeping an fp32 batch on the static:pusher instantiation (csrc/tsim_hip.hip blob_equals_static; tests/test_gpu_static_model.py)"""
+    from tactilesimulation_amd import workloads as W
+    from tactilesimulation_amd.model import blob as B
+    from tactilesimulation_amd.model.compiler import load_model
+    path = os.path.join(REF, "envs/assets/pusher/pusher.xml")
+    if not os.path.exists(path):
+        pytest.skip("reference assets not on this machine")
+    I, F = _native(path).blob()
+    asset = load_model(W.PUSHER_BLOB)
+    nfrec = int(asset.I[B.TSIM_IH_FOFF_CPT])
+    assert np.array_equal(I, asset.I)
+    assert F[:nfrec].astype(np.float32).tobytes() == asset.F[:nfrec].astype(np.float32).tobytes()
+    assert 0 < (F[:nfrec] != asset.F[:nfrec]).sum() <= 16      # (if this ever becomes 0 the two compilers agree to the bit: fine, relax the bound)
+
+
 def test_the_repositorys_own_small_models_compile_to_the_same_bits():
     """tests/models/*.xml (no meshes, axis-aligned frames): not one bit between the two compilers — the GPU test of the loader
     (tests/test_gpu_native_model.py) relies on it to compare trajectories bit for bit"""
