@@ -402,7 +402,7 @@ Body parse_body(const XNode* be, Spec& S, int jidx, const std::string& base) {
   B.density = attr_d(be, "density", 1.0);
   if (B.type == "cuboid") {
     B.size = v3(floats(be->get("size"), 3));
-    if (const char* r = be->get("general_contact_resolution")) { auto t = tokens(r, false); if (t.size() != 3) throw Err("general_contact_resolution needs 3 integers"); for (int k = 0; k < 3; ++k) B.cres[k] = to_int(t[k]); }
+    if (const char* r = be->get("general_contact_resolution")) { auto t = tokens(r, false); if (t.size() != 3) throw Err("general_contact_resolution needs 3 integers"); for (int k = 0; k < 3; ++k) { B.cres[k] = to_int(t[k]); if (B.cres[k] < 0 || B.cres[k] > 1024) throw Err("general_contact_resolution out of range (0 .. 1024 per axis)"); } }
   } else if (B.type == "sphere") {
     if (!be->get("radius")) throw Err("sphere without radius");
     B.radius = attr_d(be, "radius", 0);
@@ -410,6 +410,7 @@ Body parse_body(const XNode* be, Spec& S, int jidx, const std::string& base) {
     if (!be->get("radius") || !be->get("length")) throw Err("cylinder without radius / length");
     B.radius = attr_d(be, "radius", 0); B.length = attr_d(be, "length", 0);
     B.cyl_res[0] = to_int(attr_s(be, "general_contact_angle_resolution", "8")); B.cyl_res[1] = to_int(attr_s(be, "general_contact_radius_resolution", "2"));
+    if (B.cyl_res[0] < 0 || B.cyl_res[0] > 4096 || B.cyl_res[1] < 0 || B.cyl_res[1] > 4096) throw Err("cylinder contact resolution out of range (0 .. 4096)");
   } else if (B.type == "mesh") {
     if (!be->get("filename")) throw Err("mesh body without filename");
     std::vector<V3> V; std::vector<int> Fc;
@@ -508,6 +509,7 @@ Spec parse_xml(const std::string& path) {
       auto t = tokens(attr_s(e.get(), "resolution"), false);
       if (t.size() != 2) throw Err("tactile resolution needs 2 integers");
       s.res[0] = to_int(t[0]); s.res[1] = to_int(t[1]);
+      if (s.res[0] < 1 || s.res[1] < 1 || (long long)s.res[0] * s.res[1] > (1 << 22)) throw Err("tactile resolution out of range (1 .. 4 194 304 taxels per sensor)");
     } else if (s.type == "abstract") {
       s.pos = v3(floats_or(e.get(), "pos", "0 0 0", 3)); quat4(e.get(), "quat", s.quat);
       s.taxels = read_taxel_spec(base + "/" + attr_s(e.get(), "spec"));

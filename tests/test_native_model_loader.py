@@ -349,3 +349,43 @@ def test_bad_models_fail_with_a_reason(tmp_path, text, msg):
 def test_missing_file():
     with pytest.raises(RuntimeError, match="cannot open"):
         _native("/nonexistent/model.xml")
+
+
+FUZZ = r"""
+import os, random, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import test_native_model_loader as T
+from tactilesimulation_amd.host.native_model import NativeModel
+d = sys.argv[2]
+rng = random.Random(11)
+ok = err = 0
+for it in range(int(sys.argv[3])):
+    s = list(T.MODEL_A)
+    for _ in range(rng.randint(1, 4)):
+        k = rng.randrange(len(s)); op = rng.randrange(5)
+        if op == 0: del s[k:k + rng.randint(1, 30)]
+        elif op == 1: s[k] = rng.choice('<>/"\'= &;-!?0aZ\n')
+        elif op == 2: s.insert(k, rng.choice(['<', '>', '"', '</link>', '<link>', '<!--', '-->', '&amp', '1e999', 'nan', '-', '99999999', '<joint/>', '<body type="mesh"/>']))
+        elif op == 3: s = s[:k]
+        else:
+            j = rng.randrange(len(s)); s[k], s[j] = s[j], s[k]
+    p = os.path.join(d, "m.xml"); open(p, "w").write("".join(s))
+    try:
+        I, F = NativeModel(p).blob(); ok += 1
+        assert I[29] == len(I) and I[30] == len(F)
+    except RuntimeError:
+        err += 1
+print("ok", ok, "err", err)
+"""
+
+
+def test_mangled_models_are_refused_or_loaded_never_a_crash(model_dir):
+    """the loader is C++ inside the product library: whatever the file holds — truncated, unbalanced, numbers out of range — the call returns
+    (an error with a reason, or a model); 500 random manglings of the synthetic model in a child process, whose exit code is the check"""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, "-c", FUZZ, root, str(model_dir), "500"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    ok, err = (int(x) for x in r.stdout.split()[1::2])
+    assert ok + err == 500 and err > 300 and ok > 5
