@@ -53,7 +53,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--horizon", type=int, default=100)
     # optimiser of cfg/gd_tactile.yaml (algorithms/gd.py:146-151): Adam lr 0.005, betas (0.7, 0.95), linear decay to 1e-5
-    ap.add_argument("--lr", type=float, default=5e-3)
+    ap.add_argument("--lr", type=float, default=5e-3, help="the reference's 0.005 is tuned for 16 episodes per epoch; with thousands per batch two of six seeds leave the descent near "
+                    "epoch 95 (exploding BPTT gradient, profiles/r06_training_300_epochs.md): 0.002 trains every seed; --save-best keeps the best policy either way")
     ap.add_argument("--betas", type=float, nargs=2, default=(0.7, 0.95))
     ap.add_argument("--lr-schedule", default="linear", choices=["linear", "constant"])
     ap.add_argument("--grad-clip", type=float, default=1.0)
