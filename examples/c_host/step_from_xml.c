@@ -5,7 +5,7 @@
  *
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host/step_from_xml.c -o step_from_xml \
  *       -Ltactilesimulation_amd/csrc -ltsim_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/tactilesimulation_amd/csrc -Wl,-rpath,/opt/rocm/lib
- *   ./step_from_xml tests/models/slider_push.xml 8 6 0.6
+ *   ./step_from_xml tests/models/slider_push.xml 8 6 0.6            (a 5th argument "general_body:primitive_body": one contact stiffness per environment)
  *
  * Prints, per env-step, q of environment 0 and B-1 (fp64, %.17g), then dL/du of L = sum(q_final) for environment 0. */
 #include <stdio.h>
@@ -19,7 +19,7 @@
 #define HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-  if (argc < 5) { fprintf(stderr, "usage: %s model.xml B steps u_value\n", argv[0]); return 2; }
+  if (argc < 5) { fprintf(stderr, "usage: %s model.xml B steps u_value [general_body:primitive_body]\n", argv[0]); return 2; }
   const int B = atoi(argv[2]), T = atoi(argv[3]), S = 5;
   const double uval = atof(argv[4]);
 
@@ -42,6 +42,27 @@ int main(int argc, char** argv) {
   for (int e = 0; e < B; ++e) for (int k = 0; k < nu; ++k) host[e * nu + k] = uval * (1.0 + 0.1 * e);      /* one control per environment */
   HIP(hipMemcpy(u, host, sizeof(double) * B * (nu ? nu : 1), hipMemcpyHostToDevice));
 
+  double* tables = NULL;
+  if (argc > 5) {
+    /* Domain randomisation, one parameter set per environment (what envs/tactile_insertion_env.py:238-281 draws per episode through
+     * update_contact_parameters, here for the whole batch at once): rows = copies of the model's numeric tables, one entry overwritten. */
+    char key[256]; strncpy(key, argv[5], sizeof(key) - 1); key[sizeof(key) - 1] = 0;
+    char* colon = strchr(key, ':');
+    if (!colon) { fprintf(stderr, "expected general_body:primitive_body\n"); return 2; }
+    *colon = 0;
+    const int col = tsim_model_table_offset(model, TSIM_TAB_PAIR, key, colon + 1, 0);          /* field 0: kn */
+    if (col < 0) { fprintf(stderr, "%s\n", tsim_last_error()); return 1; }
+    const int32_t* I; const double* F; int nI, nF;
+    OK(tsim_model_blob(model, &I, &nI, &F, &nF));
+    const int n = tsim_table_size(sim);
+    double* rows = (double*)malloc(sizeof(double) * (size_t)B * n);
+    for (int e = 0; e < B; ++e) { memcpy(rows + (size_t)e * n, F, sizeof(double) * n); rows[(size_t)e * n + col] = F[col] * (1.0 + 0.05 * e); }
+    HIP(hipMalloc((void**)&tables, sizeof(double) * (size_t)B * n));
+    HIP(hipMemcpy(tables, rows, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice));
+    OK(tsim_set_env_tables(sim, tables, NULL));
+    printf("per-environment tables: column %d (kn of %s -> %s) = %.17g x (1 + 0.05 e)\n", col, key, colon + 1, F[col]);
+    free(rows);
+  }
   OK(tsim_reset(sim, q0, NULL, 1, NULL));                                                    /* set_state_init + reset(backward_flag=True) */
   for (int t = 0; t < T; ++t) {
     OK(tsim_step(sim, u, S, q, NULL, nvar ? var : NULL, ntac ? tac : NULL, status, NULL));   /* set_u; forward(5); get_q; get_variables; get_tactile_force_vector */
@@ -70,6 +91,7 @@ int main(int argc, char** argv) {
   tsim_batch_destroy(sim);
   tsim_model_free(model);
   free(host); free(st);
+  if (tables) hipFree(tables);
   hipFree(q0); hipFree(u); hipFree(q); hipFree(var); hipFree(tac); hipFree(status); hipFree(seed); hipFree(dldu);
   return 0;
 }

@@ -81,9 +81,11 @@ def test_natively_loaded_model_follows_the_oracle():
             assert np.allclose(traj[t][e], o.state()[0], rtol=0, atol=1e-9), (e, t)
 
 
-def test_plain_c_host_runs_the_same_trajectory(tmp_path):
+@pytest.mark.parametrize("tables", [False, True])
+def test_plain_c_host_runs_the_same_trajectory(tmp_path, tables):
     """examples/c_host/step_from_xml.c — a C program with nothing but include/tsim.h, include/tsim_model.h and the HIP runtime (no Python,
-    no torch in the process) — loads the XML, steps B environments and differentiates; its printed fp64 numbers are the Python host's, digit for digit."""
+    no torch in the process) — loads the XML, steps B environments and differentiates; its printed fp64 numbers are the Python host's, digit for digit.
+    tables: with one contact stiffness per environment, the column found through tsim_model_table_offset (domain randomisation from C)."""
     import shutil
     import subprocess
     from tactilesimulation_amd.host import capi
@@ -99,16 +101,25 @@ def test_plain_c_host_runs_the_same_trajectory(tmp_path):
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, text=True)
     xml = os.path.join(HERE, "models", "slider_push.xml")
     B_, T, S, uval = 8, 6, 5, 0.6
-    r = subprocess.run([exe, xml, str(B_), str(T), str(uval)], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, xml, str(B_), str(T), str(uval)] + (["pad:puck"] if tables else []), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.splitlines()
     py = load_model(xml)
     assert lines[0].startswith("model ") and "ndof_r %d ndof_u %d ndof_var %d ndof_tactile %d" % (py.ndof_r, py.ndof_u, py.ndof_var, py.ndof_tactile) in lines[0] and "generic" in lines[0]
     sim = BatchSim(py, B_, dtype=torch.float64, tape_capacity=T * S)
+    if tables:
+        col = py.table_offset("pair", ("pad", "puck"), "kn")
+        assert lines[1].startswith("per-environment tables: column %d " % col)
+        lines = [lines[0]] + lines[2:]
+        tab = sim.base_tables()
+        tab[:, col] = torch.tensor([py.F[col] * (1.0 + 0.05 * e) for e in range(B_)], device="cuda", dtype=torch.float64)
+        sim.set_env_tables(tab)
     sim.reset(torch.zeros(B_, py.ndof_r, device="cuda", dtype=torch.float64), None, backward_flag=True)
     u = torch.tensor([[uval * (1.0 + 0.1 * e)] * py.ndof_u for e in range(B_)], device="cuda", dtype=torch.float64)
+    traj = []
     for t in range(T):
         q = sim.step(u, S)["q"].cpu().numpy()
+        traj.append(q)
         a, b = lines[1 + t].split(" | ")
         assert a.split()[:3] == ["step", str(t), "q[0]"] and b.split()[0] == "q[%d]" % (B_ - 1)
         assert [float(x) for x in a.split()[3:]] == q[0].tolist() and [float(x) for x in b.split()[1:]] == q[-1].tolist(), t
@@ -116,3 +127,4 @@ def test_plain_c_host_runs_the_same_trajectory(tmp_path):
     du = sim.backward_steps(T * S, df_dq=torch.ones(B_, py.ndof_r, device="cuda", dtype=torch.float64)).cpu().numpy()
     got = [float(x) for x in lines[2 + T].split()[1:]]
     assert got == du[0].reshape(-1).tolist() and max(abs(g) for g in got) > 0
+    assert np.abs(traj[-1][0]).max() > 1e-4      # (the pad did push the puck)
