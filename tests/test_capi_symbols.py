@@ -74,3 +74,22 @@ def test_kernel_table_names_the_instantiations_a_batch_launches():
         assert mangled in table, (readable, mangled)
         rec = table[mangled]
         assert rec["vgpr_count"] > 0 and rec["code_bytes"] > 0 and rec["max_flat_workgroup_size"] == 64, (readable, rec)
+
+
+def test_public_headers_are_plain_c99_and_cxx17(tmp_path):
+    """include/*.h is the drop-in boundary: it must parse for a C host (strict ISO C99, -pedantic -Werror) and a C++ one alike, on its own —
+    no HIP, torch or project-internal header behind it"""
+    import shutil
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    hdrs = sorted(f for f in os.listdir(inc) if f.endswith(".h"))
+    assert {"tsim.h", "tsim_env.h", "tsim_model.h", "tsim_blob.h"} <= set(hdrs)
+    src = "".join('#include "%s"\n' % h for h in hdrs) + "int main(void) { return TSIM_IH_SIZE == 40 && TSIM_KT_COUNT == 3 && TSIM_UPD_VIRTUAL_OBJECT == 7 ? 0 : 1; }\n"
+    for cc, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++17", "cpp")):
+        if shutil.which(cc) is None:
+            pytest.skip("no %s on this machine" % cc)
+        p = tmp_path / ("hdr." + ext)
+        p.write_text(src)
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + inc, str(p), "-o", str(tmp_path / ("hdr_" + ext))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert subprocess.run([str(tmp_path / ("hdr_" + ext))]).returncode == 0

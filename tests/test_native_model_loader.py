@@ -389,3 +389,20 @@ def test_mangled_models_are_refused_or_loaded_never_a_crash(model_dir):
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     ok, err = (int(x) for x in r.stdout.split()[1::2])
     assert ok + err == 500 and err > 300 and ok > 5
+
+
+def test_the_c_host_example_compiles_against_the_headers(tmp_path):
+    """examples/c_host/step_from_xml.c is C99 against include/*.h: every declaration it uses parses as C and links against the built library
+    (it RUNS on the GPU box: tests/test_gpu_native_model.py)"""
+    import shutil
+    import subprocess
+    from tactilesimulation_amd.host import capi
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h") or not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("no C compiler / HIP runtime on this machine")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    libdir = os.path.dirname(capi.LIB_PATH)
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "examples", "c_host", "step_from_xml.c"), "-o", str(tmp_path / "step_from_xml"), "-L" + libdir, "-ltsim_hip",
+                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
