@@ -29,7 +29,7 @@
 // ================================================================================================ LPT ordering
 // One block: counting sort of the environments by their residual-evaluation count of the last launch, descending
 // (64 bins; order inside a bin is irrelevant), dealt out to the wavefronts like cards: rank r goes to slot r / nwaves of
-// wavefront r % nwaves.  The expensive environments start first AND sit in different wavefronts — the slots of a
+// wavefront r % nwaves (slot 0) or nwaves - 1 - r % nwaves (the other slots: see `deal` below).  The expensive environments start first AND sit in different wavefronts — the slots of a
 // wavefront are sub-step-synchronous, so two expensive environments in one wavefront cost the sum of their per-sub-step
 // maxima (measured: a batch sorted by work runs 22 % slower than the unsorted one, profiles/r01_imbalance_exp.json).
 // Runs on the same stream right after k_forward.
@@ -38,7 +38,7 @@
 // changing policy), harmless when they do not (any order is a valid one).  bin = (evals - lo) * 64 / span maps the totals onto the
 // 64 bins (lo = 2 evaluations per sub-step, the minimum of a converging Newton loop; span = 2.5 per sub-step); per-step launches keep
 // bin = evals (lo 0, span 64).
-__global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* order, int B, int ns, int lo, int span) {
+__global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* order, int B, int ns, int lo, int span, int deal) {
   __shared__ int hist[64], base[64];
   const int t = threadIdx.x;
   if (t < 64) hist[t] = 0;
@@ -51,7 +51,14 @@ __global__ void __launch_bounds__(1024) k_order_by_evals(const int* evals, int* 
   const int nwaves = (B + ns - 1) / ns;
   for (int e = t; e < B; e += 1024) {
     const int r = atomicAdd(&base[bin(evals[e])], 1);           // rank of environment e, 0 = most expensive
-    order[(r % nwaves) * ns + r / nwaves] = e;                  // slot r / nwaves of wavefront r % nwaves (B % ns == 0)
+    int w = r % nwaves;                                         // slot r / nwaves of wavefront r % nwaves (B % ns == 0)
+    const int sl = r / nwaves;
+    // deal 2 (round 6, the default): every slot but the first is dealt BACKWARDS — the most expensive environments then share their wavefronts with
+    // the cheapest of each quantile, whose slots finish first and become their line-search helpers earliest (D'Claw at B = 2048, two environments per
+    // wavefront: 34.9 -> 32.4 ms per 50-step launch; TactilePush 2.766 -> 2.747 ms; TactileInsertion unchanged; profiles/r06_lpt_deal_ab.json).
+    // A/B at creation, TSIM_LPT_DEAL: 0 = every slot dealt forwards (rounds 1 - 5), 1 = every other slot backwards (snake: no better than 0).
+    if ((deal == 1 && (sl & 1)) || (deal == 2 && sl > 0)) w = nwaves - 1 - w;
+    order[w * ns + sl] = e;
   }
 }
 
@@ -429,7 +436,7 @@ struct tsim_batch {
   int value_first = 1;           // launches without a tape: the first trial after a Newton step evaluates the residual only where the previous sub-step converged in one step (tsim_set_option TSIM_OPT_VALUE_FIRST; TSIM_NO_VALUE_FIRST=1 at creation: off)
   // A/B switches of the environment, read ONCE at creation (launches are on the host-bound path of the per-step collectors):
   // TSIM_NO_EPISODE_LPT, TSIM_INKERNEL_READOUT, TSIM_NO_FREE_RUN, TSIM_LOCKSTEP, TSIM_TAXELS_PER_RECORD, TSIM_NO_ENVTAB_CPT
-  bool ab_no_episode_lpt = false, ab_inkernel_readout = false, ab_no_free_run = false, ab_lockstep = false, ab_taxels_per_record = false, ab_no_envtab_cpt = false, ab_no_default_opts = false; int ab_bwd_lpe = 0;
+  bool ab_no_episode_lpt = false, ab_inkernel_readout = false, ab_no_free_run = false, ab_lockstep = false, ab_taxels_per_record = false, ab_no_envtab_cpt = false, ab_no_default_opts = false; int ab_bwd_lpe = 0, ab_lpt_deal = 2;
   int pair_cull = 1;             // phase 2 skips contact pairs out of reach of their primitive (tsim_set_option TSIM_OPT_PAIR_CULL; TSIM_NO_PAIR_CULL=1 at creation: off)
   // Compiled-in models (csrc/tsim_static.h).  static_id: the model whose STRUCTURE the batch's blob has (ints + the structural floats: 1 TactilePush);
   // static_exact: every float record equals the compiled asset's bit for bit as well (the fully static instantiation); env_struct_ok: the
@@ -869,10 +876,10 @@ static int launch_forward(tsim_batch* b, const void* u, int nframes, const int32
     const int ns = TS_WAVE / launch_shape(b).lpe, nsv = (b->B % ns == 0) ? ns : 1;
     if (nframes > 1) {          // episode totals: the order of the next episode launch of this length (kept across resets)
       const int n = nframes * nsub;
-      hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order_ep, b->B, nsv, 2 * n, std::max(1, 5 * n / 2));
+      hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order_ep, b->B, nsv, 2 * n, std::max(1, 5 * n / 2), b->ab_lpt_deal);
       b->order_ep_n = n; b->order_valid = 0;
     } else {
-      hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B, nsv, 0, 64);
+      hipLaunchKernelGGL(k_order_by_evals, dim3(1), dim3(1024), 0, st, (const int*)b->evals, b->order, b->B, nsv, 0, 64, b->ab_lpt_deal);
       b->order_valid = 1;
     }
     HIPCHK(hipGetLastError());
@@ -935,6 +942,7 @@ int tsim_batch_create(const int32_t* I, const double* F, int B, int tape_capacit
   b->trial_helpers = getenv("TSIM_NO_TRIAL_HELPERS") ? 0 : 1;
   b->ab_no_episode_lpt = getenv("TSIM_NO_EPISODE_LPT") != nullptr; b->ab_inkernel_readout = getenv("TSIM_INKERNEL_READOUT") != nullptr;
   b->ab_no_free_run = getenv("TSIM_NO_FREE_RUN") != nullptr; b->ab_lockstep = getenv("TSIM_LOCKSTEP") != nullptr; b->ab_no_default_opts = getenv("TSIM_NO_DEFAULT_OPTS") != nullptr;
+  if (const char* e = getenv("TSIM_LPT_DEAL")) b->ab_lpt_deal = atoi(e);
   if (const char* e = getenv("TSIM_BWD_LPE")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) b->ab_bwd_lpe = v; }
   b->ab_taxels_per_record = getenv("TSIM_TAXELS_PER_RECORD") != nullptr; b->ab_no_envtab_cpt = getenv("TSIM_NO_ENVTAB_CPT") != nullptr;
   b->value_first = getenv("TSIM_NO_VALUE_FIRST") ? 0 : 1;
