@@ -406,3 +406,28 @@ def test_the_c_host_example_compiles_against_the_headers(tmp_path):
                         os.path.join(root, "examples", "c_host", "step_from_xml.c"), "-o", str(tmp_path / "step_from_xml"), "-L" + libdir, "-ltsim_hip",
                         "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_null_and_bad_arguments_are_errors_not_crashes():
+    """every entry point of include/tsim_model.h with NULL / out-of-range arguments: an error code (or -1) and a reason in tsim_last_error"""
+    import ctypes as C
+    from tactilesimulation_amd.host import capi
+    L = capi.lib()
+    h, out = C.c_void_p(), C.c_void_p()
+    assert L.tsim_model_load(None, C.byref(h)) == 1 and L.tsim_model_load(b"/nonexistent.xml", None) == 1
+    assert L.tsim_model_blob(None, None, None, None, None) == 1 and b"null model" in L.tsim_last_error()
+    assert L.tsim_model_save_blob(None, b"/tmp/never_written.tsimblob") == 1 and L.tsim_model_load_blob(b"/nonexistent", C.byref(h)) == 1
+    assert L.tsim_model_image_pos(None, b"a", None, 0) == -1 and L.tsim_model_table_offset(None, 0, b"a", b"b", 0) == -1
+    assert L.tsim_model_update(None, 0, b"a", None, None, 0) == 1 and L.tsim_batch_create_from_model(None, 1, 1, 0, 0, C.byref(out)) == 1
+    L.tsim_model_free(None)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "pendulum.xml")
+    assert L.tsim_model_load(path.encode(), C.byref(h)) == 0
+    try:
+        assert L.tsim_model_update(h, 99, b"a", None, None, 0) == 1 and b"unknown kind" in L.tsim_last_error()
+        assert L.tsim_model_update(h, 0, b"a", None, None, 1) == 1                       # a count without values
+        assert L.tsim_model_table_offset(h, 7, b"a", None, 0) == -1 and L.tsim_model_table_offset(h, 0, b"a", None, 0) == -1
+        assert L.tsim_model_image_pos(h, b"none", None, 5) == -1 and b"unknown tactile sensor" in L.tsim_last_error()
+        assert L.tsim_batch_create_from_model(h, 0, 1, 0, 0, C.byref(out)) == 1 and not out.value      # (refused before any GPU call)
+        assert L.tsim_model_blob(h, None, None, None, None) == 0                        # every out-pointer is optional
+    finally:
+        L.tsim_model_free(h)
