@@ -431,3 +431,100 @@ def test_null_and_bad_arguments_are_errors_not_crashes():
         assert L.tsim_model_blob(h, None, None, None, None) == 0                        # every out-pointer is optional
     finally:
         L.tsim_model_free(h)
+
+
+def _random_model(rng):
+    """a random redmax XML: a forest of links with every joint / body kind, ground + general-primitive contacts, motors, rect_array sensors, end-effectors"""
+    f = lambda lo, hi: "%.6g" % rng.uniform(lo, hi)
+    vec = lambda lo, hi, n=3: " ".join(f(lo, hi) for _ in range(n))
+
+    def quat():
+        q = rng.normal(size=4)
+        return " ".join("%.4f" % x for x in q / np.linalg.norm(q)) if rng.uniform() < 0.7 else "1 0 0 0"
+    joints, bodies, budget = [], [], [28]
+    ndof = {"fixed": 0, "revolute": 1, "prismatic": 1, "planar": 2, "translational": 3, "free3d-euler": 6, "free3d-exp": 6}
+
+    def link(depth):
+        kinds = [k for k in ndof if ndof[k] <= budget[0] and (depth == 0 or not k.startswith("free3d"))]
+        jt = kinds[rng.integers(len(kinds))]
+        budget[0] -= ndof[jt]
+        name = "j%d" % len(joints)
+        joints.append((name, jt))
+        ja = 'name="%s" type="%s" pos="%s" quat="%s"' % (name, jt, vec(-0.1, 0.1), quat())
+        if jt in ("revolute", "prismatic"):
+            ja += ' axis="%s"' % vec(-1, 1)
+            if rng.uniform() < 0.5:
+                ja += ' lim="%s %s" lim_stiffness="%s"' % (f(-1, 0), f(0, 1), f(0, 50))
+        if jt == "planar":
+            ja += ' axis0="%s" axis1="%s"' % (vec(-1, 1), vec(-1, 1))
+        if rng.uniform() < 0.5:
+            ja += ' damping="%s"' % f(0, 3)
+        bt = ["cuboid", "sphere", "cylinder", "abstract"][rng.integers(4)]
+        bname = "b%d" % len(bodies)
+        bodies.append((bname, bt))
+        ba = 'name="%s" type="%s" pos="%s" quat="%s"' % (bname, bt, vec(-0.05, 0.05), quat())
+        if bt == "cuboid":
+            ba += ' size="%s" density="%s" general_contact_resolution="%d %d %d"' % (vec(0.01, 0.1), f(1, 1000), rng.integers(2, 5), rng.integers(2, 4), rng.integers(2, 4))
+        elif bt == "sphere":
+            ba += ' radius="%s" density="%s"' % (f(0.01, 0.05), f(1, 1000))
+        elif bt == "cylinder":
+            ba += ' radius="%s" length="%s" general_contact_angle_resolution="%d" general_contact_radius_resolution="%d"' % (f(0.01, 0.05), f(0.01, 0.1), rng.integers(3, 9), rng.integers(1, 4))
+        else:
+            ba += ' mass="%s" inertia="%s"' % (f(0.01, 1), vec(1e-5, 1e-3))
+        kids = "".join(link(depth + 1) for _ in range(rng.integers(0, 3))) if depth < 3 and budget[0] > 0 else ""
+        return '<link name="l_%s"><joint %s/><body %s/>%s</link>' % (name, ja, ba, kids)
+    robots = "".join("<robot>%s</robot>" % link(0) for _ in range(rng.integers(1, 4)))
+    general = [b for b, t in bodies if t in ("cuboid", "cylinder")]
+    prim = [b for b, t in bodies if t in ("cuboid", "sphere", "cylinder")]
+    contacts = ""
+    for b, t in bodies:
+        if t != "abstract" and rng.uniform() < 0.4:
+            contacts += '<ground_contact body="%s" kn="%s" mu="%s"/>' % (b, f(1e2, 1e4), f(0, 1))
+    pairs = set()
+    for _ in range(rng.integers(0, 4)):
+        if general and prim:
+            g, p_ = general[rng.integers(len(general))], prim[rng.integers(len(prim))]
+            if g != p_ and (g, p_) not in pairs:
+                pairs.add((g, p_))
+                contacts += '<general_primitive_contact general_body="%s" primitive_body="%s" kt="%s" damping="%s"/>' % (g, p_, f(0, 10), f(0, 100))
+    motors = "".join('<motor joint="%s" ctrl="%s" ctrl_range="%s %s"%s/>' % (n, ["force", "position"][rng.integers(2)], f(-3, 0), f(0, 3), ' P="%s" D="%s"' % (f(0, 50), f(0, 1)) if rng.uniform() < 0.5 else "")
+                     for n, t in joints if ndof[t] > 0 and rng.uniform() < 0.5)
+    sensors = "".join('<tactile body="%s" name="s_%s" type="rect_array" rect_pos0="%s" rect_pos1="%s" axis0="%s" axis1="%s" resolution="%d %d" kn="%s"/>'
+                      % (g, g, vec(-0.01, 0.01), vec(-0.01, 0.01), vec(-1, 1), vec(-1, 1), rng.integers(1, 6), rng.integers(1, 6), f(10, 200)) for g in sorted({g for g, _ in pairs}))
+    ee = "".join('<endeffector joint="%s" pos="%s"/>' % (n, vec(-0.05, 0.05)) for n, _ in joints if rng.uniform() < 0.3)
+    return ('<redmax model="random"><option integrator="%s" timestep="%s" gravity="%s"/><solver_option tol="1e-9" max_iter="%d" max_ls="%d"/>'
+            '<ground pos="%s" normal="%s"/><default><joint lim_stiffness="%s" damping="%s"/><motor P="%s" D="%s" ctrl_range="-1.5 1.5"/></default>%s<contact>%s</contact>'
+            '<actuator>%s</actuator><sensor>%s</sensor><variable>%s</variable></redmax>') % (
+        ["BDF1", "BDF2"][rng.integers(2)], f(1e-3, 1e-2), vec(-10, 10), rng.integers(10, 100), rng.integers(5, 20), vec(-0.1, 0.1), "%s %s 1" % (f(-0.2, 0.2), f(-0.2, 0.2)),
+        f(0, 20), f(0, 2), f(0, 10), f(0, 1), robots, contacts, motors, sensors, ee)
+
+
+def test_random_models_compile_to_the_same_blob(tmp_path):
+    """300 random kinematic forests (every joint and primitive body kind, random frames, contacts, motors, sensors): the two compilers agree on
+    every int and every real, and refuse the same models"""
+    rng = np.random.default_rng(2026)
+    p = str(tmp_path / "r.xml")
+    compiled = refused = 0
+    for it in range(300):
+        open(p, "w").write(_random_model(rng))
+        try:
+            py = _python(p)
+        except Exception:
+            py = None
+        try:
+            nm = _native(p)
+        except RuntimeError:
+            nm = None
+        assert (py is None) == (nm is None), (it, open(p).read())
+        if py is None:
+            refused += 1
+            continue
+        I, F = nm.blob()
+        try:
+            _same_blob(I, F, py)
+            _same_lookups(nm, py)
+        except AssertionError:
+            print(open(p).read())
+            raise
+        compiled += 1
+    assert compiled >= 250, (compiled, refused)
