@@ -433,7 +433,7 @@ def test_null_and_bad_arguments_are_errors_not_crashes():
         L.tsim_model_free(h)
 
 
-def _random_model(rng):
+def _random_model(rng, max_dof=28):
     """a random redmax XML: a forest of links with every joint / body kind, ground + general-primitive contacts, motors, rect_array sensors, end-effectors"""
     f = lambda lo, hi: "%.6g" % rng.uniform(lo, hi)
     vec = lambda lo, hi, n=3: " ".join(f(lo, hi) for _ in range(n))
@@ -441,7 +441,7 @@ def _random_model(rng):
     def quat():
         q = rng.normal(size=4)
         return " ".join("%.4f" % x for x in q / np.linalg.norm(q)) if rng.uniform() < 0.7 else "1 0 0 0"
-    joints, bodies, budget = [], [], [28]
+    joints, bodies, budget = [], [], [max_dof]
     ndof = {"fixed": 0, "revolute": 1, "prismatic": 1, "planar": 2, "translational": 3, "free3d-euler": 6, "free3d-exp": 6}
 
     def link(depth):
