@@ -50,6 +50,9 @@ def test_random_model_follows_the_oracle(seed, lanes, dtype, tmp_path):
         sim.set_lanes_per_env(lanes)
     sim.reset(torch.tensor(q0, device=dev, dtype=dt), None, backward_flag=True)
     outs = [sim.step(torch.tensor(u[:, t], device=dev, dtype=dt).reshape(B_, nu), S, want_qd=True) for t in range(T)]
+    if nv or nt:      # the on-demand read-out (tsim_readout: k_readout + k_taxels) of the final state == what the last step returned, bit for bit
+        rv, rt = sim.readout(want_var=bool(nv), want_tactile=bool(nt))
+        assert (not nv or torch.equal(rv, outs[-1]["var"])) and (not nt or torch.equal(rt, outs[-1]["tactile"])), seed
     outs = [{k: (v.double() if v.is_floating_point() else v).cpu().numpy() for k, v in o.items()} for o in outs]
     kw = {"df_dq": torch.tensor(wq, device=dev, dtype=dt)}
     if nv:
