@@ -95,3 +95,56 @@ def test_random_model_follows_the_oracle(seed, lanes, dtype, tmp_path):
             assert np.allclose(du[e].reshape(T * S, nu), g, rtol=0, atol=tg * gs), (seed, e, np.abs(du[e].reshape(T * S, nu) - g).max(), gs)
     if compared == 0:
         pytest.skip("every environment of this model hits max_iter in its first env-step")
+
+
+@pytest.mark.parametrize("lanes,dtype", [(0, torch.float64), (32, torch.float64), (16, torch.float32), (32, torch.float32)])
+@pytest.mark.parametrize("seed", range(0, N_MODELS, 3))
+def test_episode_launches_equal_the_step_loop_on_random_models(seed, lanes, dtype, tmp_path):
+    """tsim_rollout + tsim_backward_episode (one launch each way per episode: free-running slots, helper slots, LPT order, deferred read-out)
+    against T x tsim_step + tsim_backward_steps on the same random models — bit for bit, both precisions, ragged batch (11 environments, so that
+    wavefronts carry 1 - 4 of them and the last one is partly empty), a tactile mask, per-frame seeds."""
+    from tactilesimulation_amd.host.batch import BatchSim
+    m, rng = _case(1000 + seed, tmp_path)
+    nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
+    B2, T2, S2 = 11, 4, 3
+    dev = "cuda:0"
+    q0 = torch.tensor(0.02 * rng.normal(size=(B2, nr)), device=dev, dtype=dtype)
+    u = torch.tensor(rng.uniform(-1, 1, size=(T2, B2, max(nu, 1)))[:, :, :nu], device=dev, dtype=dtype).contiguous()
+    mask = torch.tensor([True, False, True, True])
+    wq = torch.tensor(rng.normal(size=(T2, B2, nr)), device=dev, dtype=dtype)
+    wv = torch.tensor(rng.normal(size=(T2, B2, nv)), device=dev, dtype=dtype) if nv else None
+    wt = torch.tensor(rng.normal(size=(int(mask.sum()), B2, nt)), device=dev, dtype=dtype) if nt else None
+    a, b = (BatchSim(m, B2, dtype=dtype, tape_capacity=T2 * S2) for _ in range(2))
+    for sim in (a, b):
+        if lanes:
+            sim.set_lanes_per_env(lanes)
+        sim.reset(q0, None, backward_flag=True)
+    ro = a.rollout(u, S2, want_qd=True, tactile_mask=mask)
+    steps = [b.step(u[t], S2, want_qd=True) for t in range(T2)]
+    for k in ("q", "qd") + (("var",) if nv else ()):
+        assert torch.equal(ro[k], torch.stack([s_[k] for s_ in steps])), (seed, k)
+    if nt:
+        assert torch.equal(ro["tactile"], torch.stack([steps[t]["tactile"] for t in range(T2) if mask[t]])), seed
+    bad = torch.stack([s_["status"] for s_ in steps]).ne(0).any(0)
+    assert torch.equal(ro["status"].ne(0), bad), seed
+    if nu == 0:
+        return
+    ga = a.backward_episode(T2, S2, df_dq=wq, df_dvar=wv, df_dtactile=wt, tactile_mask=mask)             # [T, B, nu]: dL/du of every env-step
+    # the same seeds for tsim_backward_steps: [B, n, dim] per SUB-step, an env-step's outputs on its last sub-step
+    def per_substep(w, dim, frames):
+        full = torch.zeros(B2, T2 * S2, dim, device=dev, dtype=dtype)
+        for j, t in enumerate(frames):
+            full[:, t * S2 + S2 - 1] = w[j]
+        return full
+    kw = {"df_dq": per_substep(wq, nr, range(T2))}
+    if nv:
+        kw["df_dvar"] = per_substep(wv, nv, range(T2))
+    if nt:
+        kw["df_dtactile"] = per_substep(wt, nt, [t for t in range(T2) if mask[t]])
+    gb = b.backward_steps(T2 * S2, all_steps=True, **kw)                                                     # [B, T*S, nu] per sub-step
+    gb = gb.reshape(B2, T2, S2, nu).sum(2).transpose(0, 1)
+    ok = ~bad
+    if dtype == torch.float64:
+        assert torch.allclose(ga[:, ok], gb[:, ok], rtol=1e-9, atol=1e-9 * (1.0 + float(gb[:, ok].abs().max()) if ok.any() else 1.0)), seed
+    else:
+        assert torch.allclose(ga[:, ok], gb[:, ok], rtol=1e-3, atol=1e-3 * (1.0 + float(gb[:, ok].abs().max()) if ok.any() else 1.0)), seed
