@@ -60,6 +60,7 @@ def test_random_model_follows_the_oracle(seed, lanes, dtype, tmp_path):
     if nt:
         kw["df_dtactile"] = torch.tensor(wt, device=dev, dtype=dt)
     du = sim.backward_steps(T * S, **kw).double().cpu().numpy()
+    lam_q, lam_v = (x.double().cpu().numpy() for x in sim.get_adjoint())      # dL/dq0, dL/dqdot0 (backward() + backward_results.df_dq0 / df_dqdot0)
     o = OracleSim(m)
     compared = 0
     for e in range(B_):
@@ -93,6 +94,13 @@ def test_random_model_follows_the_oracle(seed, lanes, dtype, tmp_path):
                                  df_dtac=np.concatenate([np.zeros((T * S - 1) * nt), wt[e]]) if nt else None)
             gs = 1.0 + np.abs(g).max()
             assert np.allclose(du[e].reshape(T * S, nu), g, rtol=0, atol=tg * gs), (seed, e, np.abs(du[e].reshape(T * S, nu) - g).max(), gs)
+        if clean:
+            if not nu:
+                o.backward_steps(T * S, df_dq=np.concatenate([np.zeros((T * S - 1) * nr), wq[e]]), df_dvar=np.concatenate([np.zeros((T * S - 1) * nv), wv[e]]) if nv else None,
+                                 df_dtac=np.concatenate([np.zeros((T * S - 1) * nt), wt[e]]) if nt else None)
+            aq, av = o.adjoint()
+            for mine, ref in ((lam_q[e], aq), (lam_v[e], av)):
+                assert np.allclose(mine, ref, rtol=0, atol=tg * (1.0 + np.abs(ref).max())), (seed, e, np.abs(mine - ref).max(), np.abs(ref).max())
     if compared == 0:
         pytest.skip("every environment of this model hits max_iter in its first env-step")
 
