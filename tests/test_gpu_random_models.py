@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 N_MODELS, B_, T, S = 120, 3, 3, 2
 
 
-def _case(seed, tmp_path):
+def _case(seed, tmp_path, files=False):
     from tactilesimulation_amd.model.compiler import parse_xml, compile_spec
     rng = np.random.default_rng(seed)
     p = str(tmp_path / ("m%d.xml" % seed))
     for _ in range(20):      # (the kernels take ndof_r, ndof_u <= 16 and one rotation-vector joint per model: include/tsim.h)
-        open(p, "w").write(_random_model(rng, max_dof=12))
+        open(p, "w").write(_random_model(rng, max_dof=12, files_dir=str(tmp_path) if files else None))
         spec = parse_xml(p)
         m = compile_spec(spec)
         if 1 <= m.ndof_r <= 16 and m.ndof_u <= 16 and sum(J["type"] == "free3d-exp" for J in spec["joints"]) <= 1:
@@ -32,12 +32,13 @@ def _case(seed, tmp_path):
     pytest.skip("no model within the kernels' sizes")
 
 
-@pytest.mark.parametrize("lanes,dtype", [(0, torch.float64), (32, torch.float64), (16, torch.float64)])
+@pytest.mark.parametrize("lanes,dtype,files", [(0, torch.float64, False), (32, torch.float64, False), (16, torch.float64, False), (0, torch.float64, True), (32, torch.float64, True)])
 @pytest.mark.parametrize("seed", range(N_MODELS))
-def test_random_model_follows_the_oracle(seed, lanes, dtype, tmp_path):
+def test_random_model_follows_the_oracle(seed, lanes, dtype, files, tmp_path):
+    """files: abstract bodies with contact-point files as general bodies, abstract taxel files as sensors (the D'Claw vocabulary)"""
     from oracle.oracle import OracleSim
     from tactilesimulation_amd.host.batch import BatchSim
-    m, rng = _case(1000 + seed, tmp_path)
+    m, rng = _case(1000 + seed, tmp_path, files)
     nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
     q0 = 0.02 * rng.normal(size=(B_, nr))
     u = rng.uniform(-1, 1, size=(B_, T, max(nu, 1)))[:, :, :nu]

@@ -433,8 +433,10 @@ def test_null_and_bad_arguments_are_errors_not_crashes():
         L.tsim_model_free(h)
 
 
-def _random_model(rng, max_dof=28):
-    """a random redmax XML: a forest of links with every joint / body kind, ground + general-primitive contacts, motors, rect_array sensors, end-effectors"""
+def _random_model(rng, max_dof=28, files_dir=None):
+    """a random redmax XML: a forest of links with every joint / body kind, ground + general-primitive contacts, motors, rect_array sensors, end-effectors;
+    files_dir: abstract bodies may carry contact-point files and sensors abstract taxel files, written there (the D'Claw vocabulary:
+    envs/assets/dclaw_rotate/dclaw_position_control.xml:18-21,133-148)"""
     f = lambda lo, hi: "%.6g" % rng.uniform(lo, hi)
     vec = lambda lo, hi, n=3: " ".join(f(lo, hi) for _ in range(n))
 
@@ -471,14 +473,21 @@ def _random_model(rng, max_dof=28):
             ba += ' radius="%s" length="%s" general_contact_angle_resolution="%d" general_contact_radius_resolution="%d"' % (f(0.01, 0.05), f(0.01, 0.1), rng.integers(3, 9), rng.integers(1, 4))
         else:
             ba += ' mass="%s" inertia="%s"' % (f(0.01, 1), vec(1e-5, 1e-3))
+        inner = ""
+        if bt == "abstract" and files_dir is not None and rng.uniform() < 0.6:
+            pts = rng.uniform(-0.03, 0.03, size=(rng.integers(1, 9), 3))
+            with open(os.path.join(files_dir, "pts_%s.txt" % bname), "w") as fh:
+                fh.write("%d\n" % len(pts) + "".join("%.6g %.6g %.6g\n" % tuple(x) for x in pts))
+            inner = '<collision contacts="pts_%s.txt" pos="%s" quat="%s"/>' % (bname, vec(-0.01, 0.01), quat())
+            bodies[-1] = (bname, "abstract+points")
         kids = "".join(link(depth + 1) for _ in range(rng.integers(0, 3))) if depth < 3 and budget[0] > 0 else ""
-        return '<link name="l_%s"><joint %s/><body %s/>%s</link>' % (name, ja, ba, kids)
+        return '<link name="l_%s"><joint %s/><body %s>%s</body>%s</link>' % (name, ja, ba, inner, kids) if inner else '<link name="l_%s"><joint %s/><body %s/>%s</link>' % (name, ja, ba, kids)
     robots = "".join("<robot>%s</robot>" % link(0) for _ in range(rng.integers(1, 4)))
-    general = [b for b, t in bodies if t in ("cuboid", "cylinder")]
+    general = [b for b, t in bodies if t in ("cuboid", "cylinder", "abstract+points")]
     prim = [b for b, t in bodies if t in ("cuboid", "sphere", "cylinder")]
     contacts = ""
     for b, t in bodies:
-        if t != "abstract" and rng.uniform() < 0.4:
+        if t != "abstract" and rng.uniform() < 0.4:      # ("abstract+points" bodies included)
             contacts += '<ground_contact body="%s" kn="%s" mu="%s"/>' % (b, f(1e2, 1e4), f(0, 1))
     pairs = set()
     for _ in range(rng.integers(0, 4)):
@@ -489,8 +498,20 @@ def _random_model(rng, max_dof=28):
                 contacts += '<general_primitive_contact general_body="%s" primitive_body="%s" kt="%s" damping="%s"/>' % (g, p_, f(0, 10), f(0, 100))
     motors = "".join('<motor joint="%s" ctrl="%s" ctrl_range="%s %s"%s/>' % (n, ["force", "position"][rng.integers(2)], f(-3, 0), f(0, 3), ' P="%s" D="%s"' % (f(0, 50), f(0, 1)) if rng.uniform() < 0.5 else "")
                      for n, t in joints if ndof[t] > 0 and rng.uniform() < 0.5)
-    sensors = "".join('<tactile body="%s" name="s_%s" type="rect_array" rect_pos0="%s" rect_pos1="%s" axis0="%s" axis1="%s" resolution="%d %d" kn="%s"/>'
-                      % (g, g, vec(-0.01, 0.01), vec(-0.01, 0.01), vec(-1, 1), vec(-1, 1), rng.integers(1, 6), rng.integers(1, 6), f(10, 200)) for g in sorted({g for g, _ in pairs}))
+    def sensor(g):
+        if files_dir is not None and rng.uniform() < 0.5:
+            n = int(rng.integers(1, 10))
+            rows = []
+            for k in range(n):
+                a0 = rng.normal(size=3); a0 /= np.linalg.norm(a0)
+                a1 = np.cross(a0, rng.normal(size=3)); a1 /= np.linalg.norm(a1)
+                rows.append('"%s" "%d %d" "%s" "%s" "%s"' % (vec(-0.01, 0.01), k // 3, k % 3, " ".join("%.6g" % x for x in np.cross(a1, a0)), " ".join("%.6g" % x for x in a0), " ".join("%.6g" % x for x in a1)))
+            with open(os.path.join(files_dir, "tax_%s.txt" % g), "w") as fh:
+                fh.write("%d\n" % n + "\n".join(rows) + "\n")
+            return '<tactile body="%s" name="s_%s" type="abstract" spec="tax_%s.txt" pos="%s" quat="%s" kt="%s"/>' % (g, g, g, vec(-0.005, 0.005), quat(), f(0, 10))
+        return ('<tactile body="%s" name="s_%s" type="rect_array" rect_pos0="%s" rect_pos1="%s" axis0="%s" axis1="%s" resolution="%d %d" kn="%s"/>'
+                % (g, g, vec(-0.01, 0.01), vec(-0.01, 0.01), vec(-1, 1), vec(-1, 1), rng.integers(1, 6), rng.integers(1, 6), f(10, 200)))
+    sensors = "".join(sensor(g) for g in sorted({g for g, _ in pairs}))
     ee = "".join('<endeffector joint="%s" pos="%s"/>' % (n, vec(-0.05, 0.05)) for n, _ in joints if rng.uniform() < 0.3)
     return ('<redmax model="random"><option integrator="%s" timestep="%s" gravity="%s"/><solver_option tol="1e-9" max_iter="%d" max_ls="%d"/>'
             '<ground pos="%s" normal="%s"/><default><joint lim_stiffness="%s" damping="%s"/><motor P="%s" D="%s" ctrl_range="-1.5 1.5"/></default>%s<contact>%s</contact>'
@@ -528,3 +549,14 @@ def test_random_models_compile_to_the_same_blob(tmp_path):
             raise
         compiled += 1
     assert compiled >= 250, (compiled, refused)
+    # ... and 150 more whose abstract bodies carry contact-point files and whose sensors may be abstract taxel files
+    files = 0
+    for it in range(150):
+        text = _random_model(rng, files_dir=str(tmp_path))
+        files += "contacts=" in text or 'type="abstract" spec=' in text
+        open(p, "w").write(text)
+        nm, py = _native(p), _python(p)
+        I, F = nm.blob()
+        _same_blob(I, F, py)
+        _same_lookups(nm, py)
+    assert files >= 60, files
