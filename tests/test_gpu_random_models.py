@@ -157,3 +157,74 @@ def test_episode_launches_equal_the_step_loop_on_random_models(seed, lanes, dtyp
         assert torch.allclose(ga[:, ok], gb[:, ok], rtol=1e-9, atol=1e-9 * (1.0 + float(gb[:, ok].abs().max()) if ok.any() else 1.0)), seed
     else:
         assert torch.allclose(ga[:, ok], gb[:, ok], rtol=1e-3, atol=1e-3 * (1.0 + float(gb[:, ok].abs().max()) if ok.any() else 1.0)), seed
+
+
+@pytest.mark.parametrize("lanes", [0, 32])
+@pytest.mark.parametrize("seed", range(1, N_MODELS, 3))
+def test_per_environment_tables_equal_separately_edited_models_on_random_models(seed, lanes, tmp_path):
+    """tsim_set_env_tables on the generic kernels: every environment of a batch with its own numeric tables (contact / tactile parameters AND primitive
+    shapes, joint damping and limits, link masses and inertias, motor gains — what the update_* randomisers of the reference's envs touch, all at once)
+    runs what a batch of the model edited to that row runs — state, tactile frame, adjoint.  (The pair cull and the sweep schedule are built by the
+    host from the SHARED model: an environment whose primitive is larger than the shared one must not lose contacts to them.)"""
+    import copy
+    import tactilesimulation_amd.model.blob as BL
+    from tactilesimulation_amd.host.batch import BatchSim
+    m, rng = _case(1000 + seed, tmp_path)
+    nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
+    Bt, Tt, St = 5, 3, 2
+    dev, dt = "cuda:0", torch.float64
+    sim = BatchSim(m, Bt, dtype=dt, tape_capacity=Tt * St)
+    if lanes:
+        sim.set_lanes_per_env(lanes)
+    tab = sim.base_tables()
+    n = tab.shape[1]
+    I = m.I
+    cols = []
+    for p_ in range(int(I[BL.TSIM_IH_NPAIR])):
+        o_ = int(I[BL.TSIM_IH_FOFF_PAIR]) + p_ * BL.TSIM_PF_SIZE
+        cols += [o_ + BL.TSIM_PF_SHAPE + k for k in range(4)] + [o_ + BL.TSIM_PF_KN + k for k in range(4)]
+    for s_ in range(int(I[BL.TSIM_IH_NSENSOR])):
+        cols += [int(I[BL.TSIM_IH_FOFF_SENSOR]) + s_ * BL.TSIM_SF_SIZE + k for k in range(4)]
+    for d in range(nr):
+        cols += [int(I[BL.TSIM_IH_FOFF_DOF]) + d * BL.TSIM_DF_SIZE + k for k in (BL.TSIM_DF_DAMPING, BL.TSIM_DF_LIM_K)]
+    for l_ in range(int(I[BL.TSIM_IH_NL])):
+        o_ = int(I[BL.TSIM_IH_FOFF_LINK]) + l_ * BL.TSIM_LF_SIZE
+        cols += [o_ + BL.TSIM_LF_MASS] + [o_ + BL.TSIM_LF_INERTIA + k for k in range(6)]
+    for k in range(nu):
+        cols += [int(I[BL.TSIM_IH_FOFF_MOTOR]) + k * BL.TSIM_MF_SIZE + j for j in (BL.TSIM_MF_P, BL.TSIM_MF_D)]
+    cols = [c for c in cols if c < n]
+    scale = torch.tensor(rng.uniform(0.7, 1.4, size=(Bt, len(cols))), device=dev, dtype=dt)
+    # (a link's mass and inertia scale together, so that the inertia stays one of a body: one factor per link and environment)
+    tab[:, cols] = tab[:, cols] * scale
+    for l_ in range(int(I[BL.TSIM_IH_NL])):
+        o_ = int(I[BL.TSIM_IH_FOFF_LINK]) + l_ * BL.TSIM_LF_SIZE
+        fac = torch.tensor(rng.uniform(0.7, 1.4, size=(Bt, 1)), device=dev, dtype=dt)
+        base = torch.tensor(m.F[o_ + BL.TSIM_LF_MASS:o_ + BL.TSIM_LF_INERTIA + 6], device=dev, dtype=dt)
+        tab[:, o_ + BL.TSIM_LF_MASS] = base[0] * fac[:, 0]
+        tab[:, o_ + BL.TSIM_LF_INERTIA:o_ + BL.TSIM_LF_INERTIA + 6] = base[BL.TSIM_LF_INERTIA - BL.TSIM_LF_MASS:] * fac
+    sim.set_env_tables(tab)
+    q0 = torch.tensor(0.02 * rng.normal(size=(Bt, nr)), device=dev, dtype=dt)
+    u = torch.tensor(rng.uniform(-1, 1, size=(Tt, Bt, max(nu, 1)))[:, :, :nu], device=dev, dtype=dt).contiguous()
+    wq = torch.tensor(rng.normal(size=(Bt, nr)), device=dev, dtype=dt)
+    sim.reset(q0, None, backward_flag=True)
+    outs = [sim.step(u[t], St, want_qd=True) for t in range(Tt)]
+    du = sim.backward_steps(Tt * St, df_dq=wq)
+    rows = tab.cpu().numpy()
+    for e in range(Bt):
+        me = copy.deepcopy(m)
+        me.F[:n] = rows[e]
+        one = BatchSim(me, 1, dtype=dt, tape_capacity=Tt * St)
+        one.reset(q0[e:e + 1], None, backward_flag=True)
+        clean = True
+        for t in range(Tt):
+            o1 = one.step(u[t, e:e + 1], St, want_qd=True)
+            assert int(o1["status"][0] != 0) == int(outs[t]["status"][e] != 0), (seed, e, t)
+            if o1["status"][0] != 0:
+                clean = False
+                break      # (a sub-step at max_iter: see the first test of this file)
+            for k in ("q", "qd") + (("var",) if nv else ()) + (("tactile",) if nt else ()):
+                a_, b_ = outs[t][k][e], o1[k][0]
+                assert torch.allclose(a_, b_, rtol=0, atol=1e-9 * (1.0 + float(b_.abs().max()))), (seed, e, t, k, float((a_ - b_).abs().max()))
+        if clean and nu:
+            d1 = one.backward_steps(Tt * St, df_dq=wq[e:e + 1])
+            assert torch.allclose(du[e], d1[0], rtol=0, atol=1e-8 * (1.0 + float(d1.abs().max()))), (seed, e, float((du[e] - d1[0]).abs().max()))
