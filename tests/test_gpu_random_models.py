@@ -13,6 +13,7 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tactilesimulation_amd", "compat"))      # `import redmax_py`
 from test_native_model_loader import _random_model      # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -228,3 +229,45 @@ def test_per_environment_tables_equal_separately_edited_models_on_random_models(
         if clean and nu:
             d1 = one.backward_steps(Tt * St, df_dq=wq[e:e + 1])
             assert torch.allclose(du[e], d1[0], rtol=0, atol=1e-8 * (1.0 + float(d1.abs().max()))), (seed, e, float((du[e] - d1[0]).abs().max()))
+
+
+@pytest.mark.parametrize("seed", range(2, N_MODELS, 6))
+def test_reference_call_sequence_on_random_model_files(seed, tmp_path):
+    """The drop-in surface end to end on models nobody wrote by hand: `redmax_py.Simulation(xml_path)` (compat/redmax_py.py: what
+    envs/redmax_torch_env.py:33 constructs) stepped and differentiated through StepSimFunction exactly as envs/redmax_torch_functions.py:115-174
+    does, with contact-point and taxel files next to the XML — loss and every action's gradient against the oracle."""
+    import redmax_py as redmax
+    from oracle.oracle import OracleSim
+    from tactilesimulation_amd.functions import StepSimFunction
+    m, rng = _case(1000 + seed, tmp_path, files=True)
+    nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
+    if nu == 0:
+        pytest.skip("no motor in this model")
+    sim = redmax.Simulation(str(tmp_path / ("m%d.xml" % (1000 + seed))))
+    assert (sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile) == (nr, nu, nv, nt) and sim.options.h == m.h
+    q0 = 0.02 * rng.normal(size=nr)
+    Tn, Sn = 3, 2
+    u = rng.uniform(-1, 1, size=(Tn, nu))
+    cq, cv, ct = rng.normal(size=nr), rng.normal(size=nv), rng.normal(size=nt)
+    sim.set_state_init(q0, np.zeros(nr))
+    sim.reset(backward_flag=True)
+    acts = [torch.tensor(u[t], dtype=torch.float64, requires_grad=True) for t in range(Tn)]
+    L = 0.0
+    for a in acts:
+        q, var, tac = StepSimFunction.apply(a, Sn, sim, True)
+        L = L + (q * torch.tensor(cq)).sum() + ((var * torch.tensor(cv)).sum() if nv else 0.0) + ((tac * torch.tensor(ct)).sum() if nt else 0.0)
+    L.backward()
+    o = OracleSim(m)
+    o.reset(q0, record=True)
+    Lo = 0.0
+    for t in range(Tn):
+        if o.forward(u[t], Sn) != 0:
+            pytest.skip("a sub-step at max_iter (see the first test of this file)")
+        q, _ = o.state()
+        v, tc = o.outputs()
+        Lo += cq @ q + (cv @ v if nv else 0.0) + (ct @ tc if nt else 0.0)
+    assert abs(float(L.detach()) - Lo) < 1e-8 * max(abs(Lo), 1.0)
+    for t in reversed(range(Tn)):
+        z = lambda c, d: np.concatenate([np.zeros((Sn - 1) * d), c]) if d else None
+        go = o.backward_steps(Sn, z(cq, nr), z(cv, nv), z(ct, nt)).sum(0)
+        assert np.abs(acts[t].grad.numpy() - go).max() < 1e-6 * max(np.abs(go).max(), 1e-3), (seed, t)
