@@ -209,3 +209,69 @@ def test_one_structure_static_evaluation_against_the_fp64_one(pusher_model):
     eHa, eHb, ega, egb = err(Ha, Hd), err(Hb, Hd), err(ga, gd), err(gb, gd)
     assert np.median(eHa) < 2e-6 and eHa.max() < 1e-3 and np.median(ega) < 1e-5 and ega.max() < 1e-2, (np.median(eHa), eHa.max(), np.median(ega), ega.max())
     assert np.median(eHa) < 3 * np.median(eHb) + 1e-7 and np.median(ega) < 3 * np.median(egb) + 1e-7
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_structure_static_kernels_on_randomly_scaled_parameters_follow_the_oracle(pusher_model, seed):
+    """Every float record of pusher.xml's blob that is a PARAMETER or a non-trivial geometric value — masses, centres of mass, inertias, joint and
+    primitive positions, end-effector offsets, dampings, limits, motor records, primitive sizes, contact and tactile parameters, contact points and
+    taxel positions — scaled by its own random factor (frames' rotations and axes are left alone: scaled they would not be rotations): the
+    batch keeps the compiled-in STRUCTURE (`param:pusher`), and the fp64 structure-static kernels land on the oracle's trajectory and gradient."""
+    import copy
+    from oracle.oracle import OracleSim
+    rng = np.random.default_rng(400 + seed)
+    m = copy.deepcopy(pusher_model)
+    I, F = m.I, m.F
+    nl, nr_, nu_ = int(I[BL.TSIM_IH_NL]), int(I[BL.TSIM_IH_NR]), int(I[BL.TSIM_IH_NU])
+    fac = lambda n=1: rng.uniform(0.8, 1.25, size=n)
+    for l_ in range(nl):
+        o_ = int(I[BL.TSIM_IH_FOFF_LINK]) + l_ * BL.TSIM_LF_SIZE
+        F[o_ + BL.TSIM_LF_P:o_ + BL.TSIM_LF_P + 3] *= fac(3)
+        k = fac()[0]
+        F[o_ + BL.TSIM_LF_MASS] *= k
+        F[o_ + BL.TSIM_LF_INERTIA:o_ + BL.TSIM_LF_INERTIA + 6] *= k
+        F[o_ + BL.TSIM_LF_COM:o_ + BL.TSIM_LF_COM + 3] *= fac(3)
+    for d in range(nr_):
+        o_ = int(I[BL.TSIM_IH_FOFF_DOF]) + d * BL.TSIM_DF_SIZE
+        F[o_:o_ + BL.TSIM_DF_SIZE] *= fac(BL.TSIM_DF_SIZE)
+    for k_ in range(nu_):
+        o_ = int(I[BL.TSIM_IH_FOFF_MOTOR]) + k_ * BL.TSIM_MF_SIZE
+        F[o_:o_ + BL.TSIM_MF_SIZE] *= fac(BL.TSIM_MF_SIZE)
+    for v_ in range(int(I[BL.TSIM_IH_NVAR])):
+        o_ = int(I[BL.TSIM_IH_FOFF_VAR]) + v_ * BL.TSIM_VF_SIZE
+        F[o_:o_ + 3] *= fac(3)
+    for p_ in range(int(I[BL.TSIM_IH_NPAIR])):
+        o_ = int(I[BL.TSIM_IH_FOFF_PAIR]) + p_ * BL.TSIM_PF_SIZE
+        F[o_ + BL.TSIM_PF_P:o_ + BL.TSIM_PF_P + 3] *= fac(3)
+        F[o_ + BL.TSIM_PF_SHAPE:o_ + BL.TSIM_PF_SIZE] *= fac(BL.TSIM_PF_SIZE - BL.TSIM_PF_SHAPE)
+    for s_ in range(int(I[BL.TSIM_IH_NSENSOR])):
+        o_ = int(I[BL.TSIM_IH_FOFF_SENSOR]) + s_ * BL.TSIM_SF_SIZE
+        F[o_:o_ + BL.TSIM_SF_SIZE] *= fac(BL.TSIM_SF_SIZE)
+    ncpt, ntax = int(I[BL.TSIM_IH_NCPT]), int(I[BL.TSIM_IH_NTAXEL])
+    F[int(I[BL.TSIM_IH_FOFF_CPT]):int(I[BL.TSIM_IH_FOFF_CPT]) + 3 * ncpt] *= fac(3 * ncpt)
+    F[int(I[BL.TSIM_IH_FOFF_TAXEL]):int(I[BL.TSIM_IH_FOFF_TAXEL]) + 3 * ntax] *= rng.uniform(0.95, 1.05, size=3 * ntax)      # (taxel positions only)
+    F[BL.TSIM_FH_TOL] = 1e-12
+    B, T, S = 16, 6, 5
+    q0, u, _ = push_workload(B, T, seed=60 + seed)
+    dt = torch.float64
+    sim = BatchSim(m, B, dtype=dt, tape_capacity=T * S)
+    assert sim.kernel_variant() == "param:pusher" and BatchSim(m, 4, dtype=torch.float32, tape_capacity=4).kernel_variant() == "param:pusher"
+    sim.reset(torch.tensor(q0, device=DEV, dtype=dt), None, backward_flag=True)
+    outs = [sim.step(torch.tensor(u[:, t], device=DEV, dtype=dt), S) for t in range(T)]
+    wq = rng.normal(size=(B, 7))
+    wt = rng.normal(size=(B, 390))
+    du = sim.backward_steps(T * S, df_dq=torch.tensor(wq, device=DEV, dtype=dt), df_dtactile=torch.tensor(wt, device=DEV, dtype=dt)).cpu().numpy()
+    o = OracleSim(m)
+    n = T * S
+    for e in range(0, B, 4):
+        o.reset(q0[e], record=True)
+        for t in range(T):
+            bad = o.forward(u[e, t], S)
+            assert bad == 0 and int(outs[t]["status"][e]) == 0, (seed, e, t)
+            q, _ = o.state()
+            var, tac = o.outputs()
+            assert np.abs(outs[t]["q"][e].cpu().numpy() - q).max() < 1e-9, (seed, e, t)
+            assert np.abs(outs[t]["var"][e].cpu().numpy() - var).max() < 1e-9
+            assert np.abs(outs[t]["tactile"][e].cpu().numpy() - tac).max() < 1e-8 * (1.0 + np.abs(tac).max())
+        g = o.backward_steps(n, df_dq=np.concatenate([np.zeros((n - 1) * 7), wq[e]]), df_dtac=np.concatenate([np.zeros((n - 1) * 390), wt[e]]))
+        assert np.abs(du[e].reshape(n, 6) - g).max() < 1e-7 * (1.0 + np.abs(g).max()), (seed, e, np.abs(du[e].reshape(n, 6) - g).max(), np.abs(g).max())
