@@ -75,8 +75,11 @@ struct XParser {
     }
     return o;
   }
+  int depth = 0;
   std::unique_ptr<XNode> element() {
     if (i >= s.size() || s[i] != '<') bad("'<' expected");
+    struct Depth { int& d; explicit Depth(int& d_) : d(d_) { ++d; } ~Depth() { --d; } } guard(depth);
+    if (depth > 256) bad("elements nested deeper than 256");
     ++i;
     auto n = std::make_unique<XNode>();
     n->tag = name();

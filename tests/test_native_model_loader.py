@@ -338,6 +338,7 @@ def test_blob_file_round_trip(model_dir, tmp_path):
     ("<redmax><robot><link name='l'><joint name='j' type='revolute'/><body name='b' type='mesh' filename='missing.obj'/></link></robot></redmax>", "cannot open mesh"),
     ("<redmax><robot><link name='l'>", "XML"),
     ("<redmax><option integrator='RK4'/></redmax>", "integrator 'RK4'"),
+    ("<redmax>" + "<a>" * 5000 + "</a>" * 5000 + "</redmax>", "nested deeper than 256"),
 ])
 def test_bad_models_fail_with_a_reason(tmp_path, text, msg):
     p = tmp_path / "bad.xml"
