@@ -3,8 +3,9 @@ ground and general-primitive contacts, force and position motors, rect_array sen
 tests/test_native_model_loader.py, which holds the two model compilers against each other on the same models).  The fixed models of the other GPU
 tests cover the structures the reference's assets have; this covers the ones they do not (a planar joint under a tilted revolute, prismatic chains,
 several sensors on one link ...).  fp64 generic kernels, a few env-steps from rest under random controls: state, variables, tactile frame and the
-adjoint of a random functional, to the oracle.  (fp32 kernels are not run here: with the models' random scales a third of them cannot reach the
-random `tol` in single precision and flag the sub-step — the fp32 envelope is the reference's assets, tests/test_gpu_parity.py.)"""
+adjoint of a random functional, to the oracle.  (fp32 kernels: with the models' random scales a third of them cannot reach the drawn `tol` in
+single precision and flag the sub-step — the last test of the file runs them with `tol` 1e-5 and bounds the error distribution; the fp32 envelope
+proper is the reference's assets, tests/test_gpu_parity.py.)"""
 import os
 import sys
 
@@ -271,3 +272,45 @@ def test_reference_call_sequence_on_random_model_files(seed, tmp_path):
         z = lambda c, d: np.concatenate([np.zeros((Sn - 1) * d), c]) if d else None
         go = o.backward_steps(Sn, z(cq, nr), z(cv, nv), z(ct, nt)).sum(0)
         assert np.abs(acts[t].grad.numpy() - go).max() < 1e-6 * max(np.abs(go).max(), 1e-3), (seed, t)
+
+
+def test_fp32_kernels_on_the_random_models_in_distribution(tmp_path):
+    """The fp32 generic kernels against the fp64 oracle on all 120 random models, with `tol` relaxed to 1e-5 (what single precision can reach on models
+    of arbitrary scale: with the drawn 1e-9 a third of them flag their sub-steps, which is why the per-model tests above are fp64).  A distribution,
+    not a per-model bound — a loose root of an ill-conditioned model is the root to 1e-3 only: measured (tools/random_model_fp32_probe.py) relative
+    state error median 9e-9, 90 % 8e-8, 99 % 1e-5, max 4e-3 over 1029 env-steps; tactile frames to 7e-7; 4 of 1046 env-steps flagged by one side only."""
+    import tactilesimulation_amd.model.blob as BL
+    from oracle.oracle import OracleSim
+    from tactilesimulation_amd.host.batch import BatchSim
+    dq, dtac, one_sided, total = [], [], 0, 0
+    for seed in range(N_MODELS):
+        try:
+            m, rng = _case(1000 + seed, tmp_path)
+        except BaseException:      # (pytest.skip inside _case)
+            continue
+        m.F[BL.TSIM_FH_TOL] = 1e-5
+        nr, nu = m.ndof_r, m.ndof_u
+        q0 = 0.02 * rng.normal(size=(B_, nr))
+        u = rng.uniform(-1, 1, size=(B_, T, max(nu, 1)))[:, :, :nu]
+        sim = BatchSim(m, B_, dtype=torch.float32, tape_capacity=T * S)
+        sim.reset(torch.tensor(q0, device="cuda:0", dtype=torch.float32), None, backward_flag=False)
+        outs = [sim.step(torch.tensor(u[:, t], device="cuda:0", dtype=torch.float32).reshape(B_, nu), S) for t in range(T)]
+        o = OracleSim(m)
+        for e in range(B_):
+            o.reset(q0[e])
+            for t in range(T):
+                bad = o.forward(u[e, t], S) != 0
+                kbad = int(outs[t]["status"][e]) != 0
+                q, _ = o.state()
+                total += 1
+                if bad or kbad or not np.all(np.isfinite(q)):
+                    one_sided += bad != kbad
+                    break
+                dq.append(np.abs(outs[t]["q"][e].double().cpu().numpy() - q).max() / (1.0 + np.abs(q).max()))
+                if m.ndof_tactile:
+                    tac = o.outputs()[1]
+                    dtac.append(np.abs(outs[t]["tactile"][e].double().cpu().numpy() - tac).max() / (1.0 + np.abs(tac).max()))
+    dq, dtac = np.array(dq), np.array(dtac)
+    assert len(dq) >= 950 and one_sided <= 0.02 * total, (len(dq), one_sided, total)
+    assert np.quantile(dq, 0.5) < 1e-6 and np.quantile(dq, 0.9) < 1e-5 and np.quantile(dq, 0.99) < 1e-3 and dq.max() < 5e-2, [float(np.quantile(dq, x)) for x in (0.5, 0.9, 0.99, 1.0)]
+    assert len(dtac) > 100 and np.quantile(dtac, 0.99) < 1e-4 and dtac.max() < 1e-2, [float(np.quantile(dtac, x)) for x in (0.5, 0.99, 1.0)]
