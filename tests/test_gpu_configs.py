@@ -381,4 +381,9 @@ def test_adjoint_properties_at_full_size(pusher_model, dtype, tol):
     assert torch.equal(grad(s1), d1)                                                        # deterministic
     small = BatchSim(pusher_model, 1024, dtype=dtype, tape_capacity=T * S)
     small.set_lanes_per_env(sim.launch_info()["lanes_per_env"])                             # the same launch shape: the same summation orders
+    if dtype == torch.float64 and os.environ.get("TSIM_LPE") == "16":
+        # the suite under a forced 16-lane shape: `sim` (forced by the environment) runs the generic fp64 kernels, `small` (forced to the fall-back
+        # shape by the line above) the compiled-in ones — two kernels, equal to round-off, not to the bit
+        assert torch.allclose(grad(s1, small, 1024), d1[:, :1024], rtol=0, atol=1e-7 * float(d1.abs().max()))
+        return
     assert torch.equal(grad(s1, small, 1024), d1[:, :1024])                                 # batch-composition independent

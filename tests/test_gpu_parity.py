@@ -51,6 +51,8 @@ def _batch(model, B, dtype, cap=64, lanes=0, kernels="default"):
         sim.set_env_tables(sim.base_tables())
     if not os.environ.get("TSIM_NO_STATIC"):
         want = {"default": ("static:pusher", "param:pusher"), "generic": ("generic",), "tables": ("param:pusher",) if dtype == torch.float32 else ("generic",)}[kernels]
+        if dtype == torch.float64 and os.environ.get("TSIM_LPE") == "16":      # an fp64 batch FORCED to 16 lanes per environment has no compiled-in instantiation (include/tsim.h)
+            want = want + ("generic",)
         assert sim.kernel_variant() in want, (kernels, sim.kernel_variant())
     if lanes:
         sim.set_lanes_per_env(lanes)

@@ -161,6 +161,9 @@ def test_static_kernels_switch_off_for_other_blobs_shapes_and_tables(pusher_mode
     sim.update_model(pusher_model)
     assert sim.kernel_variant() == "generic"                            # tsim_set_static(0) survives a model update
     d = BatchSim(pusher_model, B, dtype=torch.float64, tape_capacity=0)      # fp64 (round 5): the same two instantiations, two or one environments per wavefront
+    if os.environ.get("TSIM_LPE") == "16":      # (the suite under a forced 16-lane shape: fp64 has no compiled-in instantiation there, the generic kernels run)
+        assert d.static_model() == 0 and d.kernel_variant() == "generic"
+        return
     assert d.static_model() == 1 and d.kernel_variant() == "static:pusher" and d.launch_info()["lanes_per_env"] in (32, 64)
     d.update_model(m)
     assert d.kernel_variant() == "param:pusher"
@@ -174,6 +177,8 @@ def test_fp64_static_kernels_against_the_generic_fp64_ones(pusher_model, edited)
     """The fp64 instantiations of the compiled-in TactilePush kernels (fully static; structure-static on an edited model) against the generic fp64
     kernels — the ones tests/test_gpu_literal.py walks the oracle's iterates with: the same arithmetic up to the order of a few sums, so states to
     1e-11, tactile forces to 1e-9 of their maximum, the same Newton work in all but a handful of environments, episode gradients to 1e-7."""
+    if os.environ.get("TSIM_LPE") == "16":
+        pytest.skip("fp64 batches forced to 16 lanes per environment run the generic kernels: nothing to compare")
     B, T, S = 1024, 12, 5
     m = pusher_model
     if edited:
@@ -229,5 +234,6 @@ def test_a_blob_that_differs_below_float_resolution_is_the_compiled_in_model_to_
         outs.append((o["q"], o["tactile"], g[0] if isinstance(g, (tuple, list)) else g))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
-    assert BatchSim(m, 8, dtype=torch.float64, tape_capacity=8).kernel_variant() == "param:pusher"
-    assert BatchSim(pusher_model, 8, dtype=torch.float64, tape_capacity=8).kernel_variant() == "static:pusher"
+    f16 = os.environ.get("TSIM_LPE") == "16"      # (forced 16 lanes: fp64 runs the generic kernels)
+    assert BatchSim(m, 8, dtype=torch.float64, tape_capacity=8).kernel_variant() == ("generic" if f16 else "param:pusher")
+    assert BatchSim(pusher_model, 8, dtype=torch.float64, tape_capacity=8).kernel_variant() == ("generic" if f16 else "static:pusher")
