@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from test_native_model_loader import _random_model      # noqa: E402
 
 pytestmark = pytest.mark.gpu
-N_MODELS, B_, T, S = 120, 3, 3, 2
+N_MODELS, B_, T, S = int(os.environ.get("TSIM_RANDOM_MODELS", "120")), 3, 3, 2      # (a soak: TSIM_RANDOM_MODELS=2000 TSIM_RANDOM_SEED0=100000)
+SEED0 = int(os.environ.get("TSIM_RANDOM_SEED0", "1000"))
 
 
 def _case(seed, tmp_path, files=False):
@@ -40,7 +41,7 @@ def test_random_model_follows_the_oracle(seed, lanes, dtype, files, tmp_path):
     """files: abstract bodies with contact-point files as general bodies, abstract taxel files as sensors (the D'Claw vocabulary)"""
     from oracle.oracle import OracleSim
     from tactilesimulation_amd.host.batch import BatchSim
-    m, rng = _case(1000 + seed, tmp_path, files)
+    m, rng = _case(SEED0 + seed, tmp_path, files)
     nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
     q0 = 0.02 * rng.normal(size=(B_, nr))
     u = rng.uniform(-1, 1, size=(B_, T, max(nu, 1)))[:, :, :nu]
@@ -115,7 +116,7 @@ def test_episode_launches_equal_the_step_loop_on_random_models(seed, lanes, dtyp
     against T x tsim_step + tsim_backward_steps on the same random models — bit for bit, both precisions, ragged batch (11 environments, so that
     wavefronts carry 1 - 4 of them and the last one is partly empty), a tactile mask, per-frame seeds."""
     from tactilesimulation_amd.host.batch import BatchSim
-    m, rng = _case(1000 + seed, tmp_path)
+    m, rng = _case(SEED0 + seed, tmp_path)
     nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
     B2, T2, S2 = 11, 4, 3
     dev = "cuda:0"
@@ -171,7 +172,7 @@ def test_per_environment_tables_equal_separately_edited_models_on_random_models(
     import copy
     import tactilesimulation_amd.model.blob as BL
     from tactilesimulation_amd.host.batch import BatchSim
-    m, rng = _case(1000 + seed, tmp_path)
+    m, rng = _case(SEED0 + seed, tmp_path)
     nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
     Bt, Tt, St = 5, 3, 2
     dev, dt = "cuda:0", torch.float64
@@ -240,11 +241,11 @@ def test_reference_call_sequence_on_random_model_files(seed, tmp_path):
     import redmax_py as redmax
     from oracle.oracle import OracleSim
     from tactilesimulation_amd.functions import StepSimFunction
-    m, rng = _case(1000 + seed, tmp_path, files=True)
+    m, rng = _case(SEED0 + seed, tmp_path, files=True)
     nr, nu, nv, nt = m.ndof_r, m.ndof_u, m.ndof_var, m.ndof_tactile
     if nu == 0:
         pytest.skip("no motor in this model")
-    sim = redmax.Simulation(str(tmp_path / ("m%d.xml" % (1000 + seed))))
+    sim = redmax.Simulation(str(tmp_path / ("m%d.xml" % (SEED0 + seed))))
     assert (sim.ndof_r, sim.ndof_u, sim.ndof_var, sim.ndof_tactile) == (nr, nu, nv, nt) and sim.options.h == m.h
     q0 = 0.02 * rng.normal(size=nr)
     Tn, Sn = 3, 2
@@ -285,7 +286,7 @@ def test_fp32_kernels_on_the_random_models_in_distribution(tmp_path):
     dq, dtac, one_sided, total = [], [], 0, 0
     for seed in range(N_MODELS):
         try:
-            m, rng = _case(1000 + seed, tmp_path)
+            m, rng = _case(SEED0 + seed, tmp_path)
         except BaseException:      # (pytest.skip inside _case)
             continue
         m.F[BL.TSIM_FH_TOL] = 1e-5

@@ -14,7 +14,7 @@ B_, T, S = 3, 3, 2
 rows = []
 for seed in range(N):
     try:
-        m, rng = TR._case(1000 + seed, pathlib.Path(tempfile.mkdtemp()))
+        m, rng = TR._case(TR.SEED0 + seed, pathlib.Path(tempfile.mkdtemp()))
     except BaseException:
         continue
     m.F[BL.TSIM_FH_TOL] = tol

@@ -9,7 +9,7 @@ from tactilesimulation_amd.host.batch import BatchSim
 from oracle.oracle import OracleSim
 import test_gpu_random_models as TR
 seed, e = int(sys.argv[1]), int(sys.argv[2])
-m, rng = TR._case(1000 + seed, pathlib.Path(tempfile.mkdtemp()))
+m, rng = TR._case(TR.SEED0 + seed, pathlib.Path(tempfile.mkdtemp()))
 nr, nu = m.ndof_r, m.ndof_u
 B_, T = TR.B_, TR.T
 q0 = 0.02 * rng.normal(size=(B_, nr)); u = rng.uniform(-1, 1, size=(B_, T, max(nu, 1)))[:, :, :nu]
