@@ -279,7 +279,10 @@ def test_fp32_kernels_on_the_random_models_in_distribution(tmp_path):
     """The fp32 generic kernels against the fp64 oracle on all 120 random models, with `tol` relaxed to 1e-5 (what single precision can reach on models
     of arbitrary scale: with the drawn 1e-9 a third of them flag their sub-steps, which is why the per-model tests above are fp64).  A distribution,
     not a per-model bound — a loose root of an ill-conditioned model is the root to 1e-3 only: measured (tools/random_model_fp32_probe.py) relative
-    state error median 9e-9, 90 % 8e-8, 99 % 1e-5, max 4e-3 over 1029 env-steps; tactile frames to 7e-7; 4 of 1046 env-steps flagged by one side only."""
+    state error median 9e-9, 90 % 8e-8, 99 % 1e-5, max 4e-3 over 1029 env-steps; tactile frames to 7e-7; 4 of 1046 env-steps flagged by one side only.
+    Over 1500 more models (13 272 env-steps: the same quantiles) two environments land on ANOTHER root of their first sub-step — one through the fp32
+    default's kink crossing (the one solver option the reference does not have: with it off the kernel is on the oracle's root), one after a 476-evaluation
+    struggle in single precision (tools/random_model_fp32_case.py) — hence a bound on the share of such env-steps, not on the maximum."""
     import tactilesimulation_amd.model.blob as BL
     from oracle.oracle import OracleSim
     from tactilesimulation_amd.host.batch import BatchSim
@@ -313,5 +316,5 @@ def test_fp32_kernels_on_the_random_models_in_distribution(tmp_path):
                     dtac.append(np.abs(outs[t]["tactile"][e].double().cpu().numpy() - tac).max() / (1.0 + np.abs(tac).max()))
     dq, dtac = np.array(dq), np.array(dtac)
     assert len(dq) >= 950 and one_sided <= 0.02 * total, (len(dq), one_sided, total)
-    assert np.quantile(dq, 0.5) < 1e-6 and np.quantile(dq, 0.9) < 1e-5 and np.quantile(dq, 0.99) < 1e-3 and dq.max() < 5e-2, [float(np.quantile(dq, x)) for x in (0.5, 0.9, 0.99, 1.0)]
+    assert np.quantile(dq, 0.5) < 1e-6 and np.quantile(dq, 0.9) < 1e-5 and np.quantile(dq, 0.99) < 1e-3 and (dq > 1e-2).mean() <= 2e-3, [float(np.quantile(dq, x)) for x in (0.5, 0.9, 0.99, 1.0)]
     assert len(dtac) > 100 and np.quantile(dtac, 0.99) < 1e-4 and dtac.max() < 1e-2, [float(np.quantile(dtac, x)) for x in (0.5, 0.99, 1.0)]
